@@ -1,0 +1,58 @@
+"""Helpers to read the golden fixtures written by tools/make_goldens.py."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = ['g1_onestep_p0', 'g2_onestep_p06', 'g3_multistep', 'g4_replace', 'g5_F_pfratio', 'g6_zeros',
+         'g7_cosine', 'g8_klquirk']
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + '.npz'))
+        self.meta = json.loads(bytes(self.z['meta']).decode())
+        self.name = name
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    def data(self):
+        return [self.z['data0'].astype(np.float64), self.z['data1'].astype(np.float64)]
+
+    def state(self, prefix):
+        pre = prefix + '.'
+        return {k[len(pre):]: torch.from_numpy(self.z[k]) for k in self.z.files if k.startswith(pre)}
+
+    def noise(self, s, dtype=torch.float32):
+        m = self.meta
+        p = m['p']
+        dims, B = m['dims'], m['B']
+        out = {'enc_masks': [], 'dec_masks': [], 'eps': []}
+        for i, d in enumerate(dims):
+            out['eps'].append(torch.from_numpy(self.z[f's{s}.eps{i}']).to(dtype))
+            if p > 0:
+                widths_e = [2 * d, d]
+                widths_d = [d, 2 * d]
+                out['enc_masks'].append([torch.from_numpy(
+                    np.unpackbits(self.z[f's{s}.encmask{i}{j}'], axis=1)[:, :widths_e[j]].copy()).to(dtype)
+                    for j in range(2)])
+                out['dec_masks'].append([torch.from_numpy(
+                    np.unpackbits(self.z[f's{s}.decmask{i}{j}'], axis=1)[:, :widths_d[j]].copy()).to(dtype)
+                    for j in range(2)])
+            else:
+                out['enc_masks'].append([None, None])
+                out['dec_masks'].append([None, None])
+        return out
+
+    def step_indices(self, s):
+        """Index arrays of step s (one np.random.choice call per step for 'diag', two for 'zeros')."""
+        ch = self.z['choice']
+        if self.meta['sampling_method'] == 'diag':
+            return [ch[s], ch[s]]
+        return [ch[2 * s], ch[2 * s + 1]]

@@ -1,0 +1,159 @@
+"""Pin the CPU oracle (oracle/jamie_oracle.py) against golden vectors produced by the reference itself
+(tools/make_goldens.py).  CPU-only."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import jamie_oracle as orc
+from golden_util import CASES, Golden
+
+
+def _ctor(meta):
+    c = dict(meta['ctor'])
+    kw = dict(output_dim=meta['L'], batch_size=meta['B'] if meta['B'] <= max(meta['rows']) else meta['B'],
+              epoch_DNN=meta['epochs'])
+    for k in ('dropout', 'PF_Ratio', 'loss_weights', 'dist_method', 'min_epochs', 'model_lr'):
+        if k in c:
+            kw[k] = c[k]
+    return kw
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_init_matches_reference(name):
+    g = Golden(name)
+    torch.manual_seed(666)
+    P, Bf = orc.init_state(g.meta['dims'], g.meta['L'])
+    ref = g.state('init')
+    assert orc.param_count(g.meta['dims'], g.meta['L']) == sum(v.numel() for v in P.values())
+    for k, v in P.items():
+        assert torch.equal(v, ref[k]), k
+    for k, v in Bf.items():
+        assert torch.equal(v, ref[k]), k
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_full_loop_replay(name):
+    """Same seeds -> the restated loop (sampler, noise order, losses, clip, Adam, early-stop bookkeeping,
+    final eval embedding, transform, modal_predict) reproduces the reference run."""
+    g = Golden(name)
+    m = g.meta
+    kw = _ctor(m)
+    if m['has_F']:
+        kw['match_result'] = [g['F']]
+    o = orc.OracleJAMIE(**kw)
+    np.random.seed(m['np_seed'])
+    if m['rows'][0] != m['rows'][1]:
+        data = [g['data0'].astype(np.float64), g['data1'].astype(np.float64)]
+    else:
+        data = g.data()
+    emb = o.fit_transform(data, P=g['P'] if m['has_P'] else None, record_trace=True)
+    # sampler stream
+    ch = g['choice']
+    flat = [i for t in o.trace for i in (t['idx'][:1] if m['sampling_method'] == 'diag' else t['idx'])]
+    assert len(flat) == len(ch)
+    for a, b in zip(flat, ch):
+        assert np.array_equal(a, b)
+    # noise stream
+    for s in range(m['noise_steps']):
+        gn = g.noise(s)
+        for i in range(2):
+            assert torch.equal(o.trace[s]['noise']['eps'][i], gn['eps'][i])
+            if m['p'] > 0:
+                for j in range(2):
+                    assert torch.equal(o.trace[s]['noise']['enc_masks'][i][j], gn['enc_masks'][i][j])
+                    assert torch.equal(o.trace[s]['noise']['dec_masks'][i][j], gn['dec_masks'][i][j])
+    assert torch.allclose(o.trace[0]['corr'], torch.from_numpy(g['s0.corr']), atol=0, rtol=0)
+    lh = np.array([o.loss_history[k] for k in m['loss_names']])
+    np.testing.assert_allclose(lh, g['loss_history'], rtol=2e-5, atol=1e-7)
+    for i in range(2):
+        np.testing.assert_allclose(emb[i], g[f'emb{i}'], rtol=1e-4, atol=1e-5)
+    tr = o.transform(data)
+    for i in range(2):
+        np.testing.assert_allclose(tr[i], g[f'transform{i}'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(tr[i], g[f'transform_one{i}'], rtol=1e-4, atol=1e-5)
+        imp = o.modal_predict(data[i], i)
+        assert imp.dtype == np.float64
+        np.testing.assert_allclose(imp, g[f'impute_from{i}'], rtol=1e-4, atol=1e-5)
+    # final weights (dead pre-BN biases excluded: Adam amplifies rounding noise there)
+    fin = g.state('final')
+    for k, v in o.P_.items():
+        if orc.is_dead_bias(k):
+            continue
+        np.testing.assert_allclose(v.detach().numpy(), fin[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    for k, v in o.Bf.items():
+        np.testing.assert_allclose(v.numpy(), fin[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_first_step_explicit_noise(name):
+    """One step driven by the fixture's explicit noise/indices: internals and pre-clip gradients."""
+    g = Golden(name)
+    m = g.meta
+    P = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in g.state('init').items()
+                    if not ('running' in k or 'num_batches' in k))
+    Bf = OrderedDict((k, v.clone()) for k, v in g.state('init').items()
+                     if ('running' in k or 'num_batches' in k))
+    X = [torch.from_numpy(g[f's0.X{i}']) for i in range(2)]
+    idx = g.step_indices(0)
+    # the batch the reference fed to the model == standardised data rows at the recorded indices
+    for i in range(2):
+        d = g[f'data{i}'].astype(np.float64)
+        pc = orc.Preclass(d, axis=0)
+        np.testing.assert_array_equal(torch.from_numpy(pc.transform(d)).float().numpy()[idx[i]], X[i].numpy())
+    corr = torch.from_numpy(g['s0.corr'])
+    PF = m['ctor'].get('PF_Ratio') or 1
+    Fm = torch.from_numpy(g['F']) if m['has_F'] else None
+    Pm = torch.zeros(m['rows'][0], m['rows'][1]) if m['sampling_method'] == 'zeros' else None
+    Fblk = orc.f_block(Fm, idx[0], idx[1], m['B'])
+    corr2 = PF * orc.p_block(Pm, idx[0], idx[1]) + (1 - PF) * Fblk
+    assert torch.equal(corr2, corr)
+    c = m['ctor']
+    anneal = orc.kl_anneal(0, c.get('min_epochs', 2500), m['epochs'])
+    st = orc.train_step(P, Bf, None, X, corr, Fblk, g.noise(0), m['p'], anneal,
+                        c.get('loss_weights'), c.get('dist_method', 'euclidean'),
+                        do_step=False, return_grads=True)
+    for i in range(2):
+        np.testing.assert_allclose(st['zs'][i].numpy(), g[f's0.z{i}'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st['combined'][i].numpy(), g[f's0.comb{i}'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st['mus'][i].numpy(), g[f's0.mu{i}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st['logvar'].numpy(), g['s0.logvar'], rtol=1e-5, atol=1e-6)
+    for k, gr in st['grads'].items():
+        ref = g['grad0.' + k] if ('grad0.' + k) in g else np.zeros_like(gr.numpy())
+        if orc.is_dead_bias(k):
+            assert np.abs(gr.numpy()).max() < 1e-5
+            continue
+        np.testing.assert_allclose(gr.numpy(), ref, rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+def test_kl_quirk_gradient_rows():
+    """fc_vars of modality 0 gets no KL gradient; the last modality's only via batch rows 0 and 1
+    (SURVEY.md §7).  Witness: with eps = 0 the reparameterisation carries no logvar gradient, so the
+    fc_vars gradients come from the KL term alone."""
+    torch.manual_seed(3)
+    dims, L, B = (6, 5), 3, 8
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    X = [torch.randn(B, d) for d in dims]
+    noise = {'enc_masks': [(None, None)] * 2, 'dec_masks': [(None, None)] * 2,
+             'eps': [torch.zeros(B, L), torch.zeros(B, L)]}
+    st = orc.train_step(P, Bf, None, X, torch.eye(B), torch.zeros(B, B), noise, 0., 1.0,
+                        do_step=False, return_grads=True)
+    assert st['grads']['fc_vars.0.weight'].abs().max() == 0
+    assert st['grads']['fc_vars.1.weight'].abs().max() > 0
+    # rows >= 2 do not contribute: perturbing them leaves the gradient unchanged
+    X2 = [x.clone() for x in X]
+    st2 = orc.train_step(P, Bf, None, X2, torch.eye(B), torch.zeros(B, B), noise, 0., 1.0,
+                         do_step=False, return_grads=True)
+    assert torch.equal(st['grads']['fc_vars.1.bias'], st2['grads']['fc_vars.1.bias'])
+
+
+def test_identity_P_is_index_equality():
+    rng = np.random.default_rng(0)
+    N = 50
+    idx0 = rng.integers(0, N, 20)
+    idx1 = rng.integers(0, N, 20)
+    dense = orc.p_block(torch.eye(N), idx0, idx1)
+    assert torch.equal(dense, orc.p_block(None, idx0, idx1))
