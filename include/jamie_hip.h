@@ -1,0 +1,175 @@
+/* jamie_hip.h — C ABI of libjamie_hip.so: the MI355X (gfx950) kernels behind JAMIE's coupled-VAE
+ * training / inference hot path.
+ *
+ * The reference (Oafish1/JAMIE v4.4.5) is pure Python on PyTorch ATen CPU kernels and has no FFI of its
+ * own; its seam for this path is the duck-typed `model_class=` protocol (jamie/jamie.py:47,71,472-479,611)
+ * plus the per-step ATen ops listed in SURVEY.md §2.1 (K1..K15).  Each entry point below replaces one
+ * group of those ATen dispatches; the citation names the reference call site(s) it stands in for.
+ * INTEGRATION.md shows the ctypes binding a JAMIE maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked host;
+ *   - the caller (PyTorch) owns all buffers; no entry point allocates, frees or synchronises;
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as void*), so calls are
+ *     capturable into a hipGraph;
+ *   - return value: 0 on success, <0 for an argument error, >0 a hipError_t; the message is available
+ *     from jamie_last_error() (thread-local);
+ *   - matrices are row-major fp32 with explicit leading dimensions (elements);
+ *   - `rng` = device uint64[4] {seed, step, reserved, reserved}: counter-based Philox4x32-10 streams are
+ *     derived from (seed, step, stream id, element index), so forward and backward regenerate identical
+ *     dropout masks without storing them.  Tests pass explicit masks / noise instead.
+ */
+#ifndef JAMIE_HIP_H
+#define JAMIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JAMIE_MAX_GROUP 4      /* problems per grouped launch (modalities) */
+
+const char* jamie_last_error(void);
+int jamie_version(void);
+/* number of fp32 loss partial slots a GEMM epilogue / latent kernel may write (sizing helper) */
+int jamie_max_partials(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM (fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32).  Replaces every nn.Linear forward
+ * (`addmm`, model.py:151,161,180,185,192,197,207) and its two autograd backward products
+ * (jamie.py:734).  C[M,N] = op(A)[M,K] * op(B)[K,N]:
+ *   layout JAMIE_NT: A is [M,K] (lda), B is [N,K] (ldb)   -> y  = x  W^T      (forward)
+ *   layout JAMIE_NN: A is [M,K] (lda), B is [K,N] (ldb)   -> dx = dy W        (input gradient)
+ *   layout JAMIE_TN: A is [K,M] (lda), B is [K,N] (ldb)   -> dW = dy^T x      (weight gradient)
+ * ------------------------------------------------------------------------------------------- */
+enum { JAMIE_NT = 0, JAMIE_NN = 1, JAMIE_TN = 2 };
+
+enum {
+    JAMIE_EPI_STORE   = 0, /* C = acc (+ bias[n])                                  (+= if accumulate) */
+    JAMIE_EPI_MSE     = 1, /* d = acc + bias[n] - X[m,n]; C = d * scale; partial[block] = sum d^2
+                              (Rec loss + its gradient, jamie.py:637-641; aux0 = X, ld aux_ld)        */
+    JAMIE_EPI_BN_EVAL = 2, /* eval-mode Linear+BatchNorm1d+LeakyReLU: y = (acc + bias - aux0[n]) *
+                              rsqrt(aux1[n] + eps) * aux2[n] + aux3[n]; C = y > 0 ? y : slope*y
+                              (aux0..3 = running_mean, running_var, gamma, beta)                       */
+};
+
+typedef struct {
+    const float* A; const float* B; float* C;
+    const float* bias;          /* [N] or NULL */
+    const float* aux0; const float* aux1; const float* aux2; const float* aux3;
+    float* partial;             /* per-block fp32 partial sums (EPI_MSE) or NULL */
+    const int32_t* a_rows;      /* optional row gather for A (NT/NN: A row m -> a_rows[m]) or NULL */
+    int M, N, K;
+    int lda, ldb, ldc, aux_ld;
+    int splitk;                 /* >= 1; slab s is written at C + s * slab_stride (no bias unless s==0) */
+    long long slab_stride;
+    int epi; int accumulate;
+    float scale; float slope; float eps;
+    float pscale;               /* EPI_MSE: partial[block] = pscale * sum d^2 (e.g. w_rec / (B*d)) */
+} jamie_gemm_problem;
+
+/* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */
+int jamie_gemm_f32(const jamie_gemm_problem* problems /*host*/, int count, int layout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm1d(train) + LeakyReLU + Dropout, forward and backward, one column strip per workgroup.
+ * Replaces native_batch_norm / leaky_relu / bernoulli_ + mul (model.py:152-154,162-164,193-195,198-200)
+ * and their backward.  h may arrive as `nslab` split-K slabs (summed here; slab 0 receives the sum).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* h; int nslab; long long slab_stride;      /* pre-BN activations [B,N] (in/out: summed)   */
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;         /* updated in place (momentum, unbiased var)   */
+    float* save_mean; float* save_invstd;            /* [N] each, for the backward pass             */
+    float* out;                                      /* [B,N] activation after dropout              */
+    const uint8_t* mask;                             /* explicit 0/1 keep mask [B,N] or NULL (RNG)  */
+    int B, N; int rng_stream;
+} jamie_bnact_fwd_problem;
+
+int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* problems /*host*/, int count, float p_drop,
+                     float momentum, float eps, float slope, const uint64_t* rng, void* stream);
+
+typedef struct {
+    float* da; int nslab; long long slab_stride;     /* grad wrt activation out; dh is written to slab 0 */
+    const float* h; const float* gamma; const float* beta;
+    const float* save_mean; const float* save_invstd;
+    float* dgamma; float* dbeta; float* dbias_lin;   /* [N] each; dbias_lin = colsum(dh) or NULL    */
+    const uint8_t* mask;
+    int B, N; int rng_stream; int accumulate;        /* accumulate: d{gamma,beta,bias} += */
+} jamie_bnact_bwd_problem;
+
+int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* problems /*host*/, int count, float p_drop,
+                     float slope, const uint64_t* rng, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Latent block: reparameterisation (model.py:225-243), sigma-weighted combine (model.py:245-259),
+ * KL / alignment ("CosSim") / F losses and their gradients (jamie.py:618-668), two modalities.
+ * All [B,L] matrices are dense row-major with ld = L except `ml` / `dml` ([B,2L]: mu | logvar).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, L;
+    /* inputs */
+    const float* ml[2]; int ml_nslab; long long ml_slab_stride;  /* heads GEMM output slabs [B,2L]   */
+    const float* head_bias[2];                                   /* [2L]: b_mu | b_var                */
+    const float* eps_in[2];          /* explicit N(0,1) noise [B,L] or NULL -> drawn from `rng`       */
+    const float* sigma;              /* [2] */
+    const float* corr;               /* [B,B] or NULL (= identity)                                    */
+    const float* Fblk;               /* [B,B] row-normalised F block or NULL (= 0)                     */
+    const float* hyper;              /* device float[16]: [0] kl_scale (= w_kl*32e-3*anneal), [1] w_rec, [2] w_align
+                                        (= w_cos*32), [3] w_f; [8..13] = Adam block (see jamie_clip_adam)           */
+    /* saved forward state (device, caller-owned) */
+    float* mu[2]; float* lv[2]; float* z[2]; float* eps[2]; float* comb[2];
+    float* cz[2];                    /* cz[0] = C z1, cz[1] = C^T z0                                   */
+    float* rsum; float* qsum;        /* rowsum(C), colsum(C) [B]                                       */
+    float* fc1;                      /* F comb1 [B,L]                                                  */
+    float* partials;                 /* fp32 scratch, >= jamie_max_partials() * 16                     */
+    /* backward */
+    const float* dcomb[2]; int dcomb_nslab; long long dcomb_slab_stride; /* from decoder dX GEMM     */
+    float* H[2]; float* ch[2];       /* scratch [B,L]: H_i = G_i / den_i;  ch[0] = C H1, ch[1] = C^T H0 */
+    float* fte;                      /* scratch [B,L]: F^T E                                          */
+    float* dml[2];                   /* out: d(mu|logvar) [B,2L]                                      */
+    float* dsigma;                   /* out: [2]                                                       */
+    const float* rec_partials; int n_rec_partials;  /* MSE partials from the decoder GEMM epilogue   */
+    float* losses;                   /* out: device float[8]: KL, Rec, CosSim, F (weighted), total, running min(total) */
+    int cosine;                      /* dist_method == 'cosine' (jamie.py:484-494)                    */
+    int rng_stream;
+} jamie_latent;
+
+int jamie_latent_fwd(const jamie_latent* a /*host*/, const uint64_t* rng, void* stream);
+int jamie_latent_bwd(const jamie_latent* a /*host*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser: global-norm clip + Adam on one flat fp32 buffer
+ * (clip_grad_norm_(params, 1) + optim.Adam.step + zero_grad, jamie.py:739-741).
+ * `state` = device uint64[4] shared with `rng`: state[1] (step) is incremented by jamie_grad_sqnorm.
+ * hyper (device float[16], shared with jamie_latent): [8] lr, [9] beta1, [10] beta2, [11] eps, [12] max_norm,
+ * [13] grad_scale (1/world_size: the all-reduced SUM is averaged inside the update).
+ * ------------------------------------------------------------------------------------------- */
+int jamie_optim_blocks(long long n);   /* number of partials jamie_grad_sqnorm writes for n elements */
+int jamie_grad_sqnorm(const float* g, long long n, float* partials, int n_partials, uint64_t* state,
+                      void* stream);
+int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
+                    int n_partials, const float* hyper, const uint64_t* state, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batch assembly (jamie.py:552-604).
+ * ------------------------------------------------------------------------------------------- */
+/* dst[b,:] = src[idx[b],:]   (`dataset[i][random_batch[i]]`, jamie.py:583) */
+int jamie_gather_rows(const float* src, long long n_rows, int d, const int32_t* idx, int B, float* dst,
+                      void* stream);
+/* Uniform B-subset of [0,N) without replacement (replace=0) or B draws with replacement, from `rng`
+ * (device-side counterpart of np.random.choice, jamie.py:556); one workgroup, deterministic. */
+int jamie_sample_indices(int32_t* idx, int B, long long N, long long offset, int replace,
+                         const uint64_t* rng, int rng_stream, void* stream);
+/* corr[a,b] = (idx0[a] == idx1[b]) row-normalised (P = I_N block, jamie.py:586-589) */
+int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1, int B, float* corr, void* stream);
+/* out[n] (+)= sum_m X[m,n]  (bias gradients of the non-BN Linear layers) */
+int jamie_colsum(const float* X, int M, int N, int ld, int nslab, long long slab_stride, float* out,
+                 int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAMIE_HIP_H */

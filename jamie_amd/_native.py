@@ -1,0 +1,206 @@
+"""ctypes binding of libjamie_hip.so (C ABI declared in include/jamie_hip.h).
+
+There is NO CPU fallback: importing this module without the built library, or calling an op without a
+GPU, raises.  PyTorch is used only for device memory and streams; every op below receives raw device
+pointers and launches on torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libjamie_hip.so')
+
+MAX_GROUP = 4
+NT, NN, TN = 0, 1, 2
+EPI_STORE, EPI_MSE, EPI_BN_EVAL = 0, 1, 2
+
+c_f32p = C.c_void_p
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p),
+                ('aux0', C.c_void_p), ('aux1', C.c_void_p), ('aux2', C.c_void_p), ('aux3', C.c_void_p),
+                ('partial', C.c_void_p), ('a_rows', C.c_void_p),
+                ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
+                ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('aux_ld', C.c_int),
+                ('splitk', C.c_int), ('slab_stride', C.c_longlong),
+                ('epi', C.c_int), ('accumulate', C.c_int),
+                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float)]
+
+
+class BnFwdProblem(C.Structure):
+    _fields_ = [('h', C.c_void_p), ('nslab', C.c_int), ('slab_stride', C.c_longlong),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p),
+                ('out', C.c_void_p), ('mask', C.c_void_p),
+                ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int)]
+
+
+class BnBwdProblem(C.Structure):
+    _fields_ = [('da', C.c_void_p), ('nslab', C.c_int), ('slab_stride', C.c_longlong),
+                ('h', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p),
+                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dbias_lin', C.c_void_p),
+                ('mask', C.c_void_p),
+                ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int), ('accumulate', C.c_int)]
+
+
+class Latent(C.Structure):
+    _fields_ = [('B', C.c_int), ('L', C.c_int),
+                ('ml', C.c_void_p * 2), ('ml_nslab', C.c_int), ('ml_slab_stride', C.c_longlong),
+                ('head_bias', C.c_void_p * 2), ('eps_in', C.c_void_p * 2),
+                ('sigma', C.c_void_p), ('corr', C.c_void_p), ('Fblk', C.c_void_p), ('hyper', C.c_void_p),
+                ('mu', C.c_void_p * 2), ('lv', C.c_void_p * 2), ('z', C.c_void_p * 2),
+                ('eps', C.c_void_p * 2), ('comb', C.c_void_p * 2), ('cz', C.c_void_p * 2),
+                ('rsum', C.c_void_p), ('qsum', C.c_void_p), ('fc1', C.c_void_p), ('partials', C.c_void_p),
+                ('dcomb', C.c_void_p * 2), ('dcomb_nslab', C.c_int), ('dcomb_slab_stride', C.c_longlong),
+                ('H', C.c_void_p * 2), ('ch', C.c_void_p * 2), ('fte', C.c_void_p),
+                ('dml', C.c_void_p * 2), ('dsigma', C.c_void_p),
+                ('rec_partials', C.c_void_p), ('n_rec_partials', C.c_int), ('losses', C.c_void_p),
+                ('cosine', C.c_int), ('rng_stream', C.c_int)]
+
+
+EXPORTS = {
+    'jamie_last_error': (C.c_char_p, []),
+    'jamie_version': (C.c_int, []),
+    'jamie_max_partials': (C.c_int, []),
+    'jamie_gemm_f32': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
+    'jamie_bn_act_fwd': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_void_p, C.c_void_p]),
+    'jamie_bn_act_bwd': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                   C.c_void_p]),
+    'jamie_latent_fwd': (C.c_int, [C.POINTER(Latent), C.c_void_p, C.c_void_p]),
+    'jamie_latent_bwd': (C.c_int, [C.POINTER(Latent), C.c_void_p]),
+    'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
+    'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'jamie_gather_rows': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
+    'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_void_p]),
+    'jamie_corr_from_indices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_colsum': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p,
+                               C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+class JamieHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and declare every exported symbol's signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JamieHipError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  jamie_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise JamieHipError(f'libjamie_hip error {rc}: {load().jamie_last_error().decode()}')
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must already live on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise JamieHipError('jamie_amd ops need GPU tensors (no CPU fallback)')
+    return t.data_ptr()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise JamieHipError('no MI355X visible: jamie_amd runs on the GPU only (no CPU fallback)')
+    load()
+
+
+# ---------------------------------------------------------------------------------------------------
+# thin op wrappers
+# ---------------------------------------------------------------------------------------------------
+def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_stride=0, epi=EPI_STORE,
+                 accumulate=False, aux=(None, None, None, None), aux_ld=0, partial=None, a_rows=None,
+                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0):
+    p = GemmProblem()
+    p.A, p.B, p.C, p.bias = ptr(A), ptr(B), ptr(Cout), ptr(bias)
+    p.aux0, p.aux1, p.aux2, p.aux3 = (ptr(a) for a in aux)
+    p.partial, p.a_rows = ptr(partial), ptr(a_rows)
+    p.M, p.N, p.K, p.lda, p.ldb, p.ldc, p.aux_ld = M, N, K, lda, ldb, ldc, aux_ld
+    p.splitk, p.slab_stride, p.epi, p.accumulate = splitk, slab_stride, epi, int(accumulate)
+    p.scale, p.slope, p.eps, p.pscale = scale, slope, eps, pscale
+    return p
+
+
+def gemm(problems, layout):
+    arr = (GemmProblem * len(problems))(*problems)
+    _check(load().jamie_gemm_f32(arr, len(problems), layout, _stream()))
+
+
+def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01):
+    arr = (BnFwdProblem * len(problems))(*problems)
+    _check(load().jamie_bn_act_fwd(arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), _stream()))
+
+
+def bn_act_bwd(problems, p_drop, rng, slope=0.01):
+    arr = (BnBwdProblem * len(problems))(*problems)
+    _check(load().jamie_bn_act_bwd(arr, len(problems), p_drop, slope, ptr(rng), _stream()))
+
+
+def latent_fwd(desc, rng):
+    _check(load().jamie_latent_fwd(C.byref(desc), ptr(rng), _stream()))
+
+
+def latent_bwd(desc):
+    _check(load().jamie_latent_bwd(C.byref(desc), _stream()))
+
+
+def optim_blocks(n):
+    return load().jamie_optim_blocks(n)
+
+
+def grad_sqnorm(g, partials, state):
+    _check(load().jamie_grad_sqnorm(ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream()))
+
+
+def clip_adam(p, g, m, v, partials, hyper, state):
+    _check(load().jamie_clip_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),
+                                  ptr(hyper), ptr(state), _stream()))
+
+
+def gather_rows(src, idx, dst):
+    _check(load().jamie_gather_rows(ptr(src), src.shape[0], src.shape[1], ptr(idx), idx.numel(), ptr(dst),
+                                    _stream()))
+
+
+def sample_indices(idx, N, offset, replace, rng, rng_stream):
+    _check(load().jamie_sample_indices(ptr(idx), idx.numel(), N, offset, int(replace), ptr(rng), rng_stream,
+                                       _stream()))
+
+
+def corr_from_indices(idx0, idx1, corr):
+    _check(load().jamie_corr_from_indices(ptr(idx0), ptr(idx1), idx0.numel(), ptr(corr), _stream()))
+
+
+def colsum(X, M, N, ld, out, nslab=1, slab_stride=0, accumulate=False):
+    _check(load().jamie_colsum(ptr(X), M, N, ld, nslab, slab_stride, ptr(out), int(accumulate), _stream()))

@@ -1,0 +1,114 @@
+// Shared device/host helpers for libjamie_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/jamie_hip.h"
+
+#define JAMIE_WAVE 64
+#define JAMIE_MAX_PARTIALS 4096
+
+// ------------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------------
+extern thread_local char g_jamie_err[512];
+
+inline int jamie_fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+    snprintf(g_jamie_err, sizeof(g_jamie_err), fmt, a, b, c);
+    return code;
+}
+
+#define JAMIE_ARG(cond, msg)                                                                        \
+    do {                                                                                            \
+        if (!(cond)) return jamie_fail(-1, "%s: argument check failed: " msg " [%lld %lld]", __func__, \
+                                       0, 0);                                                       \
+    } while (0)
+
+inline int jamie_launch_status(const char* who) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_jamie_err, sizeof(g_jamie_err), "%s: launch failed: %s", who, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (counter-based; Salmon et al. 2011).  key = seed, counter = (index, stream, step).
+// ------------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// rng[0] = seed, rng[1] = step.  `stream` separates layers / uses; `idx4` is the element index / 4.
+__device__ __forceinline__ Philox4 jamie_rand4(const uint64_t* rng, uint32_t stream, uint64_t idx4) {
+    uint64_t seed = rng[0], step = rng[1];
+    return philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), stream, (uint32_t)step,
+                         (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
+}
+
+// keep-mask for dropout probability p: keep iff u32 >= p * 2^32
+__device__ __forceinline__ uint32_t jamie_drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0.0) return 0u;
+    if (t >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)t;
+}
+
+__device__ __forceinline__ bool jamie_keep(const uint64_t* rng, uint32_t stream, uint64_t elem, uint32_t thr) {
+    Philox4 r = jamie_rand4(rng, stream, elem >> 2);
+    return r.v[elem & 3] >= thr;
+}
+
+// two N(0,1) from two u32 (Box-Muller)
+__device__ __forceinline__ void jamie_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+    float u2 = (float)b * 2.3283064365386963e-10f;
+    float r = sqrtf(-2.0f * __logf(u1));
+    float s, c;
+    __sincosf(6.283185307179586f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions (wave = 64)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum; `red` is >= (blockDim.x/64) floats of LDS; result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}

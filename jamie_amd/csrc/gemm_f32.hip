@@ -1,0 +1,338 @@
+// fp32 GEMM on v_mfma_f32_32x32x2_f32 for JAMIE's Linear layers (forward NT, dX NN, dW TN), gfx950.
+//
+// Replaces the `addmm`/`mm` ATen dispatches of nn.Linear forward/backward
+// (reference model.py:151,161,180,185,192,197,207; autograd at jamie.py:734).
+//
+// Design (MI355X_MICROARCH.md § Matrix cores; cdna_hip_programming.md §3 'FP32-input MFMA'):
+//   * exact-f32 MFMA 32x32x2 runs at 64 cyc/SIMD; one accumulation chain per 32x32 tile already issues
+//     back to back, so the kernel is MFMA-issue bound as long as LDS reads and global loads hide.
+//   * block tile BM x BN x BK, WM x WN waves, each wave TM x TN tiles of 32x32.
+//   * operands are staged global -> VGPR -> LDS in the layout they have in HBM (no transposes):
+//       K-contiguous operand ("KC"): LDS [rows][BK+4]; a lane reads ONE ds_read_b128 = 4 consecutive k
+//                                    feeding 4 MFMAs (row stride 16*odd bytes -> conflict-free);
+//       row-contiguous operand ("RC"): LDS [BK][rows+4]; a lane reads 4 ds_read_b32 (lanes consecutive).
+//     MFMA step s of a k-group of 8 consumes logical k = kk + 4*(lane>>5) + s for BOTH operands.
+//   * double-buffered LDS, next tile's global loads issued before the MFMAs of the current tile.
+//   * grouped launch: up to JAMIE_MAX_GROUP problems (the modalities) share one grid; block ids are
+//     remapped so that the M-tiles that re-read one weight panel run back to back on one XCD (its L2).
+//   * split-K writes fp32 slabs (deterministic; the consumer kernel sums them).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmDev {
+    const float* A; const float* B; float* C; const float* bias;
+    const float* aux0; const float* aux1; const float* aux2; const float* aux3;
+    float* partial; const int32_t* a_rows;
+    long long slab_stride;
+    int M, N, K, lda, ldb, ldc, aux_ld;
+    int splitk, kchunk, tiles_m, tiles_n, tile_begin;
+    int epi, accumulate, a_vec, b_vec;
+    float scale, slope, eps, pscale;
+};
+
+struct GemmGroup {
+    GemmDev p[JAMIE_MAX_GROUP];
+    int count;
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid >= 4 && vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (nvalid > 0) v.x = p[0];
+        if (nvalid > 1) v.y = p[1];
+        if (nvalid > 2) v.z = p[2];
+        if (nvalid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_LD = A_KC ? BK + 4 : BM + 4;
+    constexpr int B_LD = B_KC ? BK + 4 : BN + 4;
+    constexpr int A_SZ = A_KC ? BM * A_LD : BK * A_LD;
+    constexpr int B_SZ = B_KC ? BN * B_LD : BK * B_LD;
+    constexpr int LA = BM * BK / 4 / NT, LB = BN * BK / 4 / NT;
+    static_assert(LA >= 1 && LB >= 1 && BK % 8 == 0, "tile/thread mismatch");
+    static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "tile/thread mismatch");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    __shared__ float red[WM * WN];
+
+    // ---- block -> (problem, tile) with XCD-aware remap (bijective form, cdna_hip_programming.md §5) ----
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r8 = nb & 7, xcd = bid & 7, slot = bid >> 3;
+    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
+        if (i < g.count && vid >= g.p[i].tile_begin) pi = i;
+    const GemmDev& P = g.p[pi];
+    const int t = vid - P.tile_begin;
+    const int tm_i = t % P.tiles_m;
+    const int tn_i = (t / P.tiles_m) % P.tiles_n;
+    const int ks = t / (P.tiles_m * P.tiles_n);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int kbeg = ks * P.kchunk;
+    const int kend = min(P.K, kbeg + P.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
+    const int r = lane & 31, h = lane >> 5;
+    const bool avec = P.a_vec != 0, bvec = P.b_vec != 0;
+
+    // ---- per-thread staging descriptors ----
+    const float* a_ptr[LA]; int a_lim[LA]; int a_lds[LA]; int a_k[LA];
+    const float* b_ptr[LB]; int b_lim[LB]; int b_lds[LB]; int b_k[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int f = tid + j * NT;
+        if (A_KC) {
+            const int row = f / (BK / 4), c4 = f % (BK / 4);
+            const int gm = m0 + row;
+            const bool ok = gm < P.M;
+            const long long grow = ok ? (P.a_rows ? (long long)P.a_rows[gm] : (long long)gm) : 0;
+            a_ptr[j] = P.A + grow * P.lda + c4 * 4;
+            a_lim[j] = ok ? 1 : 0;      // row valid
+            a_k[j] = c4 * 4;            // k offset within tile
+            a_lds[j] = row * A_LD + c4 * 4;
+        } else {
+            const int krow = f / (BM / 4), c4 = f % (BM / 4);
+            const int gm = m0 + c4 * 4;
+            a_ptr[j] = P.A + gm;
+            a_lim[j] = max(0, min(4, P.M - gm));   // valid elements along m
+            a_k[j] = krow;
+            a_lds[j] = krow * A_LD + c4 * 4;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int f = tid + j * NT;
+        if (B_KC) {
+            const int row = f / (BK / 4), c4 = f % (BK / 4);
+            const int gn = n0 + row;
+            const bool ok = gn < P.N;
+            b_ptr[j] = P.B + (long long)(ok ? gn : 0) * P.ldb + c4 * 4;
+            b_lim[j] = ok ? 1 : 0;
+            b_k[j] = c4 * 4;
+            b_lds[j] = row * B_LD + c4 * 4;
+        } else {
+            const int krow = f / (BN / 4), c4 = f % (BN / 4);
+            const int gn = n0 + c4 * 4;
+            b_ptr[j] = P.B + gn;
+            b_lim[j] = max(0, min(4, P.N - gn));
+            b_k[j] = krow;
+            b_lds[j] = krow * B_LD + c4 * 4;
+        }
+    }
+
+    float4 ra[LA], rb[LB];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            if (A_KC) {
+                const int k = k0 + a_k[j];
+                const int nv = a_lim[j] ? max(0, min(4, kend - k)) : 0;
+                ra[j] = ld4_guard(a_ptr[j] + k0, nv, avec);
+            } else {
+                const int k = k0 + a_k[j];
+                const int nv = (k < kend) ? a_lim[j] : 0;
+                ra[j] = ld4_guard(a_ptr[j] + (long long)k * P.lda, nv, avec);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            if (B_KC) {
+                const int k = k0 + b_k[j];
+                const int nv = b_lim[j] ? max(0, min(4, kend - k)) : 0;
+                rb[j] = ld4_guard(b_ptr[j] + k0, nv, bvec);
+            } else {
+                const int k = k0 + b_k[j];
+                const int nv = (k < kend) ? b_lim[j] : 0;
+                rb[j] = ld4_guard(b_ptr[j] + (long long)k * P.ldb, nv, bvec);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * (A_SZ + B_SZ);
+        float* Bs = As + A_SZ;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) *reinterpret_cast<float4*>(&As[a_lds[j]]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) *reinterpret_cast<float4*>(&Bs[b_lds[j]]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nk > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kbeg + (kt + 1) * BK);
+        const float* As = smem + cur * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            float af[TM][4], bf[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (A_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + r) * A_LD + kk + 4 * h]);
+                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[i][s] = As[(kk + 4 * h + s) * A_LD + wm0 + i * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + r) * B_LD + kk + 4 * h]);
+                    bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(kk + 4 * h + s) * B_LD + wn0 + j * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+    float* Cout = P.C + (long long)ks * P.slab_stride;
+    const bool add_bias = (P.bias != nullptr) && ks == 0;
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + r;
+        if (n >= P.N) continue;
+        const float bv = add_bias ? P.bias[n] : 0.f;
+        float e_mean = 0.f, e_scale = 1.f, e_shift = 0.f;
+        if (P.epi == JAMIE_EPI_BN_EVAL) {
+            e_mean = P.aux0[n];
+            e_scale = rsqrtf(P.aux1[n] + P.eps) * P.aux2[n];
+            e_shift = P.aux3[n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= P.M) continue;
+                float v = acc[i][j][e] + bv;
+                float* cp = Cout + (long long)m * P.ldc + n;
+                if (P.epi == JAMIE_EPI_STORE) {
+                    if (P.accumulate) v += *cp;
+                    *cp = v;
+                } else if (P.epi == JAMIE_EPI_MSE) {
+                    const float d = v - P.aux0[(long long)m * P.aux_ld + n];
+                    local += d * d;
+                    *cp = d * P.scale;
+                } else {  // JAMIE_EPI_BN_EVAL
+                    const float y = (v - e_mean) * e_scale + e_shift;
+                    *cp = y > 0.f ? y : P.slope * y;
+                }
+            }
+        }
+    }
+    if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
+static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        GemmDev& d = g.p[i];
+        d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias;
+        d.aux0 = s.aux0; d.aux1 = s.aux1; d.aux2 = s.aux2; d.aux3 = s.aux3;
+        d.partial = s.partial; d.a_rows = s.a_rows;
+        d.slab_stride = s.slab_stride;
+        d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.aux_ld = s.aux_ld;
+        d.splitk = s.splitk < 1 ? 1 : s.splitk;
+        int kc = (s.K + d.splitk - 1) / d.splitk;
+        kc = ((kc + BK - 1) / BK) * BK;
+        if (kc < BK) kc = BK;
+        d.kchunk = kc;
+        d.tiles_m = (s.M + BM - 1) / BM;
+        d.tiles_n = (s.N + BN - 1) / BN;
+        d.tile_begin = tiles;
+        d.epi = s.epi; d.accumulate = s.accumulate;
+        d.a_vec = ((s.lda % 4) == 0 && ((uintptr_t)s.A % 16) == 0) ? 1 : 0;
+        d.b_vec = ((s.ldb % 4) == 0 && ((uintptr_t)s.B % 16) == 0) ? 1 : 0;
+        d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
+        tiles += d.tiles_m * d.tiles_n * d.splitk;
+    }
+    if (tiles == 0) return 0;
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC>), dim3(tiles), dim3(WM * WN * 64), 0,
+                       st, g);
+    return jamie_launch_status("jamie_gemm_f32");
+}
+
+extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layout, void* stream) {
+    JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
+    JAMIE_ARG(layout >= JAMIE_NT && layout <= JAMIE_TN, "layout");
+    int max_n = 0, max_m = 0;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        JAMIE_ARG(s.A && s.B && s.C, "null operand");
+        JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
+        JAMIE_ARG(s.ldc >= s.N, "ldc < N");
+        if (layout == JAMIE_NT) JAMIE_ARG(s.lda >= s.K && s.ldb >= s.K, "NT: lda/ldb < K");
+        if (layout == JAMIE_NN) JAMIE_ARG(s.lda >= s.K && s.ldb >= s.N, "NN: lda < K or ldb < N");
+        if (layout == JAMIE_TN) JAMIE_ARG(s.lda >= s.M && s.ldb >= s.N, "TN: lda < M or ldb < N");
+        JAMIE_ARG(s.epi >= JAMIE_EPI_STORE && s.epi <= JAMIE_EPI_BN_EVAL, "epilogue id");
+        JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.splitk <= 1, "fused epilogues need splitk == 1");
+        JAMIE_ARG(s.splitk <= 1 || !s.accumulate, "split-K slabs cannot accumulate");
+        JAMIE_ARG(s.epi != JAMIE_EPI_MSE || (s.aux0 && s.aux_ld >= s.N), "MSE epilogue needs aux0 = X");
+        JAMIE_ARG(s.epi != JAMIE_EPI_BN_EVAL || (s.aux0 && s.aux1 && s.aux2 && s.aux3), "BN_EVAL needs aux0..3");
+        JAMIE_ARG(layout != JAMIE_TN || s.a_rows == nullptr, "a_rows only for NT/NN");
+        JAMIE_ARG(s.splitk <= 1 || s.slab_stride >= (long long)s.M * s.ldc, "slab_stride too small");
+        if (s.N > max_n) max_n = s.N;
+        if (s.M > max_m) max_m = s.M;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == JAMIE_NT) {
+        if (max_n <= 64) return launch_cfg<64, 64, 32, 2, 2, true, true>(pr, count, st);
+        return launch_cfg<64, 128, 32, 2, 2, true, true>(pr, count, st);
+    }
+    if (layout == JAMIE_NN) {
+        if (max_n <= 64) return launch_cfg<64, 64, 32, 2, 2, true, false>(pr, count, st);
+        return launch_cfg<64, 128, 32, 2, 2, true, false>(pr, count, st);
+    }
+    // TN (weight gradients): K = batch is short, output is large
+    if (max_n <= 64 || max_m <= 64) return launch_cfg<64, 64, 32, 2, 2, false, false>(pr, count, st);
+    return launch_cfg<128, 128, 16, 2, 2, false, false>(pr, count, st);
+}

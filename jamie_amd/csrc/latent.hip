@@ -1,0 +1,362 @@
+// Latent block of JAMIE's coupled VAE for two modalities, gfx950:
+//   reparameterisation  z = mu + eps * (exp(logvar/2) + 1e-7)                 (reference model.py:225-243)
+//   sigma-weighted combine with the B x B correspondence block `corr`          (model.py:245-259)
+//   KL (with the reference's logvars[i] = ROW i quirk), alignment ("CosSim") and F losses and their
+//   gradients w.r.t. mu, logvar, sigma                                         (jamie.py:618-668, 723-734)
+//
+// Everything here is [B, L] sized (B = batch, L = latent): HBM-resident but tiny, so the kernels are
+// thread-per-element with wavefront-shuffle + LDS block reductions; loss terms are written as per-block
+// partial sums and added up in a fixed order by block 0 of the last kernel (deterministic, no atomics).
+// The B x B products (C z, C^T z, F comb, ...) are ~8 MFLOP each: plain VALU loops, not MFMA.
+#include "common.h"
+
+#define LAT_SLOTS 16
+enum { S_MU2_0 = 0, S_MU2_1, S_TROW0, S_TROW1, S_AL0, S_AL1, S_F, S_DSIG0, S_DSIG1 };
+
+struct LatDev {
+    int B, L;
+    const float* ml[2]; int ml_nslab; long long ml_slab_stride;
+    const float* head_bias[2]; const float* eps_in[2];
+    const float* sigma; const float* corr; const float* Fblk; const float* hyper;
+    float* mu[2]; float* lv[2]; float* z[2]; float* eps[2]; float* comb[2]; float* cz[2];
+    float* rsum; float* qsum; float* fc1; float* partials;
+    const float* dcomb[2]; int dcomb_nslab; long long dcomb_slab_stride;
+    float* H[2]; float* ch[2]; float* fte; float* dml[2]; float* dsigma;
+    const float* rec_partials; int n_rec_partials; float* losses;
+    int cosine; int rng_stream;
+};
+
+static LatDev to_dev(const jamie_latent* a) {
+    LatDev d;
+    memset(&d, 0, sizeof(d));
+    d.B = a->B; d.L = a->L;
+    for (int i = 0; i < 2; ++i) {
+        d.ml[i] = a->ml[i]; d.head_bias[i] = a->head_bias[i]; d.eps_in[i] = a->eps_in[i];
+        d.mu[i] = a->mu[i]; d.lv[i] = a->lv[i]; d.z[i] = a->z[i]; d.eps[i] = a->eps[i];
+        d.comb[i] = a->comb[i]; d.cz[i] = a->cz[i]; d.dcomb[i] = a->dcomb[i]; d.H[i] = a->H[i];
+        d.ch[i] = a->ch[i]; d.dml[i] = a->dml[i];
+    }
+    d.ml_nslab = a->ml_nslab; d.ml_slab_stride = a->ml_slab_stride;
+    d.sigma = a->sigma; d.corr = a->corr; d.Fblk = a->Fblk; d.hyper = a->hyper;
+    d.rsum = a->rsum; d.qsum = a->qsum; d.fc1 = a->fc1; d.partials = a->partials;
+    d.dcomb_nslab = a->dcomb_nslab; d.dcomb_slab_stride = a->dcomb_slab_stride;
+    d.fte = a->fte; d.dsigma = a->dsigma;
+    d.rec_partials = a->rec_partials; d.n_rec_partials = a->n_rec_partials; d.losses = a->losses;
+    d.cosine = a->cosine; d.rng_stream = a->rng_stream;
+    return d;
+}
+
+__device__ __forceinline__ void put_partial(const LatDev& a, int slot, float v, float* red) {
+    const float t = block_sum(v, red);
+    if (threadIdx.x == 0) a.partials[slot * JAMIE_MAX_PARTIALS + blockIdx.x] = t;
+}
+
+// ---- K1: mu/logvar from the heads GEMM slabs, reparameterise, KL partial sums ----
+__global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uint64_t* rng) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = e < n;
+    const int b = ok ? e / L : 0, l = ok ? e % L : 0;
+    float mu2[2] = {0.f, 0.f}, trow[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!ok) continue;
+        float mu = a.head_bias[i][l], lv = a.head_bias[i][L + l];
+        for (int s = 0; s < a.ml_nslab; ++s) {
+            const float* p = a.ml[i] + s * a.ml_slab_stride + (long long)b * 2 * L;
+            mu += p[l];
+            lv += p[L + l];
+        }
+        float ep;
+        if (a.eps_in[i]) {
+            ep = a.eps_in[i][e];
+        } else {
+            Philox4 r = jamie_rand4(rng, (uint32_t)(a.rng_stream + i), (uint64_t)e);
+            float n1;
+            jamie_box_muller(r.v[0], r.v[1], ep, n1);
+        }
+        const float sd = expf(0.5f * lv) + 1e-7f;
+        a.mu[i][e] = mu; a.lv[i][e] = lv; a.eps[i][e] = ep;
+        a.z[i][e] = mu + ep * sd;
+        mu2[i] = mu * mu;
+        // KL quirk: logvars[j] is ROW j of the LAST modality's logvar (jamie.py:619-628, model.py:243)
+        if (i == 1 && b < 2) trow[b] = 1.f + lv - expf(lv);
+    }
+    put_partial(a, S_MU2_0, mu2[0], red);
+    put_partial(a, S_MU2_1, mu2[1], red);
+    put_partial(a, S_TROW0, trow[0], red);
+    put_partial(a, S_TROW1, trow[1], red);
+}
+
+// ---- small [B,B] x [B,L] products.  job 0: out = Mtx Z (+ row sums); job 1: out = Mtx^T Z (+ column sums).
+// Mtx == nullptr means identity (out = Z, sums = 1). ----
+struct MmJob { const float* Mtx; const float* Z; float* out; float* sums; int transpose; int active; };
+struct MmJobs { MmJob j[2]; int B, L; };
+
+__global__ __launch_bounds__(256) void small_mm_kernel(MmJobs js) {
+    const MmJob& J = js.j[blockIdx.y];
+    if (!J.active) return;
+    const int B = js.B, L = js.L, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int row = e / L, l = e % L;
+    float acc = 0.f, sm = 0.f;
+    if (J.Mtx == nullptr) {
+        acc = J.Z[e];
+        sm = 1.f;
+    } else if (!J.transpose) {
+        const float* mr = J.Mtx + (long long)row * B;
+        for (int c = 0; c < B; ++c) {
+            const float w = mr[c];
+            acc = fmaf(w, J.Z[c * L + l], acc);
+            sm += w;
+        }
+    } else {
+        for (int c = 0; c < B; ++c) {
+            const float w = J.Mtx[(long long)c * B + row];
+            acc = fmaf(w, J.Z[c * L + l], acc);
+            sm += w;
+        }
+    }
+    J.out[e] = acc;
+    if (J.sums && l == 0) J.sums[row] = sm;
+}
+
+static void launch_mm(hipStream_t st, int B, int L, const MmJob& j0, const MmJob& j1) {
+    MmJobs js;
+    js.j[0] = j0; js.j[1] = j1; js.B = B; js.L = L;
+    hipLaunchKernelGGL(small_mm_kernel, dim3((B * L + 255) / 256, 2), dim3(256), 0, st, js);
+}
+
+// per-row cosine pieces: s = a.c / (|a||c|)
+__device__ __forceinline__ void cos_row(const float* a, const float* c, int L, float& dot, float& na2, float& nc2) {
+    dot = 0.f; na2 = 0.f; nc2 = 0.f;
+    for (int l = 0; l < L; ++l) {
+        dot = fmaf(a[l], c[l], dot);
+        na2 = fmaf(a[l], a[l], na2);
+        nc2 = fmaf(c[l], c[l], nc2);
+    }
+}
+
+// ---- K3: combine + alignment partial sums ----
+__global__ __launch_bounds__(256) void latent_combine_kernel(LatDev a) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = e < n;
+    float al0 = 0.f, al1 = 0.f;
+    if (ok) {
+        const int b = e / L;
+        const float s0 = a.sigma[0], s1 = a.sigma[1];
+        const float z0 = a.z[0][e], z1 = a.z[1][e];
+        const float c0 = (s0 * z0 + s1 * a.cz[0][e]) / (s0 + s1 * a.rsum[b]);
+        const float c1 = (s1 * z1 + s0 * a.cz[1][e]) / (s1 + s0 * a.qsum[b]);
+        a.comb[0][e] = c0;
+        a.comb[1][e] = c1;
+        if (!a.cosine) {
+            al0 = (z0 - c0) * (z0 - c0);
+            al1 = (z1 - c1) * (z1 - c1);
+        }
+    }
+    if (!a.cosine) {
+        put_partial(a, S_AL0, al0, red);
+        put_partial(a, S_AL1, al1, red);
+    }
+}
+
+// cosine alignment: per-row (1 - cos)^2, one thread per row (L is small)
+__global__ __launch_bounds__(256) void latent_cosine_loss_kernel(LatDev a) {
+    __shared__ float red[4];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    float v[2] = {0.f, 0.f};
+    if (b < a.B) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float dot, na2, nc2;
+            cos_row(a.z[i] + (long long)b * a.L, a.comb[i] + (long long)b * a.L, a.L, dot, na2, nc2);
+            const float d = 1.f - dot / (sqrtf(na2) * sqrtf(nc2));
+            v[i] = d * d;
+        }
+    }
+    put_partial(a, S_AL0, v[0], red);
+    put_partial(a, S_AL1, v[1], red);
+}
+
+// E = comb0 - F comb1 (only when F is given); written to ch[0] as input of the F^T E product
+__global__ __launch_bounds__(256) void latent_fres_kernel(LatDev a) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < a.B * a.L) a.ch[0][e] = a.comb[0][e] - a.fc1[e];
+}
+
+// gradient of the alignment term w.r.t. z_i (its negative is the gradient w.r.t. comb_i for the
+// euclidean form; the cosine form has its own comb gradient)
+__device__ __forceinline__ void align_grads(const LatDev& a, int i, int e, int b, int l, float w_al, float invBL,
+                                            float& gz, float& gc) {
+    const float zi = a.z[i][e], ci = a.comb[i][e];
+    if (!a.cosine) {
+        gz = w_al * 2.f * (zi - ci) * invBL;
+        gc = -gz;
+    } else {
+        float dot, na2, nc2;
+        cos_row(a.z[i] + (long long)b * a.L, a.comb[i] + (long long)b * a.L, a.L, dot, na2, nc2);
+        const float na = sqrtf(na2), nc = sqrtf(nc2);
+        const float s = dot / (na * nc);
+        const float kap = -2.f * w_al * (1.f - s) * invBL;
+        gz = kap * (ci / (na * nc) - s * zi / na2);
+        gc = kap * (zi / (na * nc) - s * ci / nc2);
+    }
+}
+
+// ---- K6: total gradient w.r.t. comb_i, H_i = G_i / den_i, dsigma and F-loss partial sums ----
+__global__ __launch_bounds__(256) void latent_bwd_a_kernel(LatDev a) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = e < n;
+    float ds0 = 0.f, ds1 = 0.f, fsq = 0.f;
+    if (ok) {
+        const int b = e / L, l = e % L;
+        const float invBL = 1.f / (float)n;
+        const float w_al = a.hyper[2], w_f = a.hyper[3];
+        const float s0 = a.sigma[0], s1 = a.sigma[1];
+        const float c0 = a.comb[0][e], c1 = a.comb[1][e];
+        const float E = c0 - (a.Fblk ? a.fc1[e] : 0.f);
+        fsq = E * E;
+        float G0 = w_f * 2.f * E * invBL;
+        float G1 = a.Fblk ? -w_f * 2.f * a.fte[e] * invBL : 0.f;
+        for (int s = 0; s < a.dcomb_nslab; ++s) {
+            G0 += a.dcomb[0][e + s * a.dcomb_slab_stride];
+            G1 += a.dcomb[1][e + s * a.dcomb_slab_stride];
+        }
+        float gz, gc;
+        align_grads(a, 0, e, b, l, w_al, invBL, gz, gc);
+        G0 += gc;
+        align_grads(a, 1, e, b, l, w_al, invBL, gz, gc);
+        G1 += gc;
+        const float r = a.rsum[b], q = a.qsum[b];
+        const float H0 = G0 / (s0 + s1 * r), H1 = G1 / (s1 + s0 * q);
+        a.H[0][e] = H0;
+        a.H[1][e] = H1;
+        ds0 = H0 * a.z[0][e] - H0 * c0 + H1 * a.cz[1][e] - q * H1 * c1;
+        ds1 = H1 * a.z[1][e] - H1 * c1 + H0 * a.cz[0][e] - r * H0 * c0;
+    }
+    put_partial(a, S_DSIG0, ds0, red);
+    put_partial(a, S_DSIG1, ds1, red);
+    put_partial(a, S_F, fsq, red);
+}
+
+// ---- K8: d(mu|logvar); block 0 also finalises the losses and dsigma ----
+__global__ __launch_bounds__(256) void latent_bwd_b_kernel(LatDev a) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const float invBL = 1.f / (float)n;
+    const float kl_scale = a.hyper[0];
+    if (e < n) {
+        const int b = e / L, l = e % L;
+        const float w_al = a.hyper[2];
+        const float s[2] = {a.sigma[0], a.sigma[1]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float gz, gc;
+            align_grads(a, i, e, b, l, w_al, invBL, gz, gc);
+            const float dz = s[i] * (a.H[i][e] + a.ch[i][e]) + gz;
+            const float lv = a.lv[i][e];
+            const float dmu = dz + kl_scale * a.mu[i][e] * invBL;
+            float dlv = dz * a.eps[i][e] * 0.5f * expf(0.5f * lv);
+            if (i == 1 && b < 2) dlv += kl_scale * (-0.5f) * (1.f - expf(lv)) / (float)L;
+            a.dml[i][(long long)b * 2 * L + l] = dmu;
+            a.dml[i][(long long)b * 2 * L + L + l] = dlv;
+        }
+    }
+    if (blockIdx.x != 0) return;
+    // ---- finalise (fixed summation order) ----
+    const int nblk = (n + 255) / 256;
+    float tot[LAT_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl <= S_DSIG1; ++sl) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += 256) v += a.partials[sl * JAMIE_MAX_PARTIALS + i];
+        tot[sl] = block_sum(v, red);
+    }
+    float rec = 0.f;
+    for (int i = threadIdx.x; i < a.n_rec_partials; i += 256) rec += a.rec_partials[i];
+    rec = block_sum(rec, red);
+    if (threadIdx.x == 0) {
+        const float w_rec = a.hyper[1], w_al = a.hyper[2], w_f = a.hyper[3];
+        const float kl = -0.5f * (tot[S_TROW0] / (float)L - tot[S_MU2_0] * invBL)
+                         - 0.5f * (tot[S_TROW1] / (float)L - tot[S_MU2_1] * invBL);
+        const float l_kl = kl_scale * kl;
+        const float l_rec = w_rec * rec;
+        const float l_al = a.cosine ? w_al * (tot[S_AL0] + tot[S_AL1]) / (float)B * (1.f / (float)L)
+                                    : w_al * (tot[S_AL0] + tot[S_AL1]) * invBL;
+        const float l_f = w_f * tot[S_F] * invBL;
+        const float total = l_kl + l_rec + l_al + l_f;
+        a.losses[0] = l_kl; a.losses[1] = l_rec; a.losses[2] = l_al; a.losses[3] = l_f;
+        a.losses[4] = total;
+        a.losses[5] = fminf(a.losses[5], total);
+        a.dsigma[0] = tot[S_DSIG0];
+        a.dsigma[1] = tot[S_DSIG1];
+    }
+}
+
+static int check_common(const jamie_latent* a) {
+    JAMIE_ARG(a != nullptr, "null descriptor");
+    JAMIE_ARG(a->B >= 2 && a->L >= 1, "B >= 2 (KL uses rows 0,1), L >= 1");
+    JAMIE_ARG((long long)a->B * a->L <= 256LL * JAMIE_MAX_PARTIALS, "B*L too large for the partial buffer");
+    JAMIE_ARG(a->sigma && a->hyper && a->partials && a->rsum && a->qsum, "null pointer");
+    for (int i = 0; i < 2; ++i)
+        JAMIE_ARG(a->mu[i] && a->lv[i] && a->z[i] && a->eps[i] && a->comb[i] && a->cz[i], "null state buffer");
+    JAMIE_ARG(a->Fblk == nullptr || (a->fc1 && a->fte), "F given but fc1/fte scratch missing");
+    return 0;
+}
+
+extern "C" int jamie_latent_fwd(const jamie_latent* a, const uint64_t* rng, void* stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    JAMIE_ARG(a->ml[0] && a->ml[1] && a->head_bias[0] && a->head_bias[1] && a->ml_nslab >= 1, "heads input");
+    JAMIE_ARG(a->ml_nslab == 1 || a->ml_slab_stride >= (long long)a->B * 2 * a->L, "ml_slab_stride too small");
+    JAMIE_ARG((a->eps_in[0] && a->eps_in[1]) || rng, "rng state required when eps is not given");
+    hipStream_t st = (hipStream_t)stream;
+    const LatDev d = to_dev(a);
+    const int nblk = (a->B * a->L + 255) / 256;
+    hipLaunchKernelGGL(latent_reparam_kernel, dim3(nblk), dim3(256), 0, st, d, rng);
+    MmJob j0 = {a->corr, a->z[1], a->cz[0], a->rsum, 0, 1};
+    MmJob j1 = {a->corr, a->z[0], a->cz[1], a->qsum, 1, 1};
+    launch_mm(st, a->B, a->L, j0, j1);
+    hipLaunchKernelGGL(latent_combine_kernel, dim3(nblk), dim3(256), 0, st, d);
+    if (a->cosine)
+        hipLaunchKernelGGL(latent_cosine_loss_kernel, dim3(nblk), dim3(256), 0, st, d);  // nblk >= ceil(B/256): every partial slot written
+    if (a->Fblk) {
+        MmJob f0 = {a->Fblk, a->comb[1], a->fc1, nullptr, 0, 1};
+        MmJob f1 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+        launch_mm(st, a->B, a->L, f0, f1);
+    }
+    return jamie_launch_status("jamie_latent_fwd");
+}
+
+extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    JAMIE_ARG(a->dcomb[0] && a->dcomb[1] && a->dcomb_nslab >= 1, "dcomb input");
+    JAMIE_ARG(a->dcomb_nslab == 1 || a->dcomb_slab_stride >= (long long)a->B * a->L, "dcomb_slab_stride too small");
+    JAMIE_ARG(a->H[0] && a->H[1] && a->ch[0] && a->ch[1] && a->dml[0] && a->dml[1] && a->dsigma && a->losses,
+              "null output/scratch");
+    JAMIE_ARG(a->n_rec_partials == 0 || a->rec_partials, "rec_partials");
+    hipStream_t st = (hipStream_t)stream;
+    const LatDev d = to_dev(a);
+    const int nblk = (a->B * a->L + 255) / 256;
+    if (a->Fblk) {
+        hipLaunchKernelGGL(latent_fres_kernel, dim3(nblk), dim3(256), 0, st, d);
+        MmJob f0 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+        MmJob f1 = {a->Fblk, a->ch[0], a->fte, nullptr, 1, 1};
+        launch_mm(st, a->B, a->L, f0, f1);
+    }
+    hipLaunchKernelGGL(latent_bwd_a_kernel, dim3(nblk), dim3(256), 0, st, d);
+    MmJob j0 = {a->corr, a->H[1], a->ch[0], nullptr, 0, 1};
+    MmJob j1 = {a->corr, a->H[0], a->ch[1], nullptr, 1, 1};
+    launch_mm(st, a->B, a->L, j0, j1);
+    hipLaunchKernelGGL(latent_bwd_b_kernel, dim3(nblk), dim3(256), 0, st, d);
+    return jamie_launch_status("jamie_latent_bwd");
+}

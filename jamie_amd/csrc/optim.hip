@@ -1,0 +1,105 @@
+// Global-norm gradient clip + Adam on one flat fp32 buffer, gfx950.
+//
+// Replaces torch.nn.utils.clip_grad_norm_(params, 1) + torch.optim.Adam.step + zero_grad
+// (reference jamie.py:481,739-741).  All parameters, gradients and both Adam moments live in four flat
+// fp32 buffers (every tensor a 16-byte aligned view), so the update is two HBM-bound streaming kernels:
+//   jamie_grad_sqnorm : per-block sum of g^2                      (reads 4n bytes)
+//   jamie_clip_adam   : every block re-sums the <= 4096 partials, derives the clip coefficient and
+//                       updates p, m, v                           (reads 16n, writes 12n bytes)
+// 16 B per lane loads/stores, grid-stride over <= 2048 blocks (cdna_hip_programming.md Guideline 11).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n,
+                                                          float* partials, uint64_t* state) {
+    __shared__ float red[4];
+    const long long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = g4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        if (i < n) acc += g[i] * g[i];
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t;
+        if (blockIdx.x == 0 && state) state[1] += 1;   // step counter (Adam's t, RNG step)
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n,
+                                                        const float* partials, int n_partials,
+                                                        const float* hyper, const uint64_t* state) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
+    s = block_sum(s, red);
+    const float lr = hyper[8], b1 = hyper[9], b2 = hyper[10], eps = hyper[11], max_norm = hyper[12];
+    const float gscale = hyper[13];
+    const float total = sqrtf(s) * gscale;                 // norm of the (averaged) gradient
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f) * gscale;
+    const double t = (double)state[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= coef;
+        mm = mm + (gg - mm) * omb1;                        // exp_avg.lerp_(grad, 1 - beta1)
+        vv = vv * b2 + omb2 * gg * gg;                     // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vv) / bc2s + eps;
+        pp -= step_size * (mm / denom);
+    };
+    const long long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        upd(pp.x, gg.x, mm.x, vv.x);
+        upd(pp.y, gg.y, mm.y, vv.y);
+        upd(pp.z, gg.z, mm.z, vv.z);
+        upd(pp.w, gg.w, mm.w, vv.w);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        if (i < n) upd(p[i], g[i], m[i], v[i]);
+    }
+}
+
+static int grid_for(long long n) {
+    long long b = (n / 4 + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+extern "C" int jamie_grad_sqnorm(const float* g, long long n, float* partials, int n_partials, uint64_t* state,
+                                 void* stream) {
+    JAMIE_ARG(g && partials && n > 0, "null pointer / empty");
+    JAMIE_ARG(((uintptr_t)g % 16) == 0, "g must be 16-byte aligned");
+    const int grid = grid_for(n);
+    JAMIE_ARG(n_partials == grid, "n_partials must equal jamie_optim_blocks(n)");
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, partials, state);
+    return jamie_launch_status("jamie_grad_sqnorm");
+}
+
+extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
+                               int n_partials, const float* hyper, const uint64_t* state, void* stream) {
+    JAMIE_ARG(p && g && m && v && partials && hyper && state && n > 0, "null pointer / empty");
+    JAMIE_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                  ((uintptr_t)v % 16) == 0, "buffers must be 16-byte aligned");
+    JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       partials, n_partials, hyper, state);
+    return jamie_launch_status("jamie_clip_adam");
+}
+
+extern "C" int jamie_optim_blocks(long long n) { return grid_for(n); }

@@ -1,0 +1,64 @@
+"""Data-parallel plumbing: one process per GPU, cells sharded by rows, ONE all-reduce of the flat
+gradient buffer per step (RCCL over xGMI on the GPU box: torch.distributed backend "nccl"; gloo on CPU
+for tests).  The reference has no distributed code; this is new.
+
+BatchNorm statistics stay per-rank (no SyncBN): north_star allows exactly one collective per step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if launched under torchrun."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ['RANK'])
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend)
+    return rank, world, local
+
+
+def shard_bounds(n_rows, rank, world):
+    """Contiguous row shard [lo, hi) of rank `rank`: sizes differ by at most one."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradAllReduce:
+    """All-reduce (SUM) of the flat gradient buffer in `n_buckets` contiguous chunks issued
+    asynchronously; the 1/world average is applied inside the clip+Adam kernel (hyper[grad_scale]).
+    With xGMI's point-to-point links a few large messages beat many small ones; the default is one."""
+
+    def __init__(self, group=None, n_buckets=1):
+        self.group = group
+        self.n_buckets = max(1, int(n_buckets))
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def __call__(self, flat):
+        if self.world == 1:
+            return
+        n = flat.numel()
+        if self.n_buckets == 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        step = (n + self.n_buckets - 1) // self.n_buckets
+        step = (step + 3) // 4 * 4
+        works = [dist.all_reduce(flat[s:min(n, s + step)], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for s in range(0, n, step)]
+        for w in works:
+            w.wait()
+
+
+def broadcast_flat(flat, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)

@@ -1,0 +1,293 @@
+"""Training step of JAMIE's coupled VAE on one MI355X: the hot loop body of the reference's
+`project_jamie` (jamie/jamie.py:546-741) as a fixed sequence of HIP kernel launches through the C ABI
+(`include/jamie_hip.h`): gather -> encoder GEMM/BN/act x2 -> heads GEMM -> latent block -> decoder
+GEMM/BN/act x2 -> output GEMM with fused MSE -> backward of all of it -> clip + Adam.
+
+All buffers are allocated once per batch size; no step allocates, synchronises or reads back.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _native as nv
+from .model import BN_EPS, BN_MOMENTUM, LRELU_SLOPE
+
+KL_WEIGHT = 32 * 1e-3       # jamie.py:632
+ALIGN_WEIGHT = 32           # jamie.py:658
+LOSS_NAMES = ['KL', 'Rec', 'CosSim', 'F']
+
+# hyper buffer slots (device float[16]; see include/jamie_hip.h)
+H_KL, H_REC, H_ALIGN, H_F = 0, 1, 2, 3
+H_LR, H_B1, H_B2, H_EPS, H_MAXNORM, H_GSCALE = 8, 9, 10, 11, 12, 13
+
+
+def choose_splitk(M, N, K, bm=64, bn=128):
+    """Split K so that a skinny problem still offers ~256 workgroups (one per CU); each slice keeps
+    at least 256 of K.  Slabs are summed by the consuming kernel."""
+    if N <= 64:
+        bn = 64
+    tiles = math.ceil(M / bm) * math.ceil(N / bn)
+    if tiles >= 192:
+        return 1
+    s = max(1, round(256 / tiles))
+    return int(max(1, min(s, K // 256)))
+
+
+def kl_anneal(epoch, min_epochs, epoch_DNN):
+    """jamie.py:630-631."""
+    c = (min_epochs / 2) if min_epochs > 0 else (epoch_DNN / 2)
+    return float(1 / (1 + np.exp(-5 * (epoch - c) / c)))
+
+
+class TrainEngine:
+    def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
+                 world_size=1, general_corr=True, use_F=False):
+        nv.require_gpu()
+        self.m = model
+        self.dev = model.device
+        self.B = B = int(batch_size)
+        self.dims = model.input_dim
+        self.L = L = model.output_dim
+        self.p_drop = model.dropout
+        self.cosine = dist_method == 'cosine'
+        if dist_method not in ('euclidean', 'cosine'):
+            raise ValueError("dist_method must be 'euclidean' or 'cosine' (jamie.py:483-502)")
+        self.loss_weights = [1., 1., 1., 1.] if loss_weights is None else [float(w) for w in loss_weights]
+        assert len(self.loss_weights) == 4, f'There are 4 losses and {len(self.loss_weights)} weights'
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        n = model.layout.total
+        self.grad = torch.zeros(n, **f32)
+        self.exp_avg = torch.zeros(n, **f32)
+        self.exp_avg_sq = torch.zeros(n, **f32)
+        self.g = model.layout.views(self.grad)
+        self.n_norm = nv.optim_blocks(n)
+        self.norm_partials = torch.zeros(self.n_norm, **f32)
+        # rng/state: [seed, step, 0, 0]
+        self.state = torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=self.dev)
+        hyper = torch.zeros(16)
+        hyper[H_REC], hyper[H_ALIGN], hyper[H_F] = (self.loss_weights[1], self.loss_weights[2] * ALIGN_WEIGHT,
+                                                     self.loss_weights[3])
+        hyper[H_LR], hyper[H_B1], hyper[H_B2], hyper[H_EPS] = lr, 0.9, 0.999, 1e-8
+        hyper[H_MAXNORM], hyper[H_GSCALE] = 1.0, 1.0 / world_size
+        self._hyper_host = hyper
+        self.hyper = hyper.to(self.dev)
+        self.set_kl_anneal(1.0)
+        self.losses = torch.zeros(8, **f32)
+        self.reset_best()
+        self.lat_partials = torch.zeros(16 * nv.load().jamie_max_partials(), **f32)
+        # ---- per-modality workspace ----
+        self.ws = []
+        # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
+        sk_head = min(choose_splitk(B, 2 * L, d) for d in self.dims)
+        sk_dcomb = min(choose_splitk(B, L, d) for d in self.dims)
+        for i, d in enumerate(self.dims):
+            w = {}
+            sk = {'enc0': choose_splitk(B, 2 * d, d), 'enc1': choose_splitk(B, d, 2 * d),
+                  'head': sk_head, 'dec0': 1, 'dec1': choose_splitk(B, 2 * d, d),
+                  'd_e2': choose_splitk(B, 2 * d, d),     # dxhat  D3   : [B,d]  x [d,2d]
+                  'd_e1': choose_splitk(B, d, 2 * d),     # dg2p   D2   : [B,2d] x [2d,d]
+                  'd_comb': sk_dcomb,                     # dg1p   D1   : [B,d]  x [d,L]
+                  'd_a2': 1,                              # dml    Wh   : [B,2L] x [2L,d]
+                  'd_a1': choose_splitk(B, 2 * d, d)}     # dh2p   W2   : [B,d]  x [d,2d]
+            w['sk'] = sk
+            w['x'] = torch.empty(B, d, **f32)
+            w['h1'] = torch.empty(sk['enc0'], B, 2 * d, **f32); w['a1'] = torch.empty(B, 2 * d, **f32)
+            w['h2'] = torch.empty(sk['enc1'], B, d, **f32); w['a2'] = torch.empty(B, d, **f32)
+            w['ml'] = torch.empty(sk['head'], B, 2 * L, **f32)
+            for k in ('mu', 'lv', 'z', 'eps', 'comb', 'cz', 'H', 'ch'):
+                w[k] = torch.empty(B, L, **f32)
+            w['g1'] = torch.empty(1, B, d, **f32); w['e1'] = torch.empty(B, d, **f32)
+            w['g2'] = torch.empty(sk['dec1'], B, 2 * d, **f32); w['e2'] = torch.empty(B, 2 * d, **f32)
+            w['dxhat'] = torch.empty(B, d, **f32)
+            w['de2'] = torch.empty(sk['d_e2'], B, 2 * d, **f32)
+            w['de1'] = torch.empty(sk['d_e1'], B, d, **f32)
+            w['dcomb'] = torch.empty(sk['d_comb'], B, L, **f32)
+            w['dml'] = torch.empty(B, 2 * L, **f32)
+            w['da2'] = torch.empty(1, B, d, **f32)
+            w['da1'] = torch.empty(sk['d_a1'], B, 2 * d, **f32)
+            for k, nn in (('bn0', 2 * d), ('bn1', d), ('bn2', d), ('bn3', 2 * d)):
+                w[k + '.mean'] = torch.empty(nn, **f32); w[k + '.invstd'] = torch.empty(nn, **f32)
+            w['idx'] = torch.zeros(B, dtype=torch.int32, device=self.dev)
+            self.ws.append(w)
+        # dec2 (MSE epilogue) uses the 64x128 tile config unless N <= 64
+        bn_tile = 64 if max(self.dims) <= 64 else 128      # the grouped launch picks one config by max N
+        self.rec_tiles = [math.ceil(B / 64) * math.ceil(d / bn_tile) for d in self.dims]
+        self.rec_partials = torch.zeros(sum(self.rec_tiles), **f32)
+        self.rsum = torch.empty(B, **f32); self.qsum = torch.empty(B, **f32)
+        self.fc1 = torch.empty(B, L, **f32); self.fte = torch.empty(B, L, **f32)
+        self.corr = torch.empty(B, B, **f32)
+        self.accumulate = False
+
+    # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
+    def set_kl_anneal(self, anneal):
+        self._hyper_host[H_KL] = self.loss_weights[0] * KL_WEIGHT * anneal
+        self.hyper[H_KL:H_KL + 1].copy_(self._hyper_host[H_KL:H_KL + 1], non_blocking=True)
+
+    def reset_best(self):
+        self.losses[5] = float('inf')
+
+    # ---- pieces ----
+    def _mask(self, noise, kind, i, j):
+        if noise is None or self.p_drop == 0:
+            return None
+        return noise[kind][i][j]
+
+    def _bn_fwd(self, layer, h_key, out_key, stream_base, noise, kind, j):
+        probs = []
+        for i, d in enumerate(self.dims):
+            w, P, bn = self.ws[i], self.m.p, self.m.bn
+            h = w[h_key]
+            pr = nv.BnFwdProblem()
+            pr.h, pr.nslab, pr.slab_stride = nv.ptr(h), h.shape[0], h.shape[1] * h.shape[2]
+            pr.gamma, pr.beta = nv.ptr(P[f'm{i}.{layer}.g']), nv.ptr(P[f'm{i}.{layer}.b'])
+            pr.running_mean, pr.running_var = nv.ptr(bn[f'm{i}.{layer}.mean']), nv.ptr(bn[f'm{i}.{layer}.var'])
+            pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
+            pr.out, pr.mask = nv.ptr(w[out_key]), nv.ptr(self._mask(noise, kind, i, j))
+            pr.B, pr.N, pr.rng_stream = self.B, h.shape[2], stream_base + 8 * i
+            probs.append(pr)
+        nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE)
+
+    def _bn_bwd(self, layer, da_key, h_key, lin, stream_base, noise, kind, j):
+        probs = []
+        for i, d in enumerate(self.dims):
+            w, P = self.ws[i], self.m.p
+            da, h = w[da_key], w[h_key]
+            pr = nv.BnBwdProblem()
+            pr.da, pr.nslab, pr.slab_stride = nv.ptr(da), da.shape[0], da.shape[1] * da.shape[2]
+            pr.h, pr.gamma, pr.beta = nv.ptr(h), nv.ptr(P[f'm{i}.{layer}.g']), nv.ptr(P[f'm{i}.{layer}.b'])
+            pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
+            pr.dgamma, pr.dbeta = nv.ptr(self.g[f'm{i}.{layer}.g']), nv.ptr(self.g[f'm{i}.{layer}.b'])
+            pr.dbias_lin = nv.ptr(self.g[f'm{i}.{lin}.b'])
+            pr.mask = nv.ptr(self._mask(noise, kind, i, j))
+            pr.B, pr.N, pr.rng_stream, pr.accumulate = self.B, h.shape[2], stream_base + 8 * i, int(self.accumulate)
+            probs.append(pr)
+        nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE)
+
+    def _fwd_gemm(self, a_key, lin, out_key, sk_key, with_bias=True):
+        """out[B, out_f] (slabs) = a[B, in_f] W^T (+ b)."""
+        probs = []
+        for i, d in enumerate(self.dims):
+            w, P = self.ws[i], self.m.p
+            a, W, out = w[a_key], P[f'm{i}.{lin}.W'], w[out_key]
+            nout, nin = W.shape
+            probs.append(nv.gemm_problem(a, W, out, self.B, nout, nin, nin, nin, nout,
+                                         bias=P[f'm{i}.{lin}.b'] if with_bias else None,
+                                         splitk=w['sk'][sk_key], slab_stride=self.B * nout))
+        nv.gemm(probs, nv.NT)
+
+    def _dx_gemm(self, dy_key, lin, out_key, sk_key):
+        """dx[B, in_f] (slabs) = dy[B, out_f] W."""
+        probs = []
+        for i, d in enumerate(self.dims):
+            w, P = self.ws[i], self.m.p
+            dy, W, out = w[dy_key], P[f'm{i}.{lin}.W'], w[out_key]
+            nout, nin = W.shape
+            probs.append(nv.gemm_problem(dy, W, out, self.B, nin, nout, nout, nin, nin,
+                                         splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+        nv.gemm(probs, nv.NN)
+
+    def _dw_gemm(self, dy_key, a_key, lin):
+        """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer."""
+        probs = []
+        for i, d in enumerate(self.dims):
+            w = self.ws[i]
+            dy, a, dW = w[dy_key], w[a_key], self.g[f'm{i}.{lin}.W']
+            nout, nin = dW.shape
+            probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
+        nv.gemm(probs, nv.TN)
+
+    def _latent_desc(self, corr, Fblk, noise):
+        B, L = self.B, self.L
+        d = nv.Latent()
+        d.B, d.L = B, L
+        for i in range(2):
+            w = self.ws[i]
+            d.ml[i] = nv.ptr(w['ml']); d.head_bias[i] = nv.ptr(self.m.p[f'm{i}.head.b'])
+            d.eps_in[i] = nv.ptr(noise['eps'][i]) if noise is not None else None
+            for k in ('mu', 'lv', 'z', 'eps', 'comb', 'cz', 'H', 'ch', 'dml'):
+                getattr(d, k)[i] = nv.ptr(w[k])
+            d.dcomb[i] = nv.ptr(w['dcomb'])
+        d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
+        d.sigma, d.corr, d.Fblk, d.hyper = nv.ptr(self.m.p['sigma']), nv.ptr(corr), nv.ptr(Fblk), nv.ptr(self.hyper)
+        d.rsum, d.qsum, d.fc1, d.fte = nv.ptr(self.rsum), nv.ptr(self.qsum), nv.ptr(self.fc1), nv.ptr(self.fte)
+        d.partials = nv.ptr(self.lat_partials)
+        d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['dcomb'].shape[0], B * L
+        d.dsigma = nv.ptr(self.g['sigma'])
+        d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
+        d.losses = nv.ptr(self.losses)
+        d.cosine, d.rng_stream = int(self.cosine), 100
+        return d
+
+    # ---- the step ----
+    def load_batch(self, data, idx):
+        """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors."""
+        for i in range(2):
+            nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
+
+    def forward_backward(self, corr=None, Fblk=None, noise=None):
+        """Forward, losses and backward for the batch already in the workspace.  `corr` None = identity,
+        `Fblk` None = 0; `noise` (explicit masks / eps, for parity tests) None = Philox streams."""
+        B, L = self.B, self.L
+        # ---------------- forward ----------------
+        self._fwd_gemm('x', 'enc0', 'h1', 'enc0')
+        self._bn_fwd('bn0', 'h1', 'a1', 10, noise, 'enc_masks', 0)
+        self._fwd_gemm('a1', 'enc1', 'h2', 'enc1')
+        self._bn_fwd('bn1', 'h2', 'a2', 11, noise, 'enc_masks', 1)
+        self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)      # bias added in the latent kernel
+        lat = self._latent_desc(corr, Fblk, noise)
+        nv.latent_fwd(lat, self.state)
+        self._fwd_gemm('comb', 'dec0', 'g1', 'dec0')
+        self._bn_fwd('bn2', 'g1', 'e1', 12, noise, 'dec_masks', 0)
+        self._fwd_gemm('e1', 'dec1', 'g2', 'dec1')
+        self._bn_fwd('bn3', 'g2', 'e2', 13, noise, 'dec_masks', 1)
+        probs, off = [], 0
+        for i, d in enumerate(self.dims):                                 # x_hat GEMM + fused MSE
+            w, P = self.ws[i], self.m.p
+            W = P[f'm{i}.dec2.W']
+            probs.append(nv.gemm_problem(w['e2'], W, w['dxhat'], B, d, 2 * d, 2 * d, 2 * d, d,
+                                         bias=P[f'm{i}.dec2.b'], epi=nv.EPI_MSE, aux=(w['x'], None, None, None),
+                                         aux_ld=d, partial=self.rec_partials[off:off + self.rec_tiles[i]],
+                                         scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
+            off += self.rec_tiles[i]
+        nv.gemm(probs, nv.NT)
+        # ---------------- backward ----------------
+        acc = self.accumulate
+        for i, d in enumerate(self.dims):
+            nv.colsum(self.ws[i]['dxhat'], B, d, d, self.g[f'm{i}.dec2.b'], accumulate=acc)
+        self._dw_gemm('dxhat', 'e2', 'dec2')
+        self._dx_gemm('dxhat', 'dec2', 'de2', 'd_e2')
+        self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1)   # de2[0] <- dg2p
+        self._dw_gemm('de2', 'e1', 'dec1')
+        self._dx_gemm('de2', 'dec1', 'de1', 'd_e1')
+        self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
+        self._dw_gemm('de1', 'comb', 'dec0')
+        self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
+        nv.latent_bwd(lat)                                                      # dml, dsigma, losses
+        for i, d in enumerate(self.dims):
+            nv.colsum(self.ws[i]['dml'], B, 2 * L, 2 * L, self.g[f'm{i}.head.b'], accumulate=acc)
+        self._dw_gemm('dml', 'a2', 'head')
+        self._dx_gemm('dml', 'head', 'da2', 'd_a2')
+        self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
+        self._dw_gemm('da2', 'a1', 'enc1')
+        self._dx_gemm('da2', 'enc1', 'da1', 'd_a1')
+        self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
+        self._dw_gemm('da1', 'x', 'enc0')
+        self.m.num_batches_tracked += 1
+
+    def optimizer_step(self):
+        """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step)."""
+        nv.grad_sqnorm(self.grad, self.norm_partials, self.state)
+        nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.norm_partials, self.hyper,
+                     self.state)
+
+    def step(self, corr=None, Fblk=None, noise=None, allreduce=None):
+        self.forward_backward(corr, Fblk, noise)
+        if allreduce is not None:
+            allreduce(self.grad)
+        self.optimizer_step()
+
+    def read_losses(self):
+        """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""
+        v = self.losses.tolist()
+        return v[:4], v[4], v[5]

@@ -1,0 +1,365 @@
+"""`JAMIE` facade with the reference's constructor and method surface (reference jamie/jamie.py:29-972)
+for the coupled-VAE path: `fit_transform` / `fit`, `transform`, `transform_one`, `modal_predict` /
+`impute`, `save_model`, `load_model`, `loss_history`.
+
+Scope: `project_mode='jamie'` with the correspondence `F` either absent (`use_f_tilde=False`) or supplied
+as `match_result`.  Stage A (`compute_distances`, jamie.py:839-890) and stage B (`match`/`Prime_Dual`,
+jamie.py:224-414) are dense O(N^2)/O(N^3) preprocessing outside this hot path; asking for them raises.
+Unlike the reference no N x N matrix is ever formed when `P` is the identity (the reference's default for
+equally sized datasets, jamie.py:425-426): the B x B block `P[idx][:, idx]` is index equality.
+"""
+import random
+import warnings
+
+import numpy as np
+import torch
+
+from . import _native as nv
+from . import distributed as jd
+from .engine import LOSS_NAMES, TrainEngine, kl_anneal
+from .model import edModelVar
+from .utilities import preclass, time_logger
+
+_DISTANCE_MODES = [
+    'euclidean', 'l2', 'l1', 'manhattan', 'cityblock', 'braycurtis', 'canberra', 'chebyshev', 'correlation',
+    'cosine', 'dice', 'hamming', 'jaccard', 'kulsinski', 'mahalanobis', 'matching', 'minkowski',
+    'rogerstanimoto', 'russellrao', 'seuclidean', 'sokalmichener', 'sokalsneath', 'sqeuclidean', 'yule',
+    'wminkowski', 'nan_euclidean', 'haversine', 'geodesic', 'spearman', 'pearson']
+
+
+def init_random_seed(manual_seed):
+    """unioncom.utils.init_random_seed (called at reference jamie.py:142): seeds python `random` and torch."""
+    seed = random.randint(1, 10000) if manual_seed is None else manual_seed
+    print('use random seed: {}'.format(seed))
+    random.seed(seed)
+    torch.manual_seed(seed)
+    return seed
+
+
+def _row_normalise(blk):
+    """reference jamie.py:587-589 / 593-595."""
+    s = blk.sum(dim=1)
+    s = torch.where(s == 0, torch.ones_like(s), s)
+    return blk / s[:, None]
+
+
+class JAMIE:
+    """MI355X drop-in for `jamie.JAMIE` (coupled-VAE path).
+
+    Constructor keywords are the reference's (jamie.py:38-63) plus the UnionCom keywords it forwards
+    (jamie.py:99-111; defaults from unioncom==0.4.0).  Extra, MI355X-only keywords:
+      sampler      'numpy' (default; the reference's `np.random.choice` index stream) or 'device'
+                   (Philox sampler on the GPU, no host work per step)
+      distributed  True -> one process per GPU under torchrun; cells are sharded by rows and the flat
+                   gradient is all-reduced once per step over RCCL
+    """
+
+    def __init__(self, match_result=None, PF_Ratio=None, corr_method='unioncom', dist_method='euclidean',
+                 in_place=False, loss_weights=None, model_pca='pca', model_class=edModelVar, model_lr=1e-3,
+                 dropout=None, pca_dim=2 * [512], batch_step=True, use_f_tilde=True, use_early_stop=True,
+                 min_epochs=2500, min_increment=1e-8, max_steps_without_increment=500, debug=False,
+                 log_debug=100, record_loss=True, enable_memory_logging=False, device='cuda',
+                 sampler='numpy', distributed=False, **kwargs):
+        self.match_result = match_result
+        self.PF_Ratio = PF_Ratio
+        self.corr_method = corr_method
+        self.dist_method = dist_method
+        self.in_place = in_place
+        self.loss_weights = loss_weights
+        self.model_pca = model_pca
+        self.model_class = model_class
+        self.model_lr = model_lr
+        self.dropout = dropout
+        self.pca_dim = pca_dim
+        self.batch_step = batch_step
+        self.use_f_tilde = use_f_tilde
+        self.use_early_stop = use_early_stop
+        self.min_epochs = min_epochs
+        self.min_increment = min_increment
+        self.max_steps_without_increment = max_steps_without_increment
+        self.debug = debug
+        self.log_debug = log_debug
+        self.record_loss = record_loss
+        self.enable_memory_logging = enable_memory_logging
+        if device == 'cpu':
+            raise nv.JamieHipError("jamie_amd runs on the MI355X only; use device='cuda' (no CPU fallback)")
+        self.device = device
+        self.sampler = sampler
+        self.distributed = distributed
+        # UnionCom attributes (reference jamie.py:99-111 defaults, then unioncom 0.4.0's)
+        defaults = {'project_mode': 'jamie', 'log_pd': 500, 'lr': 1e-3, 'epoch_DNN': 10000, 'log_DNN': 500,
+                    'batch_size': 512, 'epoch_pd': 2000, 'epsilon': 1e-3, 'rho': 10, 'beta': 1, 'perplexity': 30,
+                    'manual_seed': 666, 'delay': 0, 'kmax': 40, 'output_dim': 32, 'distance_mode': 'geodesic',
+                    'integration_type': 'MultiOmics'}
+        for k, v in defaults.items():
+            setattr(self, k, kwargs.pop(k, v))
+        if kwargs:
+            raise TypeError(f'unexpected keyword arguments: {sorted(kwargs)}')
+        self.model = None
+        self.engine = None
+        self.loss_history = {}
+
+    # ------------------------------------------------------------------------------------------
+    def fit_transform(self, dataset=None, P=None):
+        """reference jamie.py:113-222."""
+        self.P = P
+        if self.integration_type not in ['MultiOmics']:
+            raise Exception('integration_type error! Enter MultiOmics.')
+        if self.distance_mode not in _DISTANCE_MODES:
+            raise Exception('distance_mode error! Enter a correct distance_mode.')
+        if self.project_mode not in ('jamie', 'tsne'):
+            raise Exception("Choose correct project_mode: 'nlma', 'tsne'.")
+        assert self.model_pca in ('pca', 'umap')
+        if self.project_mode == 'tsne':
+            raise NotImplementedError("project_mode='tsne' is outside the accelerated path (SURVEY.md §8)")
+        if self.use_f_tilde and self.match_result is None:
+            raise NotImplementedError(
+                'Stages A/B (compute_distances + Prime_Dual, reference jamie.py:224-414, 839-890) are outside '
+                'the accelerated path: pass use_f_tilde=False, or a precomputed match_result=[F].')
+        time = time_logger(sync=torch.cuda.synchronize)
+        init_random_seed(self.manual_seed)                         # jamie.py:142
+        self.dataset = dataset
+        self.dataset_annotation = None
+        if hasattr(self.dataset[0], 'X') and not isinstance(self.dataset[0], np.ndarray):   # AnnData
+            self.dataset = [d.X for d in self.dataset]
+            self.dataset_annotation = dataset
+        if not self.in_place:
+            self.dataset = self.dataset * 1                        # shallow copy, jamie.py:152-153
+        self.dataset_num = len(self.dataset)
+        self.row = [np.shape(d)[0] for d in self.dataset]
+        self.col = [np.shape(d)[1] for d in self.dataset]
+        time.log('Distance')
+        time.log('Correspondence')
+        integrated = self.project_jamie()
+        time.log('Mapping')
+        print('-' * 33)
+        print('JAMIE Done!')
+        time.aggregate()
+        print()
+        return integrated
+
+    def fit(self, dataset=None, P=None):
+        """north_star spelling: train, return self."""
+        self._last_embedding = self.fit_transform(dataset, P)
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def _build_preprocessing(self):
+        """reference jamie.py:434-469."""
+        pre = []
+        if self.pca_dim is not None:
+            for dim, data in zip(self.pca_dim, self.dataset):
+                if dim is not None:
+                    from sklearn.decomposition import PCA
+                    if min(*data.shape) < dim:
+                        warnings.warn(f'PCA dim must be lower than {min(*data.shape)}, found {dim}, '
+                                      f'adjusting to compensate.')
+                        dim = min(*data.shape)
+                    if self.model_pca != 'pca':
+                        raise NotImplementedError("model_pca='umap' needs umap-learn (absent)")
+                    pca = PCA(n_components=dim)
+                    sample = pca.fit_transform(data)
+                    pre.append(preclass(sample, pca=pca))
+                else:
+                    pre.append(preclass(np.asarray(data), axis=0))
+        else:
+            pre = [preclass(np.asarray(d), axis=0) for d in self.dataset]
+        return pre
+
+    def project_jamie(self, W=None):
+        """The training loop, reference jamie.py:416-804."""
+        print('-' * 33)
+        print('Train coupled autoencoders')
+        assert self.dataset_num == 2, 'Currently only compatible with 2 modalities.'
+        dev = torch.device(self.device)
+        rank, world = 0, 1
+        allreduce = None
+        if self.distributed:
+            rank, world, _ = jd.init_from_env()
+            allreduce = jd.GradAllReduce()
+        # ---- P / F (never densified for the identity) ----
+        P_dense = None
+        if self.P is None:
+            method = 'diag' if self.row[0] == self.row[1] else 'zeros'      # jamie.py:423-428, 518-533
+        else:
+            P_dense = torch.as_tensor(np.asarray(self.P), dtype=torch.float32, device=dev)
+            if P_dense.shape[0] == P_dense.shape[1] and torch.abs(
+                    P_dense - torch.eye(self.row[0], device=dev)).sum() == 0:
+                method, P_dense = 'diag', None
+            elif torch.abs(P_dense).sum() != 0:
+                raise NotImplementedError("partial correspondence ('hybrid' sampling, reference jamie.py:523-579) "
+                                          'is the next scope row (SURVEY.md §8(f) rank 2)')
+            else:
+                method = 'zeros'
+        self.sampling_method = method
+        F_dense = None
+        if self.use_f_tilde:
+            F_dense = torch.as_tensor(np.asarray(self.match_result[0]), dtype=torch.float32, device=dev)
+        timer = time_logger(sync=torch.cuda.synchronize)
+        # ---- preprocessing (host, numpy/sklearn like the reference) ----
+        pre = self._build_preprocessing()
+        self.dataset = [p.transform(np.asarray(x)) for p, x in zip(pre, self.dataset)]
+        self.col = [x.shape[1] for x in self.dataset]
+        # ---- model / engine ----
+        self.model = self.model_class(self.col, self.output_dim, preprocessing=[p.transform for p in pre],
+                                      preprocessing_inverse=[p.inverse_transform for p in pre],
+                                      dropout=self.dropout).to(self.device)
+        if world > 1:
+            jd.broadcast_flat(self.model.flat)
+        self.model.train()
+        data_all = [torch.from_numpy(np.ascontiguousarray(x)).float() for x in self.dataset]
+        # row shards for data parallelism ('diag' keeps the same rows of both modalities on one rank)
+        bounds = [jd.shard_bounds(r, rank, world) for r in self.row]
+        data = [d[lo:hi].to(dev) for d, (lo, hi) in zip(data_all, bounds)]
+        rows = [hi - lo for lo, hi in bounds]
+        len_dataloader = int(np.max(rows) / self.batch_size)                 # jamie.py:511-514
+        if len_dataloader == 0:
+            len_dataloader = 1
+            self.batch_size = int(np.max(rows))
+        B = int(self.batch_size)
+        self.PF_Ratio = 1 if self.PF_Ratio is None else self.PF_Ratio        # jamie.py:517
+        eng = TrainEngine(self.model, B, lr=self.model_lr, loss_weights=self.loss_weights,
+                          dist_method=self.dist_method, seed=int(self.manual_seed) + 7919 * rank,
+                          world_size=world)
+        eng.accumulate = False
+        self.engine = eng
+        rep = min(self.col) < B                                              # jamie.py:553 (sic)
+        need_block = (method == 'diag' and rep) or method == 'zeros' or F_dense is not None or P_dense is not None
+        idx_dev = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        best_running_loss = np.inf
+        streak = 0
+        if self.record_loss:
+            self.loss_history = {}
+        if not self.batch_step:
+            raise NotImplementedError('batch_step=False (one optimiser step per epoch) is not accelerated yet')
+        timer.log('Setup')
+        for epoch in range(self.epoch_DNN):                                   # jamie.py:546
+            eng.set_kl_anneal(kl_anneal(epoch, self.min_epochs, self.epoch_DNN))
+            eng.reset_best()
+            for batch_idx in range(len_dataloader):
+                # ---- sampler (jamie.py:552-583) ----
+                if self.sampler == 'numpy':
+                    if method == 'diag':
+                        s = np.random.choice(range(rows[0]), B, replace=rep)
+                        idx_dev[0].copy_(torch.from_numpy(s.astype(np.int32)))
+                        idx_dev[1].copy_(idx_dev[0])
+                    else:
+                        for i in range(2):
+                            s = np.random.choice(range(rows[i]), B, replace=rep)
+                            idx_dev[i].copy_(torch.from_numpy(s.astype(np.int32)))
+                else:
+                    nv.sample_indices(idx_dev[0], rows[0], 0, rep, eng.state, 200)
+                    if method == 'diag':
+                        idx_dev[1].copy_(idx_dev[0])
+                    else:
+                        nv.sample_indices(idx_dev[1], rows[1], 0, rep, eng.state, 201)
+                eng.load_batch(data, idx_dev)
+                # ---- P / F blocks (jamie.py:585-604) ----
+                corr = Fblk = None
+                if need_block:
+                    i0, i1 = idx_dev[0].long(), idx_dev[1].long()
+                    if P_dense is not None:
+                        Pb = _row_normalise(P_dense[i0 + bounds[0][0]][:, i1 + bounds[1][0]])
+                    elif method == 'diag':
+                        nv.corr_from_indices(idx_dev[0], idx_dev[1], eng.corr)
+                        Pb = eng.corr
+                    else:
+                        Pb = torch.zeros(B, B, device=dev)
+                    if F_dense is not None:
+                        Fblk = _row_normalise(F_dense[i0 + bounds[0][0]][:, i1 + bounds[1][0]]).contiguous()
+                        corr = (self.PF_Ratio * Pb + (1 - self.PF_Ratio) * Fblk).contiguous()
+                    else:
+                        corr = (self.PF_Ratio * Pb).contiguous() if self.PF_Ratio != 1 else Pb
+                timer.log('Get subset samples')
+                eng.step(corr, Fblk, None, allreduce)
+                timer.log('Step')
+            # ---- per-epoch bookkeeping (one device read per epoch; jamie.py:751-792) ----
+            ls, total, best_batch_loss = eng.read_losses()
+            if self.record_loss:
+                for name, lo in zip(LOSS_NAMES, ls):
+                    self.loss_history.setdefault(name, []).append(lo)
+            if (epoch + 1) % self.log_debug == 0 and self.debug:
+                print('  '.join(f'{n}: {lo:.4f}' for n, lo in zip(LOSS_NAMES, ls)))
+            if (epoch + 1) % self.log_DNN == 0:
+                print(f'epoch:[{epoch + 1:d}/{self.epoch_DNN}]: loss:{total:4f}')
+            if epoch > self.min_epochs:
+                if best_running_loss - best_batch_loss > self.min_increment:
+                    best_running_loss = best_batch_loss
+                    streak = 0
+                else:
+                    streak += 1
+                if streak >= self.max_steps_without_increment and self.use_early_stop:
+                    break
+        self.model.eval()
+        out = [self.model.embed(data_all[i], i).cpu().numpy() for i in range(2)]   # jamie.py:794-799
+        timer.log('Output')
+        print('Finished Mapping!')
+        if self.debug:
+            timer.aggregate()
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def modal_predict(self, data, modality, pre_transformed=False):
+        """reference jamie.py:806-815 (returns float64: the inverse scaling promotes)."""
+        assert self.model is not None, 'Model must be trained before modal prediction.'
+        to_modality = (modality + 1) % self.dataset_num
+        if not pre_transformed:
+            data = self.model.preprocessing[modality](np.asarray(data))
+        self.model.eval()
+        decoded = self.model.impute(torch.as_tensor(np.asarray(data)).float(), compose=[modality, to_modality])
+        return np.array(self.model.preprocessing_inverse[to_modality](decoded.detach().cpu()))
+
+    def impute(self, data, modality, pre_transformed=False):
+        """north_star spelling of `modal_predict`."""
+        return self.modal_predict(data, modality, pre_transformed)
+
+    def transform(self, dataset, corr=None, pre_transformed=False):
+        """reference jamie.py:817-829.  In eval mode the returned embeddings are the `mu`s, so `corr` has no
+        effect ("Doesn't actually do anything", jamie.py:820) and no N x N matrix is built."""
+        if not pre_transformed:
+            dataset = [self.model.preprocessing[i](np.asarray(dataset[i])) for i in range(len(dataset))]
+        self.model.eval()
+        return [self.model.embed(torch.as_tensor(np.asarray(d)).float(), i).cpu().numpy()
+                for i, d in enumerate(dataset)]
+
+    def transform_one(self, data, i, pre_transformed=False):
+        """reference jamie.py:831-837."""
+        if not pre_transformed:
+            data = self.model.preprocessing[i](np.asarray(data))
+        self.model.eval()
+        return self.model.embed(torch.as_tensor(np.asarray(data)).float(), i).cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------
+    def save_model(self, f):
+        """reference jamie.py:967-968.  Saved as state_dict + preprocessing objects (the reference's
+        whole-module pickle no longer loads on torch >= 2.6)."""
+        m = self.model
+        torch.save({'format': 'jamie_amd.v1', 'input_dim': m.input_dim, 'output_dim': m.output_dim,
+                    'dropout': m.dropout, 'state_dict': {k: v.cpu() for k, v in m.state_dict().items()},
+                    'preprocessing': m.preprocessing, 'preprocessing_inverse': m.preprocessing_inverse}, f)
+
+    def load_model(self, f):
+        """reference jamie.py:970-972."""
+        ck = torch.load(f, weights_only=False)
+        m = self.model_class(ck['input_dim'], ck['output_dim'], preprocessing=ck['preprocessing'],
+                             preprocessing_inverse=ck['preprocessing_inverse'], dropout=ck['dropout'])
+        m.load_state_dict(ck['state_dict'])
+        self.model = m.to(self.device)
+        self.dataset_num = self.model.num_modalities
+
+    # ---- metrics kept for sanity checks (reference jamie.py:892-915) ----
+    def test_closer(self, integrated_data, distance_metric=None):
+        """FOSCTTM: fraction of samples closer than the true match."""
+        assert len(integrated_data) == 2, 'Two datasets are supported for FOSCTTM'
+        from sklearn.metrics.pairwise import pairwise_distances
+        d = pairwise_distances(np.concatenate(integrated_data, axis=0), metric='euclidean')
+        size = integrated_data[0].shape[0]
+        closer = 0
+        for i in range(size):
+            ld = d[i][size:]
+            closer += np.sum(ld < ld[i])
+            ld = d[size + i][:size]
+            closer += np.sum(ld < ld[i])
+        foscttm = closer / (2 * size ** 2)
+        print(f'foscttm: {foscttm}')
+        return foscttm

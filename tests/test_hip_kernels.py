@@ -1,0 +1,463 @@
+"""Per-kernel parity tests of libjamie_hip.so through the C ABI (ctypes), against fp64/fp32 PyTorch CPU
+references and the oracle.  Run on the MI355X box:  pytest -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import jamie_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nv():
+    from jamie_amd import _native
+    _native.require_gpu()
+    return _native
+
+
+def dev(t):
+    return t.to('cuda').contiguous()
+
+
+def close(a, ref, rtol=1e-4, atol=1e-5, msg=''):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
+    np.testing.assert_allclose(a, ref, rtol=rtol, atol=atol, err_msg=msg)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(64, 64, 32), (512, 256, 128), (100, 70, 50), (33, 130, 17), (512, 64, 1000), (17, 3, 5),
+               (130, 257, 264), (256, 1000, 512)]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+def test_gemm_layouts(nv, layout, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ b.double() + (bias.double() if layout == 'NT' else 0)
+    out = torch.full((M, N), float('nan'), device='cuda')
+    if layout == 'NT':
+        A, Bm = dev(a), dev(b.t())
+        pr = nv.gemm_problem(A, Bm, out, M, N, K, K, K, N, bias=dev(bias))
+        nv.gemm([pr], nv.NT)
+    elif layout == 'NN':
+        A, Bm = dev(a), dev(b)
+        nv.gemm([nv.gemm_problem(A, Bm, out, M, N, K, K, N, N)], nv.NN)
+    else:
+        A, Bm = dev(a.t()), dev(b)
+        nv.gemm([nv.gemm_problem(A, Bm, out, M, N, K, M, N, N)], nv.TN)
+    torch.cuda.synchronize()
+    scale = float(np.sqrt(K))
+    close(out, ref, rtol=1e-5, atol=2e-6 * scale)
+
+
+def test_gemm_identity_asymmetric(nv):
+    """A = I with an asymmetric B catches a swapped C/D register map (cdna_hip_programming.md §3)."""
+    n = 96
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    out = torch.zeros(n, n, device='cuda')
+    nv.gemm([nv.gemm_problem(dev(torch.eye(n)), dev(B), out, n, n, n, n, n, n)], nv.NN)
+    assert torch.equal(out.cpu(), B)
+    nv.gemm([nv.gemm_problem(dev(torch.eye(n)), dev(B.t()), out, n, n, n, n, n, n)], nv.NT)
+    assert torch.equal(out.cpu(), B)
+    nv.gemm([nv.gemm_problem(dev(torch.eye(n)), dev(B), out, n, n, n, n, n, n)], nv.TN)
+    assert torch.equal(out.cpu(), B)
+
+
+@pytest.mark.parametrize('splitk', [2, 3, 7])
+def test_gemm_splitk_slabs(nv, splitk):
+    M, N, K = 200, 48, 1000
+    g = torch.Generator().manual_seed(splitk)
+    a, w, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    slabs = torch.full((splitk, M, N), float('nan'), device='cuda')
+    nv.gemm([nv.gemm_problem(dev(a), dev(w), slabs, M, N, K, K, K, N, bias=dev(bias), splitk=splitk,
+                             slab_stride=M * N)], nv.NT)
+    close(slabs.sum(0), a.double() @ w.double().t() + bias.double(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_grouped_and_row_gather(nv):
+    g = torch.Generator().manual_seed(5)
+    table = torch.randn(300, 72, generator=g)
+    rows = torch.randint(0, 300, (64,), generator=g, dtype=torch.int32)
+    w0, w1 = torch.randn(144, 72, generator=g), torch.randn(40, 66, generator=g)
+    x1 = torch.randn(64, 66, generator=g)
+    o0 = torch.zeros(64, 144, device='cuda')
+    o1 = torch.zeros(64, 40, device='cuda')
+    nv.gemm([nv.gemm_problem(dev(table), dev(w0), o0, 64, 144, 72, 72, 72, 144, a_rows=dev(rows)),
+             nv.gemm_problem(dev(x1), dev(w1), o1, 64, 40, 66, 66, 66, 40)], nv.NT)
+    close(o0, table[rows.long()].double() @ w0.double().t(), rtol=1e-5, atol=2e-5)
+    close(o1, x1.double() @ w1.double().t(), rtol=1e-5, atol=2e-5)
+
+
+def test_gemm_mse_epilogue(nv):
+    B, d, K = 100, 150, 80
+    g = torch.Generator().manual_seed(9)
+    e2, W, b, X = (torch.randn(B, K, generator=g), torch.randn(d, K, generator=g), torch.randn(d, generator=g),
+                   torch.randn(B, d, generator=g))
+    import math
+    tiles = math.ceil(B / 64) * math.ceil(d / 128)
+    part = torch.zeros(tiles, device='cuda')
+    out = torch.zeros(B, d, device='cuda')
+    scale = 2.0 / (B * d)
+    nv.gemm([nv.gemm_problem(dev(e2), dev(W), out, B, d, K, K, K, d, bias=dev(b), epi=nv.EPI_MSE,
+                             aux=(dev(X), None, None, None), aux_ld=d, partial=part, scale=scale,
+                             pscale=1.0 / (B * d))], nv.NT)
+    diff = e2.double() @ W.double().t() + b.double() - X.double()
+    close(out, diff * scale, rtol=1e-5, atol=1e-7)
+    close(part.sum(), (diff ** 2).mean(), rtol=1e-5, atol=0)
+
+
+def test_gemm_bn_eval_epilogue(nv):
+    n, K, N = 77, 40, 90
+    g = torch.Generator().manual_seed(11)
+    x, W, b = torch.randn(n, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    rm, rv = torch.randn(N, generator=g), torch.rand(N, generator=g) + .5
+    ga, be = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    out = torch.zeros(n, N, device='cuda')
+    nv.gemm([nv.gemm_problem(dev(x), dev(W), out, n, N, K, K, K, N, bias=dev(b), epi=nv.EPI_BN_EVAL,
+                             aux=(dev(rm), dev(rv), dev(ga), dev(be)), slope=0.01, eps=1e-5)], nv.NT)
+    h = torch.nn.functional.linear(x.double(), W.double(), b.double())
+    ref = torch.nn.functional.leaky_relu(
+        torch.nn.functional.batch_norm(h, rm.double(), rv.double(), ga.double(), be.double(), False, 0.1, 1e-5), 0.01)
+    close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_gemm_accumulate(nv):
+    M, N, K = 70, 90, 64
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    c0 = torch.randn(M, N, generator=g)
+    out = dev(c0.clone())
+    nv.gemm([nv.gemm_problem(dev(a), dev(b), out, M, N, K, M, N, N, accumulate=True)], nv.TN)
+    close(out, c0.double() + a.double().t() @ b.double(), rtol=1e-5, atol=2e-5)
+
+
+def test_gemm_bad_arguments_fail_loudly(nv):
+    a = torch.zeros(4, 4, device='cuda')
+    with pytest.raises(nv.JamieHipError):
+        nv.gemm([nv.gemm_problem(a, a, a, 4, 4, 4, 2, 4, 4)], nv.NT)           # lda < K
+    with pytest.raises(nv.JamieHipError):
+        nv.gemm([nv.gemm_problem(a, a, a, 4, 4, 4, 4, 4, 4, epi=nv.EPI_MSE)], nv.NT)   # aux missing
+    with pytest.raises(nv.JamieHipError):
+        nv.gemm_problem(torch.zeros(4, 4), a, a, 4, 4, 4, 4, 4, 4)               # CPU tensor
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm + LeakyReLU + Dropout
+# ------------------------------------------------------------------------------------------------
+def _bn_ref(h, gamma, beta, mask, p, da):
+    h = h.double().requires_grad_(True)
+    gamma = gamma.double().requires_grad_(True)
+    beta = beta.double().requires_grad_(True)
+    rm, rv = torch.zeros(h.shape[1], dtype=torch.float64), torch.ones(h.shape[1], dtype=torch.float64)
+    y = torch.nn.functional.batch_norm(h, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    y = torch.nn.functional.leaky_relu(y, 0.01)
+    if p > 0:
+        y = y * (mask.double() / (1 - p))
+    y.backward(da.double())
+    return y.detach(), rm, rv, h.grad, gamma.grad, beta.grad
+
+
+@pytest.mark.parametrize('B,N,p,nslab', [(32, 40, 0.6, 1), (512, 100, 0.6, 2), (100, 33, 0.0, 1), (700, 24, 0.25, 3)])
+def test_bn_act_fwd_bwd(nv, B, N, p, nslab):
+    g = torch.Generator().manual_seed(B + N)
+    hs = torch.randn(nslab, B, N, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(N, generator=g) + .5, torch.randn(N, generator=g)
+    mask = (torch.rand(B, N, generator=g) >= p).to(torch.uint8)
+    da_s = torch.randn(nslab, B, N, generator=g)
+    h_sum, da = hs.sum(0), da_s.sum(0)
+    y, rm, rv, dh, dg, db = _bn_ref(h_sum, gamma, beta, mask, p, da)
+    hd = dev(hs)
+    out = torch.zeros(B, N, device='cuda')
+    rmean, rvar = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda')
+    smean, sinv = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+    mk = dev(mask) if p > 0 else None
+    pr = nv.BnFwdProblem()
+    pr.h, pr.nslab, pr.slab_stride = nv.ptr(hd), nslab, B * N
+    pr.gamma, pr.beta = nv.ptr(dev(gamma)), nv.ptr(dev(beta))
+    gd, bd = dev(gamma), dev(beta)
+    pr.gamma, pr.beta = nv.ptr(gd), nv.ptr(bd)
+    pr.running_mean, pr.running_var, pr.save_mean, pr.save_invstd = (nv.ptr(rmean), nv.ptr(rvar), nv.ptr(smean),
+                                                                      nv.ptr(sinv))
+    pr.out, pr.mask, pr.B, pr.N, pr.rng_stream = nv.ptr(out), nv.ptr(mk), B, N, 0
+    nv.bn_act_fwd([pr], p, None)
+    close(out, y, rtol=1e-4, atol=1e-5)
+    close(rmean, rm, rtol=1e-5, atol=1e-6)
+    close(rvar, rv, rtol=1e-5, atol=1e-6)
+    close(hd[0], h_sum, rtol=1e-6, atol=1e-6)
+    dad = dev(da_s)
+    dgam, dbet, dbl = (torch.zeros(N, device='cuda') for _ in range(3))
+    pb = nv.BnBwdProblem()
+    pb.da, pb.nslab, pb.slab_stride = nv.ptr(dad), nslab, B * N
+    pb.h, pb.gamma, pb.beta, pb.save_mean, pb.save_invstd = nv.ptr(hd), nv.ptr(gd), nv.ptr(bd), nv.ptr(smean), nv.ptr(sinv)
+    pb.dgamma, pb.dbeta, pb.dbias_lin, pb.mask = nv.ptr(dgam), nv.ptr(dbet), nv.ptr(dbl), nv.ptr(mk)
+    pb.B, pb.N, pb.rng_stream, pb.accumulate = B, N, 0, 0
+    nv.bn_act_bwd([pb], p, None)
+    close(dad[0], dh, rtol=1e-3, atol=2e-5)
+    close(dgam, dg, rtol=1e-4, atol=1e-4)
+    close(dbet, db, rtol=1e-4, atol=1e-4)
+    assert dbl.abs().max().item() < 1e-3      # colsum(dh) is mathematically zero
+
+
+def test_dropout_rng_consistency_and_rate(nv):
+    """Philox masks: forward and backward regenerate the same mask; keep rate = 1 - p; a new step or a
+    different stream gives a different mask."""
+    B, N, p = 512, 256, 0.6
+    h = torch.randn(1, B, N)
+    hd = dev(h)
+    state = torch.tensor([1234, 0, 0, 0], dtype=torch.int64, device='cuda')
+    ones, zeros = torch.ones(N, device='cuda'), torch.zeros(N, device='cuda')
+
+    def fwd(stream):
+        out = torch.zeros(B, N, device='cuda')
+        pr = nv.BnFwdProblem()
+        pr.h, pr.nslab, pr.slab_stride, pr.gamma, pr.beta = nv.ptr(hd), 1, B * N, nv.ptr(ones), nv.ptr(zeros)
+        rm, rv, sm, si = (torch.zeros(N, device='cuda') for _ in range(4))
+        pr.running_mean, pr.running_var, pr.save_mean, pr.save_invstd = nv.ptr(rm), nv.ptr(rv), nv.ptr(sm), nv.ptr(si)
+        pr.out, pr.mask, pr.B, pr.N, pr.rng_stream = nv.ptr(out), None, B, N, stream
+        nv.bn_act_fwd([pr], p, state)
+        return out, sm, si
+    o1, sm, si = fwd(3)
+    o2, _, _ = fwd(3)
+    o3, _, _ = fwd(4)
+    assert torch.equal(o1, o2)
+    keep = (o1 != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.01
+    assert (o1 != 0).ne(o3 != 0).float().mean().item() > 0.3
+    # backward with da = 1: dy != 0 exactly where the forward kept the element
+    da = torch.ones(1, B, N, device='cuda')
+    dg, db = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+    pb = nv.BnBwdProblem()
+    pb.da, pb.nslab, pb.slab_stride = nv.ptr(da), 1, B * N
+    pb.h, pb.gamma, pb.beta, pb.save_mean, pb.save_invstd = nv.ptr(hd), nv.ptr(ones), nv.ptr(zeros), nv.ptr(sm), nv.ptr(si)
+    pb.dgamma, pb.dbeta, pb.dbias_lin, pb.mask = nv.ptr(dg), nv.ptr(db), None, None
+    pb.B, pb.N, pb.rng_stream, pb.accumulate = B, N, 3, 0
+    nv.bn_act_bwd([pb], p, state)
+    # dbeta = sum_b dy = sum over kept of (1/(1-p)) * lrelu'(y)
+    y = (h[0] - h[0].mean(0)) / torch.sqrt(h[0].var(0, unbiased=False) + 1e-5)
+    kept = (o1 != 0).cpu()
+    ref_db = (kept.float() / (1 - p) * torch.where(y > 0, 1.0, 0.01)).sum(0)
+    close(db, ref_db, rtol=1e-4, atol=1e-3)
+    state[1] = 1
+    o4, _, _ = fwd(3)
+    assert (o1 != 0).ne(o4 != 0).float().mean().item() > 0.3
+
+
+# ------------------------------------------------------------------------------------------------
+# latent block
+# ------------------------------------------------------------------------------------------------
+def _latent_case(nv, B, L, general, useF, cosine, nslab, seed):
+    g = torch.Generator().manual_seed(seed)
+    ml = [torch.randn(nslab, B, 2 * L, generator=g) * .5 for _ in range(2)]
+    hb = [torch.randn(2 * L, generator=g) * .1 for _ in range(2)]
+    eps = [torch.randn(B, L, generator=g) for _ in range(2)]
+    sigma = torch.rand(2, generator=g) + .2
+    corr = Fb = None
+    if general:
+        idx = torch.randint(0, B // 2 + 1, (B,), generator=g)
+        corr = orc.p_block(None, idx.numpy(), idx.numpy())
+        if useF:
+            Fb = orc.row_normalise(torch.rand(B, B, generator=g) * (torch.rand(B, B, generator=g) < .3))
+            corr = .5 * corr + .5 * Fb
+    dcomb = [torch.randn(nslab, B, L, generator=g) * .01 for _ in range(2)]
+    kl_scale, w_rec, w_al, w_f = 0.02, 1.0, 32.0 * 1.5, 0.7
+    # ---- reference (fp64 autograd) ----
+    mlr = [(m.sum(0) + b).double().requires_grad_(True) for m, b in zip(ml, hb)]
+    sig = sigma.double().requires_grad_(True)
+    mus = [m[:, :L] for m in mlr]
+    lvs = [m[:, L:] for m in mlr]
+    zs = [mus[i] + eps[i].double() * (torch.exp(lvs[i] / 2) + 1e-7) for i in range(2)]
+    C = torch.eye(B, dtype=torch.float64) if corr is None else corr.double()
+    Fm = torch.zeros(B, B, dtype=torch.float64) if Fb is None else Fb.double()
+    comb = orc.combine({'sigma': sig}, zs, C)
+    logv = lvs[1]
+    kl = sum(-.5 * torch.mean(1 + logv[i] - mus[i].square() - logv[i].exp(), axis=1).mean(axis=0) for i in range(2))
+    if cosine:
+        d = [1 - torch.nn.functional.cosine_similarity(zs[i], comb[i], dim=1, eps=0) for i in range(2)]
+        al = sum((d[i] ** 2).mean() / L for i in range(2))
+    else:
+        al = sum(((zs[i] - comb[i]) ** 2).sum(1).mean() / L for i in range(2))
+    lf = torch.square(comb[0] - Fm @ comb[1]).mean()
+    ext = sum((comb[i] * dcomb[i].sum(0).double()).sum() for i in range(2))    # stands for the decoder path
+    total = kl_scale * kl + w_al * al + w_f * lf + ext
+    total.backward()
+    # ---- HIP ----
+    f32 = dict(device='cuda', dtype=torch.float32)
+    d = nv.Latent()
+    d.B, d.L = B, L
+    keep = {}
+    hyper = torch.zeros(16)
+    hyper[0], hyper[1], hyper[2], hyper[3] = kl_scale, w_rec, w_al, w_f
+    keep['hyper'] = dev(hyper)
+    for i in range(2):
+        keep[f'ml{i}'], keep[f'hb{i}'], keep[f'eps{i}'], keep[f'dc{i}'] = dev(ml[i]), dev(hb[i]), dev(eps[i]), dev(dcomb[i])
+        d.ml[i], d.head_bias[i], d.eps_in[i], d.dcomb[i] = (nv.ptr(keep[f'ml{i}']), nv.ptr(keep[f'hb{i}']),
+                                                            nv.ptr(keep[f'eps{i}']), nv.ptr(keep[f'dc{i}']))
+        for k in ('mu', 'lv', 'z', 'eps', 'comb', 'cz', 'H', 'ch'):
+            keep[f'{k}{i}'] = torch.zeros(B, L, **f32)
+            getattr(d, k)[i] = nv.ptr(keep[f'{k}{i}'])
+        keep[f'dml{i}'] = torch.zeros(B, 2 * L, **f32)
+        d.dml[i] = nv.ptr(keep[f'dml{i}'])
+    d.ml_nslab, d.ml_slab_stride, d.dcomb_nslab, d.dcomb_slab_stride = nslab, B * 2 * L, nslab, B * L
+    keep['sigma'] = dev(sigma)
+    keep['corr'] = dev(corr) if corr is not None else None
+    keep['F'] = dev(Fb) if Fb is not None else None
+    for k in ('rsum', 'qsum'):
+        keep[k] = torch.zeros(B, **f32)
+    for k in ('fc1', 'fte'):
+        keep[k] = torch.zeros(B, L, **f32)
+    keep['partials'] = torch.zeros(16 * nv.load().jamie_max_partials(), **f32)
+    keep['dsigma'] = torch.zeros(2, **f32)
+    keep['losses'] = torch.zeros(8, **f32)
+    keep['losses'][5] = float('inf')
+    keep['rec'] = dev(torch.tensor([0.25, 0.5]))
+    d.sigma, d.corr, d.Fblk, d.hyper = nv.ptr(keep['sigma']), nv.ptr(keep['corr']), nv.ptr(keep['F']), nv.ptr(keep['hyper'])
+    d.rsum, d.qsum, d.fc1, d.fte, d.partials = (nv.ptr(keep['rsum']), nv.ptr(keep['qsum']), nv.ptr(keep['fc1']),
+                                               nv.ptr(keep['fte']), nv.ptr(keep['partials']))
+    d.dsigma, d.rec_partials, d.n_rec_partials, d.losses = nv.ptr(keep['dsigma']), nv.ptr(keep['rec']), 2, nv.ptr(keep['losses'])
+    d.cosine, d.rng_stream = int(cosine), 100
+    nv.latent_fwd(d, None)
+    nv.latent_bwd(d)
+    torch.cuda.synchronize()
+    for i in range(2):
+        close(keep[f'mu{i}'], mus[i], 1e-5, 1e-6, 'mu')
+        close(keep[f'z{i}'], zs[i], 1e-5, 1e-6, 'z')
+        close(keep[f'comb{i}'], comb[i], 1e-5, 1e-6, 'comb')
+        close(keep[f'dml{i}'], mlr[i].grad, 2e-4, 2e-6, f'dml{i}')
+    close(keep['dsigma'], sig.grad, 2e-4, 1e-5, 'dsigma')
+    ls = keep['losses'].cpu().double()
+    close(ls[0], kl_scale * kl, 1e-4, 1e-7, 'KL')
+    close(ls[1], w_rec * 0.75, 1e-6, 0, 'Rec')
+    close(ls[2], w_al * al, 1e-4, 1e-6, 'align')
+    close(ls[3], w_f * lf, 1e-4, 1e-7, 'F')
+    close(ls[4], ls[:4].sum(), 1e-6, 0)
+    close(ls[5], ls[4], 1e-7, 0)
+
+
+@pytest.mark.parametrize('B,L,general,useF,cosine,nslab', [
+    (16, 4, False, False, False, 1), (64, 8, True, False, False, 2), (48, 4, True, True, False, 1),
+    (20, 3, True, False, True, 1), (512, 32, False, False, False, 7), (300, 16, True, True, True, 2)])
+def test_latent_fwd_bwd(nv, B, L, general, useF, cosine, nslab):
+    _latent_case(nv, B, L, general, useF, cosine, nslab, B * 3 + L)
+
+
+def test_latent_rng_eps_is_standard_normal(nv):
+    """Without explicit eps the kernel draws N(0,1): check moments and that z = mu + eps*std holds."""
+    B, L = 1024, 32
+    f32 = dict(device='cuda', dtype=torch.float32)
+    d = nv.Latent()
+    d.B, d.L = B, L
+    keep = {'hyper': torch.ones(16, **f32), 'sigma': torch.ones(2, **f32)}
+    for i in range(2):
+        keep[f'ml{i}'] = torch.zeros(1, B, 2 * L, **f32)
+        keep[f'hb{i}'] = torch.zeros(2 * L, **f32)
+        d.ml[i], d.head_bias[i], d.eps_in[i] = nv.ptr(keep[f'ml{i}']), nv.ptr(keep[f'hb{i}']), None
+        for k in ('mu', 'lv', 'z', 'eps', 'comb', 'cz'):
+            keep[f'{k}{i}'] = torch.zeros(B, L, **f32)
+            getattr(d, k)[i] = nv.ptr(keep[f'{k}{i}'])
+    d.ml_nslab, d.ml_slab_stride = 1, B * 2 * L
+    keep['rsum'], keep['qsum'] = torch.zeros(B, **f32), torch.zeros(B, **f32)
+    keep['partials'] = torch.zeros(16 * nv.load().jamie_max_partials(), **f32)
+    d.sigma, d.hyper, d.rsum, d.qsum, d.partials = (nv.ptr(keep['sigma']), nv.ptr(keep['hyper']), nv.ptr(keep['rsum']),
+                                                    nv.ptr(keep['qsum']), nv.ptr(keep['partials']))
+    d.rng_stream = 100
+    state = torch.tensor([99, 5, 0, 0], dtype=torch.int64, device='cuda')
+    nv.latent_fwd(d, state)
+    e0, e1 = keep['eps0'].cpu(), keep['eps1'].cpu()
+    assert abs(e0.mean().item()) < 0.02 and abs(e0.std().item() - 1) < 0.02
+    assert abs((e0 * e1).mean().item()) < 0.02                       # the two modalities use different streams
+    assert abs((e0 ** 4).mean().item() - 3) < 0.2                     # kurtosis of a normal
+    close(keep['z0'], e0 * (1 + 1e-7), 1e-6, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,gscale_world', [(1000, 1), (4099, 1), (1 << 20, 4)])
+def test_clip_adam_matches_oracle(nv, n, gscale_world):
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    params = [p0.clone()]
+    opt = orc.Adam(params, 1e-3)
+    pd, md, vd = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    state = torch.tensor([0, 0, 0, 0], dtype=torch.int64, device='cuda')
+    hyper = torch.zeros(16)
+    hyper[8:14] = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1.0, 1.0 / gscale_world])
+    hd = dev(hyper)
+    nb = nv.optim_blocks(n)
+    part = torch.zeros(nb, device='cuda')
+    for t in range(5):
+        gr = torch.randn(n, generator=g) * (0.01 if t % 2 else 3.0)      # alternate clipped / unclipped
+        gsum = gr * gscale_world                                           # what an all-reduce SUM would hold
+        gd = dev(gsum)
+        nv.grad_sqnorm(gd, part, state)
+        nv.clip_adam(pd, gd, md, vd, part, hd, state)
+        grads = [gr.clone()]
+        orc.clip_grad_norm(grads)
+        opt.step(grads)
+        close(pd, params[0], rtol=1e-5, atol=2e-6, msg=f'step {t}')
+    assert int(state[1].item()) == 5
+
+
+# ------------------------------------------------------------------------------------------------
+# batch assembly
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [24, 70, 2000])
+def test_gather_rows(nv, d):
+    g = torch.Generator().manual_seed(d)
+    src = torch.randn(1000, d, generator=g)
+    idx = torch.randint(0, 1000, (300,), generator=g, dtype=torch.int32)
+    dst = torch.zeros(300, d, device='cuda')
+    nv.gather_rows(dev(src), dev(idx), dst)
+    assert torch.equal(dst.cpu(), src[idx.long()])
+
+
+def test_corr_from_indices(nv):
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 40, (64,), generator=g, dtype=torch.int32)
+    corr = torch.zeros(64, 64, device='cuda')
+    nv.corr_from_indices(dev(idx), dev(idx), corr)
+    close(corr, orc.p_block(None, idx.numpy(), idx.numpy()), 1e-7, 0)
+
+
+def test_colsum(nv):
+    X = torch.randn(3, 130, 50)
+    out = torch.zeros(50, device='cuda')
+    nv.colsum(dev(X), 130, 50, 50, out, nslab=3, slab_stride=130 * 50)
+    close(out, X.double().sum((0, 1)), 1e-5, 1e-5)
+    nv.colsum(dev(X), 130, 50, 50, out, nslab=3, slab_stride=130 * 50, accumulate=True)
+    close(out, 2 * X.double().sum((0, 1)), 1e-5, 1e-5)
+
+
+def test_sampler_without_replacement(nv):
+    state = torch.tensor([7, 0, 0, 0], dtype=torch.int64, device='cuda')
+    N, B = 100000, 512
+    idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+    seen = []
+    for step in range(20):
+        state[1] = step
+        nv.sample_indices(idx, N, 0, False, state, 200)
+        v = idx.cpu().numpy()
+        assert len(set(v.tolist())) == B and v.min() >= 0 and v.max() < N
+        seen.append(v.copy())
+    again = torch.zeros(B, dtype=torch.int32, device='cuda')
+    nv.sample_indices(again, N, 0, False, state, 200)
+    assert np.array_equal(again.cpu().numpy(), seen[-1])            # deterministic in (seed, step)
+    allv = np.concatenate(seen)
+    assert abs(allv.mean() / N - 0.5) < 0.02                          # uniform over [0, N)
+    # small N forces collisions: still a permutation-like subset
+    idx2 = torch.zeros(48, dtype=torch.int32, device='cuda')
+    nv.sample_indices(idx2, 50, 10, False, state, 200)
+    v = idx2.cpu().numpy()
+    assert len(set(v.tolist())) == 48 and v.min() >= 10 and v.max() < 60
+    # with replacement: duplicates allowed, range respected
+    idx3 = torch.zeros(512, dtype=torch.int32, device='cuda')
+    nv.sample_indices(idx3, 100, 0, True, state, 200)
+    v = idx3.cpu().numpy()
+    assert v.min() >= 0 and v.max() < 100 and len(set(v.tolist())) < 512

@@ -1,0 +1,186 @@
+"""CPU-side tests: C-ABI library exports, host logic (layout, schedules, preprocessing, sharding), the
+world_size-2 gradient exchange over gloo, and the no-fallback guarantees.  No GPU needed."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import jamie_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import jamie_amd
+    jamie_amd.build_library()
+    from jamie_amd import _native
+    return _native
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'jamie_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(jamie_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 15
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    handle = lib.load()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.jamie_version() >= 100
+    assert handle.jamie_max_partials() >= 1024
+
+
+def test_ctypes_struct_sizes_match_header(lib, tmp_path):
+    """sizeof() of every C struct equals the ctypes mirror (compiled with gcc from the public header)."""
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include "jamie_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+                   'sizeof(jamie_gemm_problem),sizeof(jamie_bnact_fwd_problem),sizeof(jamie_bnact_bwd_problem),'
+                   'sizeof(jamie_latent));return 0;}\n')
+    exe = tmp_path / 'sz'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    import ctypes
+    assert sizes == [ctypes.sizeof(lib.GemmProblem), ctypes.sizeof(lib.BnFwdProblem),
+                     ctypes.sizeof(lib.BnBwdProblem), ctypes.sizeof(lib.Latent)]
+
+
+def test_no_gpu_fails_loudly(lib):
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from jamie_amd.model import edModelVar
+    with pytest.raises(lib.JamieHipError):
+        edModelVar([8, 6], 2)
+    import jamie_amd
+    with pytest.raises(lib.JamieHipError):
+        jamie_amd.JAMIE(device='cpu')
+    with pytest.raises(lib.JamieHipError):
+        lib.ptr(torch.zeros(3))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'jamie_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
+
+
+@pytest.mark.parametrize('dims,L', [((200, 100), 16), ((2000, 1000), 32), ((24, 20), 4), ((70, 66), 8)])
+def test_param_layout(dims, L):
+    from jamie_amd.model import ParamLayout
+    lay = ParamLayout(dims, L)
+    assert lay.num_parameters() == orc.param_count(dims, L)
+    for name, (off, shape) in lay.entries.items():
+        assert off % 4 == 0, name                      # 16-byte aligned views
+    offs = sorted((o, int(np.prod(s))) for o, s in lay.entries.values())
+    for (o0, n0), (o1, _) in zip(offs, offs[1:]):
+        assert o0 + n0 <= o1                            # no overlap
+    assert offs[-1][0] + offs[-1][1] <= lay.total
+    torch.manual_seed(0)
+    P, Bf = orc.init_state(dims, L)
+    names = lay.reference_names()
+    assert set(names) == set(P)
+    flat = torch.zeros(lay.total)
+    views = lay.views(flat)
+    for ref, (mine, sl) in names.items():
+        v = views[mine] if sl is None else views[mine][sl]
+        assert tuple(v.shape) == tuple(P[ref].shape), ref
+    assert set(lay.reference_bn_names()) == {k for k in Bf if 'num_batches' not in k}
+
+
+def test_reference_parameter_count_formula():
+    assert orc.param_count((200, 100), 16) == 420166
+    assert orc.param_count((2000, 1000), 32) == 40345130
+    assert orc.param_count((5000, 2000), 64) == 233477258
+
+
+def test_kl_anneal_and_splitk():
+    from jamie_amd.engine import choose_splitk, kl_anneal
+    for e, me, ed in [(0, 2500, 10000), (1250, 2500, 10000), (7, 0, 30), (3, 4, 5)]:
+        assert kl_anneal(e, me, ed) == pytest.approx(float(orc.kl_anneal(e, me, ed)), rel=1e-15)
+    assert choose_splitk(512, 4000, 2000) == 1
+    assert choose_splitk(512, 64, 2000) > 1
+    assert choose_splitk(512, 64, 100) == 1
+    for M, N, K in [(512, 2000, 4000), (512, 32, 1000), (64, 70, 50)]:
+        s = choose_splitk(M, N, K)
+        assert s >= 1 and (s == 1 or K // s >= 128)
+
+
+def test_preclass_matches_oracle():
+    from jamie_amd.utilities import preclass
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((50, 7))
+    X[:, 3] = 2.0                                        # zero-variance feature -> NaN -> 0
+    a, b = preclass(X, axis=0), orc.Preclass(X, axis=0)
+    Y = rng.standard_normal((9, 7))
+    np.testing.assert_array_equal(a.transform(Y.copy()), b.transform(Y.copy()))
+    assert np.all(a.transform(X.copy())[:, 3] == 0)
+    np.testing.assert_array_equal(a.inverse_transform(Y), b.inverse_transform(Y))
+    g = preclass(X, axis=None)
+    assert g.mean.shape == () and np.isclose(g.transform(X.copy()).std(), 1)
+
+
+def test_shard_bounds_partition():
+    from jamie_amd.distributed import shard_bounds
+    for n, w in [(100000, 8), (10, 3), (7, 8), (1000001, 8)]:
+        b = [shard_bounds(n, r, w) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_time_logger_labels():
+    from jamie_amd.utilities import time_logger
+    t = time_logger()
+    t.log('Setup'); t.log('Step'); t.log('Step')
+    assert list(t.history) == ['Setup', 'Step'] and len(t.history['Step']) == 2
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from jamie_amd import distributed as jd
+rank, world, _ = jd.init_from_env('gloo')
+assert world == 2
+torch.manual_seed(rank)
+flat = torch.randn(1003)
+mine = flat.clone()
+jd.broadcast_flat(flat)                       # parameters start from rank 0
+ref0 = torch.manual_seed(0) and torch.randn(1003)
+assert torch.equal(flat, ref0)
+for nb in (1, 3):
+    g = torch.full((1003,), float(rank + 1)) + torch.arange(1003) * 0.001
+    jd.GradAllReduce(n_buckets=nb)(g)
+    want = 3.0 + 2 * torch.arange(1003) * 0.001
+    assert torch.allclose(g, want), nb
+# averaging happens inside the optimiser through grad_scale = 1/world: emulate the oracle update
+from oracle import jamie_oracle as orc
+p = [torch.ones(8)]
+opt = orc.Adam(p, 1e-2)
+gs = [(g[:8] / world).clone()]
+orc.clip_grad_norm(gs); opt.step(gs)
+out = [torch.zeros(8) for _ in range(world)]
+dist.all_gather(out, p[0])
+assert torch.equal(out[0], out[1])            # identical updates on every rank
+lo, hi = jd.shard_bounds(11, rank, world)
+assert (lo, hi) == ((0, 6) if rank == 0 else (6, 11))
+dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def test_gradient_exchange_world2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533', str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count('OK') == 2
