@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: training cells/sec of JAMIE's two-modality coupled VAE on MI355X
+(BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c5dims] [--no-cpu-baseline]
+
+N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+One rank per GPU; cells are sharded by rows; every rank trains on B = 512 cells per step (weak scaling)
+and the flat gradient is all-reduced once per step over RCCL.  A "step" is one pass of the hot path over
+one batch: device sampler -> row gather -> forward -> losses -> backward -> (all-reduce) -> clip + Adam.
+Inputs are synthetic (SURVEY.md §8(d) generator) and resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (cells, dims, latent)
+    'c1': (5000, (200, 100), 16),
+    'c2': (100000, (2000, 1000), 32),
+    'c5dims': (100000, (5000, 2000), 64),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_shard(n_rows, dims, seed, device):
+    """X_i = Z A_i + 0.1 E_i with a 16-dim latent, fp32, standardised per feature
+    (what `preclass(axis=0)` does on the host in the reference, jamie.py:462-465)."""
+    g = torch.Generator(device=device).manual_seed(1234)             # A_i shared by all ranks
+    A = [torch.randn(16, d, generator=g, device=device) for d in dims]
+    g2 = torch.Generator(device=device).manual_seed(seed)
+    Z = torch.randn(n_rows, 16, generator=g2, device=device)
+    out = []
+    for a in A:
+        x = Z @ a + 0.1 * torch.randn(n_rows, a.shape[1], generator=g2, device=device)
+        x = (x - x.mean(0)) / x.std(0, unbiased=False)
+        out.append(x.contiguous())
+    return out
+
+
+def flops_per_cell(dims, L):
+    """F_cell = 6 P_mm - 4 sum d_i^2, P_mm = sum(8 d^2 + 3 d L)."""
+    pmm = sum(8 * d * d + 3 * d * L for d in dims)
+    return 6 * pmm - 4 * sum(d * d for d in dims)
+
+
+def cpu_baseline(dims, L, B, budget_s=20.0):
+    """The CPU oracle (plain-PyTorch restatement of the reference step, pinned to the reference by the
+    golden fixtures) timed on this box's host cores: same dims, fp32, B = 512, default dropout."""
+    from oracle import jamie_oracle as orc
+    threads = torch.get_num_threads()
+    torch.manual_seed(666)
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    opt = orc.Adam(P.values(), 1e-3)
+    p = orc.default_dropout(dims)
+    rng = np.random.default_rng(0)
+    n = 8192
+    Z = rng.standard_normal((n, 16)).astype(np.float32)
+    data = [torch.from_numpy(Z @ rng.standard_normal((16, d)).astype(np.float32)
+                             + 0.1 * rng.standard_normal((n, d)).astype(np.float32)) for d in dims]
+    data = [(x - x.mean(0)) / x.std(0) for x in data]
+    eye, zero = torch.eye(B), torch.zeros(B, B)
+
+    def one():
+        idx = np.random.choice(range(n), B, replace=False)
+        X = [d[idx] for d in data]
+        noise = orc.draw_noise(dims, L, B, p)
+        orc.train_step(P, Bf, opt, X, eye, zero, noise, p, 0.5)
+    one()                                     # warm-up (first step dropped)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 40 and (time.perf_counter() - t0 < budget_s or steps < 3):
+        one()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {'value': B * steps / dt, 'unit': 'cells/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{steps} steps of B={B} at dims={tuple(dims)}, L={L}, N capped at {n}, fp32, '
+                      f'{dt:.1f} s on {threads} torch threads ({os.cpu_count()} logical CPUs)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    args = ap.parse_args()
+
+    from jamie_amd import distributed as jd
+    rank, world, local = jd.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    from jamie_amd import _native as nv
+    nv.require_gpu()
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+
+    n_cells, dims, L = CONFIGS[args.config]
+    B = args.batch
+    lo, hi = jd.shard_bounds(n_cells, rank, world)
+    data = synth_shard(hi - lo, dims, 1000 + rank, dev)
+    torch.manual_seed(666)
+    model = edModelVar(dims, L, device=dev)
+    if world > 1:
+        jd.broadcast_flat(model.flat)
+    eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world)
+    allreduce = jd.GradAllReduce() if world > 1 else None
+    idx = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    rep = min(dims) < B
+    corr = None
+    eng.set_kl_anneal(0.5)
+
+    def step():
+        nv.sample_indices(idx[0], hi - lo, 0, rep, eng.state, 200)
+        idx[1].copy_(idx[0])                                  # 'diag' sampling: same rows in both modalities
+        eng.load_batch(data, idx)
+        c = corr
+        if rep:
+            nv.corr_from_indices(idx[0], idx[1], eng.corr)
+            c = eng.corr
+        eng.step(c, None, None, allreduce)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.enable_kernel_timing('enc_gemm')
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ls, total, _ = eng.read_losses()
+    if not np.isfinite(total):
+        raise SystemExit('non-finite loss in benchmark')
+    cells_s = world * B * args.steps / dt
+
+    if rank == 0:
+        # roofline of the dominant kernel: the d <-> 2d Linear GEMM launch (both modalities grouped),
+        # 4 forward launches per step, each 4*B*sum(d^2) FLOP
+        gemm_ms = eng.kernel_timing_ms('enc_gemm')
+        gemm_flop = 4.0 * B * sum(d * d for d in dims)
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.config, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'training cells/sec (two-modality coupled VAE)', 'value': cells_s, 'unit': 'cells/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.config}: 2-modality synthetic {n_cells} cells x {tuple(dims)} features, '
+                                   f'latent={L}, B={B}/GPU, dropout={model.dropout}, fp32 MFMA, '
+                                   f'identity P (diag sampling), F=0',
+                       'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
+                       'parallelism': f'dp{world}', 'parameters': model.num_parameters(),
+                       'flop_per_cell': flops_per_cell(dims, L)},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<64,128,32,2,2,KC,KC> (Linear d<->2d forward, '
+                                                    'both modalities in one launch)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
+                         'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop, 'traffic': traffic,
+                         'whole_step_frac': cells_s / world * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
+            'final_loss': total,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(dims, L, B, args.cpu_budget)
+            out['gpu_over_cpu'] = cells_s / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

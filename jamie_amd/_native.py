@@ -149,6 +149,7 @@ def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_s
     p.M, p.N, p.K, p.lda, p.ldb, p.ldc, p.aux_ld = M, N, K, lda, ldb, ldc, aux_ld
     p.splitk, p.slab_stride, p.epi, p.accumulate = splitk, slab_stride, epi, int(accumulate)
     p.scale, p.slope, p.eps, p.pscale = scale, slope, eps, pscale
+    p._keep = (A, B, Cout, bias, aux, partial, a_rows)      # keep the tensors alive with the descriptor
     return p
 
 

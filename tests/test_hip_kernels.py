@@ -296,9 +296,9 @@ def _latent_case(nv, B, L, general, useF, cosine, nslab, seed):
     hyper[0], hyper[1], hyper[2], hyper[3] = kl_scale, w_rec, w_al, w_f
     keep['hyper'] = dev(hyper)
     for i in range(2):
-        keep[f'ml{i}'], keep[f'hb{i}'], keep[f'eps{i}'], keep[f'dc{i}'] = dev(ml[i]), dev(hb[i]), dev(eps[i]), dev(dcomb[i])
+        keep[f'ml{i}'], keep[f'hb{i}'], keep[f'epsin{i}'], keep[f'dc{i}'] = dev(ml[i]), dev(hb[i]), dev(eps[i]), dev(dcomb[i])
         d.ml[i], d.head_bias[i], d.eps_in[i], d.dcomb[i] = (nv.ptr(keep[f'ml{i}']), nv.ptr(keep[f'hb{i}']),
-                                                            nv.ptr(keep[f'eps{i}']), nv.ptr(keep[f'dc{i}']))
+                                                            nv.ptr(keep[f'epsin{i}']), nv.ptr(keep[f'dc{i}']))
         for k in ('mu', 'lv', 'z', 'eps', 'comb', 'cz', 'H', 'ch'):
             keep[f'{k}{i}'] = torch.zeros(B, L, **f32)
             getattr(d, k)[i] = nv.ptr(keep[f'{k}{i}'])
