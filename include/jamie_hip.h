@@ -72,6 +72,11 @@ typedef struct {
 
 /* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */
 int jamie_gemm_f32(const jamie_gemm_problem* problems /*host*/, int count, int layout, void* stream);
+/* Same with an explicit tile configuration (tuning / benchmarks); cfg < 0 = choose by shape. */
+int jamie_gemm_f32_cfg(const jamie_gemm_problem* problems /*host*/, int count, int layout, int cfg, void* stream);
+/* Block tile (BM x BN) the launcher uses for a group with these maximum extents: one EPI_MSE partial is
+ * written per tile, tile id = m_tile + tiles_m * n_tile. */
+int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm /*host*/, int* bn /*host*/);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d(train) + LeakyReLU + Dropout, forward and backward, one column strip per workgroup.

@@ -68,6 +68,8 @@ EXPORTS = {
     'jamie_version': (C.c_int, []),
     'jamie_max_partials': (C.c_int, []),
     'jamie_gemm_f32': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
+    'jamie_gemm_f32_cfg': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_gemm_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'jamie_bn_act_fwd': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_void_p]),
     'jamie_bn_act_bwd': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -153,9 +155,15 @@ def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_s
     return p
 
 
-def gemm(problems, layout):
+def gemm(problems, layout, cfg=-1):
     arr = (GemmProblem * len(problems))(*problems)
-    _check(load().jamie_gemm_f32(arr, len(problems), layout, _stream()))
+    _check(load().jamie_gemm_f32_cfg(arr, len(problems), layout, cfg, _stream()))
+
+
+def gemm_tile(layout, max_m, max_n, max_k, cfg=-1):
+    bm, bn = C.c_int(), C.c_int()
+    _check(load().jamie_gemm_tile(layout, max_m, max_n, max_k, cfg, C.byref(bm), C.byref(bn)))
+    return bm.value, bn.value
 
 
 def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01):

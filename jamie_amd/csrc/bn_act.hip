@@ -6,15 +6,19 @@
 // One workgroup owns a strip of CW = 16 feature columns for ALL batch rows, so the batch statistics
 // (exact two-pass mean / biased variance, like ATen's CPU kernel) are local to the workgroup:
 // 256 threads = 16 columns x 16 row phases; with B <= 512 every thread keeps its <= 32 values in
-// registers and h is read from HBM/L2 exactly once.  Larger batches fall back to re-reading.
+// registers and h is read from HBM/L2 exactly once.  Larger batches re-read h.
+// All loads are raw buffer loads: a row/column beyond the matrix is an out-of-range offset that returns 0,
+// so the 32 loads of a thread are issued back to back with no branches and one wait.
 // The pre-BN activations may arrive as split-K slabs; they are summed on the fly and the sum is written
-// back to slab 0 for the backward pass.  Dropout masks come from Philox (seed, step, stream, element)
-// and are regenerated identically in the backward kernel; tests pass explicit masks.
+// back to slab 0 for the backward pass.  Dropout masks come from Philox4x32-10 keyed by (seed, step,
+// stream) with one call per 4 elements, and are regenerated identically in the backward kernel; tests
+// pass explicit masks.
 #include "common.h"
 
 #define BN_CW 16
 #define BN_RP 16
 #define BN_MAXR 32
+#define BN_OOB 0xFFFFFFF0u
 
 struct BnFwdDev {
     float* h; const float* gamma; const float* beta; float* rmean; float* rvar;
@@ -43,6 +47,19 @@ __device__ __forceinline__ float col_reduce(float v, float (*sh)[BN_CW + 1], int
     return t;
 }
 
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ unsigned buf_u8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
+}
+
+// Keep decision of element (row, col): Philox counter = (col, row % 16, row / 64), lane = (row / 16) % 4, i.e.
+// the four keep bits of one call belong to rows r, r+16, r+32, r+48 of one column (a thread's own rows).
+__device__ __forceinline__ Philox4 drop_rand(const uint64_t* rng, int stream, int col, int rp, int g) {
+    return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)col << 24) | ((uint64_t)rp << 16) | (uint64_t)g);
+}
+
 template <bool CACHED>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                          float slope, const uint64_t* rng) {
@@ -56,42 +73,49 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
     const int col = ((int)blockIdx.x - P.blk_begin) * BN_CW + c;
     const bool cok = col < P.N;
     const int B = P.B, N = P.N;
-
-    auto load_h = [&](int row) -> float {
-        float v = 0.f;
-        const long long o = (long long)row * N + col;
-        for (int s = 0; s < P.nslab; ++s) v += P.h[o + s * P.slab_stride];
-        return v;
-    };
+    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.h, 0, (int)((unsigned)(P.nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
+    const unsigned col_off = cok ? (unsigned)col * 4u : BN_OOB;
+    const int nslab = P.nslab;
 
     float v[CACHED ? BN_MAXR : 1];
     float sum = 0.f;
     if (CACHED) {
 #pragma unroll
-        for (int j = 0; j < BN_MAXR; ++j) {
-            const int row = rp + j * BN_RP;
-            v[j] = (cok && row < B) ? load_h(row) : 0.f;
-            sum += v[j];
+        for (int j = 0; j < BN_MAXR; ++j) v[j] = 0.f;
+        for (int s = 0; s < nslab; ++s) {
+#pragma unroll
+            for (int j = 0; j < BN_MAXR; ++j) {
+                const int row = rp + j * BN_RP;
+                const unsigned off = (row < B && cok) ? (unsigned)s * slab_bytes + (unsigned)row * row_bytes + col_off : BN_OOB;
+                v[j] += buf_f32(h_rs, off);
+            }
         }
+#pragma unroll
+        for (int j = 0; j < BN_MAXR; ++j) sum += v[j];
     } else {
-        if (cok)
-            for (int row = rp; row < B; row += BN_RP) sum += load_h(row);
+        for (int row = rp; row < B; row += BN_RP)
+            for (int s = 0; s < nslab; ++s)
+                sum += buf_f32(h_rs, cok ? (unsigned)s * slab_bytes + (unsigned)row * row_bytes + col_off : BN_OOB);
     }
     const float mean = col_reduce(sum, sh, rp, c) / (float)B;
     float sq = 0.f;
     if (CACHED) {
 #pragma unroll
         for (int j = 0; j < BN_MAXR; ++j) {
-            const int row = rp + j * BN_RP;
             const float d = v[j] - mean;
-            if (row < B) sq += d * d;
+            if (rp + j * BN_RP < B) sq += d * d;
         }
     } else {
-        if (cok)
-            for (int row = rp; row < B; row += BN_RP) {
-                const float d = load_h(row) - mean;
-                sq += d * d;
-            }
+        for (int row = rp; row < B; row += BN_RP) {
+            float hv = 0.f;
+            for (int s = 0; s < nslab; ++s)
+                hv += buf_f32(h_rs, cok ? (unsigned)s * slab_bytes + (unsigned)row * row_bytes + col_off : BN_OOB);
+            sq += (hv - mean) * (hv - mean);
+        }
     }
     const float var = col_reduce(sq, sh, rp, c) / (float)B;   // biased
     const float invstd = rsqrtf(var + eps);
@@ -107,25 +131,51 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thr = jamie_drop_threshold(p_drop);
-    auto finish = [&](int row, float hv) {
-        const long long o = (long long)row * N + col;
-        if (P.nslab > 1) P.h[o] = hv;
-        float y = (hv - mean) * invstd * ga + be;
-        y = y > 0.f ? y : slope * y;
-        if (drop) {
-            const bool keep = P.mask ? (P.mask[o] != 0) : jamie_keep(rng, (uint32_t)P.rng_stream, (uint64_t)o, thr);
-            y = keep ? y * keep_scale : 0.f;
-        }
-        P.out[o] = y;
-    };
     if (CACHED) {
+        unsigned mk[BN_MAXR];
+        if (drop && P.mask) {
+#pragma unroll
+            for (int j = 0; j < BN_MAXR; ++j) {
+                const int row = rp + j * BN_RP;
+                mk[j] = buf_u8(m_rs, row < B ? (unsigned)row * (unsigned)N + (unsigned)col : BN_OOB);
+            }
+        }
+        Philox4 r;
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
 #pragma unroll
         for (int j = 0; j < BN_MAXR; ++j) {
             const int row = rp + j * BN_RP;
-            if (row < B) finish(row, v[j]);
+            if (drop && !P.mask && (j & 3) == 0) r = drop_rand(rng, P.rng_stream, col, rp, j >> 2);
+            if (row < B) {
+                const long long o = (long long)row * N + col;
+                if (nslab > 1) P.h[o] = v[j];
+                float y = (v[j] - mean) * invstd * ga + be;
+                y = y > 0.f ? y : slope * y;
+                if (drop) {
+                    const bool keep = P.mask ? (mk[j] != 0) : (r.v[j & 3] >= thr);
+                    y = keep ? y * keep_scale : 0.f;
+                }
+                P.out[o] = y;
+            }
         }
     } else {
-        for (int row = rp; row < B; row += BN_RP) finish(row, load_h(row));
+        for (int row = rp; row < B; row += BN_RP) {
+            float hv = 0.f;
+            for (int s = 0; s < nslab; ++s)
+                hv += buf_f32(h_rs, (unsigned)s * slab_bytes + (unsigned)row * row_bytes + col_off);
+            const long long o = (long long)row * N + col;
+            if (nslab > 1) P.h[o] = hv;
+            float y = (hv - mean) * invstd * ga + be;
+            y = y > 0.f ? y : slope * y;
+            if (drop) {
+                const int j = row / BN_RP;
+                bool keep;
+                if (P.mask) keep = P.mask[o] != 0;
+                else keep = drop_rand(rng, P.rng_stream, col, rp, j >> 2).v[j & 3] >= thr;
+                y = keep ? y * keep_scale : 0.f;
+            }
+            P.out[o] = y;
+        }
     }
 }
 
@@ -147,37 +197,78 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thr = jamie_drop_threshold(p_drop);
+    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.da, 0, (int)((unsigned)(P.nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)((unsigned)B * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
+    const unsigned col_off = cok ? (unsigned)col * 4u : BN_OOB;
+    const int nslab = P.nslab;
 
-    // dy (grad wrt BN output) and xn (normalised input) of one element
-    auto elem = [&](int row, float& dy, float& xn) {
+    // dy (grad wrt BN output) from the activation gradient d, the normalised input xn and the keep decision
+    auto to_dy = [&](float d, float xn, bool keep) -> float {
+        const float y = xn * ga + be;
+        if (drop) d = keep ? d * keep_scale : 0.f;
+        return y > 0.f ? d : d * slope;
+    };
+    // non-cached element: everything re-read
+    auto elem_slow = [&](int row, float& dy, float& xn) {
         const long long o = (long long)row * N + col;
         float d = 0.f;
-        for (int s = 0; s < P.nslab; ++s) d += P.da[o + s * P.slab_stride];
+        for (int s = 0; s < nslab; ++s) d += P.da[o + s * P.slab_stride];
         xn = (P.h[o] - mean) * invstd;
-        const float y = xn * ga + be;
+        bool keep = true;
         if (drop) {
-            const bool keep = P.mask ? (P.mask[o] != 0) : jamie_keep(rng, (uint32_t)P.rng_stream, (uint64_t)o, thr);
-            d = keep ? d * keep_scale : 0.f;
+            const int j = row / BN_RP;
+            keep = P.mask ? (P.mask[o] != 0) : (drop_rand(rng, P.rng_stream, col, rp, j >> 2).v[j & 3] >= thr);
         }
-        dy = y > 0.f ? d : d * slope;
+        dy = to_dy(d, xn, keep);
     };
 
     float dyv[CACHED ? BN_MAXR : 1], xnv[CACHED ? BN_MAXR : 1];
     float s1 = 0.f, s2 = 0.f;
     if (CACHED) {
 #pragma unroll
+        for (int j = 0; j < BN_MAXR; ++j) dyv[j] = 0.f;
+        for (int s = 0; s < nslab; ++s) {
+#pragma unroll
+            for (int j = 0; j < BN_MAXR; ++j) {
+                const int row = rp + j * BN_RP;
+                dyv[j] += buf_f32(d_rs, (row < B && cok) ? (unsigned)s * slab_bytes + (unsigned)row * row_bytes + col_off : BN_OOB);
+            }
+        }
+#pragma unroll
         for (int j = 0; j < BN_MAXR; ++j) {
             const int row = rp + j * BN_RP;
-            dyv[j] = 0.f; xnv[j] = 0.f;
-            if (cok && row < B) elem(row, dyv[j], xnv[j]);
+            xnv[j] = buf_f32(h_rs, (row < B && cok) ? (unsigned)row * row_bytes + col_off : BN_OOB);
+        }
+        unsigned mk[BN_MAXR];
+        if (drop && P.mask) {
+#pragma unroll
+            for (int j = 0; j < BN_MAXR; ++j) {
+                const int row = rp + j * BN_RP;
+                mk[j] = buf_u8(m_rs, (row < B && cok) ? (unsigned)row * (unsigned)N + (unsigned)col : BN_OOB);
+            }
+        }
+        Philox4 r;
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
+#pragma unroll
+        for (int j = 0; j < BN_MAXR; ++j) {
+            const int row = rp + j * BN_RP;
+            if (drop && !P.mask && (j & 3) == 0) r = drop_rand(rng, P.rng_stream, col, rp, j >> 2);
+            const bool keep = drop ? (P.mask ? (mk[j] != 0) : (r.v[j & 3] >= thr)) : true;
+            const bool ok = cok && row < B;
+            const float xn = ok ? (xnv[j] - mean) * invstd : 0.f;
+            xnv[j] = xn;
+            dyv[j] = ok ? to_dy(dyv[j], xn, keep) : 0.f;
             s1 += dyv[j];
-            s2 += dyv[j] * xnv[j];
+            s2 += dyv[j] * xn;
         }
     } else {
         if (cok)
             for (int row = rp; row < B; row += BN_RP) {
                 float dy, xn;
-                elem(row, dy, xn);
+                elem_slow(row, dy, xn);
                 s1 += dy;
                 s2 += dy * xn;
             }
@@ -201,7 +292,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
         if (cok)
             for (int row = rp; row < B; row += BN_RP) {
                 float dy, xn;
-                elem(row, dy, xn);
+                elem_slow(row, dy, xn);
                 const float dh = gi * (dy - k1 - xn * k2);
                 P.da[(long long)row * N + col] = dh;   // slab 0 <- dh (slab 0 is only read by this thread)
                 s3 += dh;
@@ -236,6 +327,8 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
                   "null pointer");
         JAMIE_ARG(s.B >= 1 && s.N >= 1 && s.nslab >= 1, "B, N, nslab >= 1");
         JAMIE_ARG(s.nslab == 1 || s.slab_stride >= (long long)s.B * s.N, "slab_stride too small");
+        JAMIE_ARG(((long long)(s.nslab - 1) * s.slab_stride + (long long)s.B * s.N) * 4 < 0xFFFFFFF0LL,
+                  "activation slabs must stay below 4 GiB");
         BnFwdDev& d = g.p[i];
         d.h = s.h; d.gamma = s.gamma; d.beta = s.beta; d.rmean = s.running_mean; d.rvar = s.running_var;
         d.smean = s.save_mean; d.sinvstd = s.save_invstd; d.out = s.out; d.mask = s.mask;
@@ -269,6 +362,8 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
                   "null pointer");
         JAMIE_ARG(s.B >= 1 && s.N >= 1 && s.nslab >= 1, "B, N, nslab >= 1");
         JAMIE_ARG(s.nslab == 1 || s.slab_stride >= (long long)s.B * s.N, "slab_stride too small");
+        JAMIE_ARG(((long long)(s.nslab - 1) * s.slab_stride + (long long)s.B * s.N) * 4 < 0xFFFFFFF0LL,
+                  "activation slabs must stay below 4 GiB");
         BnBwdDev& d = g.p[i];
         d.da = s.da; d.h = s.h; d.gamma = s.gamma; d.beta = s.beta; d.smean = s.save_mean;
         d.sinvstd = s.save_invstd; d.dgamma = s.dgamma; d.dbeta = s.dbeta; d.dbias = s.dbias_lin; d.mask = s.mask;

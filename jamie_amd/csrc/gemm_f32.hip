@@ -28,6 +28,7 @@ struct GemmDev {
     int M, N, K, lda, ldb, ldc, aux_ld;
     int splitk, kchunk, tiles_m, tiles_n, tile_begin;
     int epi, accumulate, a_vec, b_vec;
+    unsigned a_bytes, b_bytes;
     float scale, slope, eps, pscale;
 };
 
@@ -49,7 +50,30 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec
     return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Branch-free staging load: a raw buffer load returns 0 for an offset beyond the descriptor's num_records, so
+// invalid rows / k-slices are expressed as an out-of-range offset and the in-row tails as selects.  (The
+// guarded flat-load version serialises every load behind its own branch + s_waitcnt vmcnt(0).)
+#define JAMIE_OOB 0xFFFFFFF0u
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// applied when the tile is written to LDS (AFTER the MFMAs of the previous tile), so that the loads stay
+// in flight under the compute phase
+__device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
+    float4 f;
+    f.x = nvalid > 0 ? v.x : 0.f;
+    f.y = nvalid > 1 ? v.y : 0.f;
+    f.z = nvalid > 2 ? v.z : 0.f;
+    f.w = nvalid > 3 ? v.w : 0.f;
+    return f;
+}
+
+// FAST = true : operands addressed through buffer descriptors (needs 16-byte aligned bases, ld % 4 == 0,
+//               < 4 GiB per operand, no row gather); FAST = false: guarded flat loads (any shape/alignment).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool FAST>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -131,8 +155,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
         }
     }
 
+    // ---- FAST path: buffer descriptors (wave-uniform) and per-thread byte offsets ----
+    __amdgpu_buffer_rsrc_t a_rs, b_rs;
+    unsigned a_off[LA], b_off[LB];
+    if (FAST) {
+        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (int)P.a_bytes, 0x00020000);
+        b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (int)P.b_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < LA; ++j) a_off[j] = (unsigned)((a_ptr[j] - P.A) * 4);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) b_off[j] = (unsigned)((b_ptr[j] - P.B) * 4);
+    }
+
     float4 ra[LA], rb[LB];
     auto load_tile = [&](int k0) {
+        if (FAST) {
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int k = k0 + a_k[j];
+                if (A_KC)
+                    ra[j] = buf_ld4(a_rs, a_lim[j] ? a_off[j] + (unsigned)k0 * 4u : JAMIE_OOB);
+                else
+                    ra[j] = buf_ld4(a_rs, k < kend ? a_off[j] + (unsigned)k * (unsigned)P.lda * 4u : JAMIE_OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const int k = k0 + b_k[j];
+                if (B_KC)
+                    rb[j] = buf_ld4(b_rs, b_lim[j] ? b_off[j] + (unsigned)k0 * 4u : JAMIE_OOB);
+                else
+                    rb[j] = buf_ld4(b_rs, k < kend ? b_off[j] + (unsigned)k * (unsigned)P.ldb * 4u : JAMIE_OOB);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             if (A_KC) {
@@ -158,13 +213,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int k0) {
         float* As = smem + buf * (A_SZ + B_SZ);
         float* Bs = As + A_SZ;
 #pragma unroll
-        for (int j = 0; j < LA; ++j) *reinterpret_cast<float4*>(&As[a_lds[j]]) = ra[j];
+        for (int j = 0; j < LA; ++j) {
+            float4 v = ra[j];
+            if (FAST) v = mask4(v, A_KC ? kend - (k0 + a_k[j]) : a_lim[j]);   // in-row tails (k or m)
+            *reinterpret_cast<float4*>(&As[a_lds[j]]) = v;
+        }
 #pragma unroll
-        for (int j = 0; j < LB; ++j) *reinterpret_cast<float4*>(&Bs[b_lds[j]]) = rb[j];
+        for (int j = 0; j < LB; ++j) {
+            float4 v = rb[j];
+            if (FAST) v = mask4(v, B_KC ? kend - (k0 + b_k[j]) : b_lim[j]);
+            *reinterpret_cast<float4*>(&Bs[b_lds[j]]) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -177,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
 
     if (nk > 0) {
         load_tile(kbeg);
-        store_tile(0);
+        store_tile(0, kbeg);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -217,7 +280,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the masks / LDS writes (and their vmcnt wait) after the MFMAs
+        if (more) store_tile(cur ^ 1, kbeg + (kt + 1) * BK);
         __syncthreads();
     }
 
@@ -273,6 +337,7 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     memset(&g, 0, sizeof(g));
     g.count = count;
     int tiles = 0;
+    bool fast = true;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];
         GemmDev& d = g.p[i];
@@ -294,17 +359,53 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.b_vec = ((s.ldb % 4) == 0 && ((uintptr_t)s.B % 16) == 0) ? 1 : 0;
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
         tiles += d.tiles_m * d.tiles_n * d.splitk;
+        // operand extents in bytes, last row rounded up to a whole float4 (stays inside the ld-strided storage)
+        const long long a_rows_n = A_KC ? s.M : s.K, a_cols = A_KC ? s.K : s.M;
+        const long long b_rows_n = B_KC ? s.N : s.K, b_cols = B_KC ? s.K : s.N;
+        const long long ab = ((a_rows_n - 1) * s.lda + (a_cols + 3) / 4 * 4) * 4;
+        const long long bb = ((b_rows_n - 1) * s.ldb + (b_cols + 3) / 4 * 4) * 4;
+        if (!d.a_vec || !d.b_vec || s.a_rows || ab >= 0xFFFFFFF0LL || bb >= 0xFFFFFFF0LL) fast = false;
+        d.a_bytes = (unsigned)ab; d.b_bytes = (unsigned)bb;
     }
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC>), dim3(tiles), dim3(WM * WN * 64), 0,
-                       st, g);
+    if (fast)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, true>), dim3(tiles),
+                           dim3(WM * WN * 64), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, false>), dim3(tiles),
+                           dim3(WM * WN * 64), 0, st, g);
     return jamie_launch_status("jamie_gemm_f32");
 }
 
-extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layout, void* stream) {
+// Tile configurations (BM, BN, BK, WM, WN).  cfg < 0 selects by shape (see pick_cfg).
+//   0: 64x128x32, 4 waves of 32x64   1: 64x64x32, 4 waves of 32x32    2: 128x128x16, 4 waves of 64x64
+//   3: 128x64x32, 4 waves of 64x32   4: 128x128x32, 8 waves of 64x32  5: 32x128x32, 4 waves of 32x32
+template <bool A_KC, bool B_KC>
+static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_cfg<64, 128, 32, 2, 2, A_KC, B_KC>(pr, count, st);
+        case 1: return launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC>(pr, count, st);
+        case 2: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC>(pr, count, st);
+        case 3: return launch_cfg<128, 64, 32, 2, 2, A_KC, B_KC>(pr, count, st);
+        case 4: return launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC>(pr, count, st);
+        case 5: return launch_cfg<32, 128, 32, 1, 4, A_KC, B_KC>(pr, count, st);
+        default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
+    }
+}
+
+static int pick_cfg(int layout, int max_m, int max_n, int max_k) {
+    // small-N or small-K problems (heads, latent -> hidden) take the 64x64 tile: more workgroups, and the
+    // larger instances then only ever run the big d <-> 2d Linear layers (clean per-kernel profiles)
+    // measured on MI355X at the config-2 layer shapes (tools/bench_gemm.py, profiles/): the 64x64x32 tile
+    // (3-4 workgroups per CU, finest load balance between the two modalities) wins or ties every layout
+    (void)layout; (void)max_m; (void)max_n; (void)max_k;
+    return 1;
+}
+
+extern "C" int jamie_gemm_f32_cfg(const jamie_gemm_problem* pr, int count, int layout, int cfg, void* stream) {
     JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
     JAMIE_ARG(layout >= JAMIE_NT && layout <= JAMIE_TN, "layout");
-    int max_n = 0, max_m = 0;
+    int max_n = 0, max_m = 0, max_k = 0;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];
         JAMIE_ARG(s.A && s.B && s.C, "null operand");
@@ -322,17 +423,24 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
         JAMIE_ARG(s.splitk <= 1 || s.slab_stride >= (long long)s.M * s.ldc, "slab_stride too small");
         if (s.N > max_n) max_n = s.N;
         if (s.M > max_m) max_m = s.M;
+        if (s.K > max_k) max_k = s.K;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (layout == JAMIE_NT) {
-        if (max_n <= 64) return launch_cfg<64, 64, 32, 2, 2, true, true>(pr, count, st);
-        return launch_cfg<64, 128, 32, 2, 2, true, true>(pr, count, st);
-    }
-    if (layout == JAMIE_NN) {
-        if (max_n <= 64) return launch_cfg<64, 64, 32, 2, 2, true, false>(pr, count, st);
-        return launch_cfg<64, 128, 32, 2, 2, true, false>(pr, count, st);
-    }
-    // TN (weight gradients): K = batch is short, output is large
-    if (max_n <= 64 || max_m <= 64) return launch_cfg<64, 64, 32, 2, 2, false, false>(pr, count, st);
-    return launch_cfg<128, 128, 16, 2, 2, false, false>(pr, count, st);
+    if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
+    if (layout == JAMIE_NT) return launch_layout<true, true>(pr, count, cfg, st);
+    if (layout == JAMIE_NN) return launch_layout<true, false>(pr, count, cfg, st);
+    return launch_layout<false, false>(pr, count, cfg, st);
+}
+
+extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layout, void* stream) {
+    return jamie_gemm_f32_cfg(pr, count, layout, -1, stream);
+}
+
+// tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
+extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
+    static const int T[6][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}};
+    if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
+    if (cfg > 5 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    *bm = T[cfg][0]; *bn = T[cfg][1];
+    return 0;
 }

@@ -22,16 +22,15 @@ H_KL, H_REC, H_ALIGN, H_F = 0, 1, 2, 3
 H_LR, H_B1, H_B2, H_EPS, H_MAXNORM, H_GSCALE = 8, 9, 10, 11, 12, 13
 
 
-def choose_splitk(M, N, K, bm=64, bn=128):
-    """Split K so that a skinny problem still offers ~256 workgroups (one per CU); each slice keeps
-    at least 256 of K.  Slabs are summed by the consuming kernel."""
-    if N <= 64:
-        bn = 64
+def choose_splitk(M, N, K, bm=64, bn=64):
+    """Split K so that a problem offers >= ~2 workgroups of 64x64 per CU (512 in all); each slice keeps at
+    least 512 of K (256 for the skinny heads / latent products).  Slabs are summed by the consuming kernel.
+    Measured (tools/bench_gemm.py): [512x2000x4000] 65 -> 89 TFLOP/s with 2 slices."""
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
-    if tiles >= 192:
+    if tiles >= 384:
         return 1
-    s = max(1, round(256 / tiles))
-    return int(max(1, min(s, K // 256)))
+    s = max(1, math.ceil(512 / tiles))
+    return int(max(1, min(s, K // (512 if N > 64 else 256))))
 
 
 def kl_anneal(epoch, min_epochs, epoch_DNN):
@@ -111,13 +110,14 @@ class TrainEngine:
             w['idx'] = torch.zeros(B, dtype=torch.int32, device=self.dev)
             self.ws.append(w)
         # dec2 (MSE epilogue) uses the 64x128 tile config unless N <= 64
-        bn_tile = 64 if max(self.dims) <= 64 else 128      # the grouped launch picks one config by max N
-        self.rec_tiles = [math.ceil(B / 64) * math.ceil(d / bn_tile) for d in self.dims]
+        bm_t, bn_t = nv.gemm_tile(nv.NT, B, max(self.dims), 2 * max(self.dims))   # tile of the grouped launch
+        self.rec_tiles = [math.ceil(B / bm_t) * math.ceil(d / bn_t) for d in self.dims]
         self.rec_partials = torch.zeros(sum(self.rec_tiles), **f32)
         self.rsum = torch.empty(B, **f32); self.qsum = torch.empty(B, **f32)
         self.fc1 = torch.empty(B, L, **f32); self.fte = torch.empty(B, L, **f32)
         self.corr = torch.empty(B, B, **f32)
         self.accumulate = False
+        self._timing = None
 
     # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
     def set_kl_anneal(self, anneal):
@@ -126,6 +126,26 @@ class TrainEngine:
 
     def reset_best(self):
         self.losses[5] = float('inf')
+
+    # ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----
+    def enable_kernel_timing(self, label):
+        self._timing = {label: []}
+
+    def _launch(self, label, fn):
+        if self._timing is None or label not in self._timing:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self._timing[label].append((e0, e1))
+
+    def kernel_timing_ms(self, label):
+        if self._timing is None or not self._timing.get(label):
+            return None
+        torch.cuda.synchronize()
+        t = [a.elapsed_time(b) for a, b in self._timing[label]]
+        return float(np.mean(t))
 
     # ---- pieces ----
     def _mask(self, noise, kind, i, j):
@@ -174,7 +194,7 @@ class TrainEngine:
             probs.append(nv.gemm_problem(a, W, out, self.B, nout, nin, nin, nin, nout,
                                          bias=P[f'm{i}.{lin}.b'] if with_bias else None,
                                          splitk=w['sk'][sk_key], slab_stride=self.B * nout))
-        nv.gemm(probs, nv.NT)
+        self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') else lin, lambda: nv.gemm(probs, nv.NT))
 
     def _dx_gemm(self, dy_key, lin, out_key, sk_key):
         """dx[B, in_f] (slabs) = dy[B, out_f] W."""
@@ -250,7 +270,7 @@ class TrainEngine:
                                          aux_ld=d, partial=self.rec_partials[off:off + self.rec_tiles[i]],
                                          scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
             off += self.rec_tiles[i]
-        nv.gemm(probs, nv.NT)
+        self._launch('enc_gemm', lambda: nv.gemm(probs, nv.NT))
         # ---------------- backward ----------------
         acc = self.accumulate
         for i, d in enumerate(self.dims):

@@ -101,7 +101,8 @@ def test_gemm_mse_epilogue(nv):
     e2, W, b, X = (torch.randn(B, K, generator=g), torch.randn(d, K, generator=g), torch.randn(d, generator=g),
                    torch.randn(B, d, generator=g))
     import math
-    tiles = math.ceil(B / 64) * math.ceil(d / 128)
+    bm, bn = nv.gemm_tile(nv.NT, B, d, K)
+    tiles = math.ceil(B / bm) * math.ceil(d / bn)
     part = torch.zeros(tiles, device='cuda')
     out = torch.zeros(B, d, device='cuda')
     scale = 2.0 / (B * d)
