@@ -185,8 +185,8 @@ def main():
                        'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
                        'parallelism': f'dp{world}', 'parameters': model.num_parameters(),
                        'flop_per_cell': flops_per_cell(dims, L)},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<64,128,32,2,2,KC,KC> (Linear d<->2d forward, '
-                                                    'both modalities in one launch)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<64, 64, 32, 2, 2, true, true, true, 1> (Linear d<->2d '
+                                                    'forward GEMM, both modalities in one launch; 4 launches/step)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None,
                          'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop, 'traffic': traffic,

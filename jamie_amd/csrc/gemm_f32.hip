@@ -18,6 +18,11 @@
 //   * split-K writes fp32 slabs (deterministic; the consumer kernel sums them).
 #include "common.h"
 
+// diagnostic ablations (tools/ablate_gemm.sh): 1 = no global loads in the k-loop, 2 = no MFMAs, 3 = no LDS writes
+#ifndef JAMIE_GEMM_ABL
+#define JAMIE_GEMM_ABL 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmDev {
@@ -26,7 +31,7 @@ struct GemmDev {
     float* partial; const int32_t* a_rows;
     long long slab_stride;
     int M, N, K, lda, ldb, ldc, aux_ld;
-    int splitk, kchunk, tiles_m, tiles_n, tile_begin;
+    int splitk, kchunk, tiles_m, tiles_n, tile_begin, n_tiles;
     int epi, accumulate, a_vec, b_vec;
     unsigned a_bytes, b_bytes;
     float scale, slope, eps, pscale;
@@ -73,7 +78,10 @@ __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
 
 // FAST = true : operands addressed through buffer descriptors (needs 16-byte aligned bases, ld % 4 == 0,
 //               < 4 GiB per operand, no row gather); FAST = false: guarded flat loads (any shape/alignment).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool FAST>
+// TAG = 1 marks launches in which every problem is one of the big d <-> 2d Linear products: the same code under
+// a second kernel symbol, so that per-kernel profiles (rocprofv3 --stats) of the dominant GEMMs are not mixed with
+// the skinny heads / latent products.
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool FAST, int TAG>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -87,16 +95,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
     __shared__ float red[WM * WN];
 
-    // ---- block -> (problem, tile) with XCD-aware remap (bijective form, cdna_hip_programming.md §5) ----
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q = nb >> 3, r8 = nb & 7, xcd = bid & 7, slot = bid >> 3;
-    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
-    int pi = 0;
+    // ---- block -> (problem, tile), XCD-aware.  Hardware deals consecutive block ids round-robin over the 8
+    // XCDs (block b and b+8 share an L2).  Every problem's tile list (m fastest, so the M-tiles that re-read
+    // one weight panel are adjacent) is cut into 8 contiguous chunks, one per XCD, and an XCD walks its chunk
+    // of problem 0, then of problem 1, ...: each XCD gets the same number of tiles OF EACH PROBLEM (the
+    // modalities have different K, so mixing them unevenly left whole XCDs with only long or only short
+    // tiles), and a weight panel is fetched from HBM into one L2 only.  Remainders are dealt round-robin
+    // (rotation o_p) so the chunk sizes add up to exactly the number of blocks each XCD receives.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    int pi = 0, t = 0, rot = 0;
 #pragma unroll
-    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
-        if (i < g.count && vid >= g.p[i].tile_begin) pi = i;
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+        if (i < g.count) {
+            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
+            const int j = (xcd - rot) & 7;
+            const int cp = qp + (j < rp ? 1 : 0);
+            if (slot >= 0 && slot < cp) {
+                pi = i;
+                t = j * qp + min(j, rp) + slot;
+                slot = -1;
+            } else if (slot >= 0) {
+                slot -= cp;
+            }
+            rot = (rot + rp) & 7;
+        }
+    }
     const GemmDev& P = g.p[pi];
-    const int t = vid - P.tile_begin;
     const int tm_i = t % P.tiles_m;
     const int tn_i = (t / P.tiles_m) % P.tiles_n;
     const int ks = t / (P.tiles_m * P.tiles_n);
@@ -246,42 +272,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more) load_tile(kbeg + (kt + 1) * BK);
+        if (more && JAMIE_GEMM_ABL != 1) load_tile(kbeg + (kt + 1) * BK);
         const float* As = smem + cur * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
-            float af[TM][4], bf[TN][4];
+        // fragments are fetched one k-group (8 k) ahead of the MFMAs that consume them, so the LDS latency
+        // of group g+1 runs under the 4*TM*TN MFMAs of group g
+        float af[2][TM][4], bf[2][TN][4];
+        auto read_frags = [&](int buf, int kk) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (A_KC) {
                     const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + r) * A_LD + kk + 4 * h]);
-                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+                    af[buf][i][0] = v.x; af[buf][i][1] = v.y; af[buf][i][2] = v.z; af[buf][i][3] = v.w;
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) af[i][s] = As[(kk + 4 * h + s) * A_LD + wm0 + i * 32 + r];
+                    for (int s = 0; s < 4; ++s) af[buf][i][s] = As[(kk + 4 * h + s) * A_LD + wm0 + i * 32 + r];
                 }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (B_KC) {
                     const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + r) * B_LD + kk + 4 * h]);
-                    bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+                    bf[buf][j][0] = v.x; bf[buf][j][1] = v.y; bf[buf][j][2] = v.z; bf[buf][j][3] = v.w;
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(kk + 4 * h + s) * B_LD + wn0 + j * 32 + r];
+                    for (int s = 0; s < 4; ++s) bf[buf][j][s] = Bs[(kk + 4 * h + s) * B_LD + wn0 + j * 32 + r];
                 }
             }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            __builtin_amdgcn_sched_barrier(0);   // pin: reads of group g+1 are ISSUED before the MFMAs of group g
+            if (gk + 1 < BK / 8) read_frags((gk + 1) & 1, (gk + 1) * 8);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                    {
+#if JAMIE_GEMM_ABL == 2
+                        asm volatile("" ::"v"(af[gk & 1][i][s]), "v"(bf[gk & 1][j][s]));
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gk & 1][i][s], bf[gk & 1][j][s], acc[i][j], 0, 0, 0);
+#endif
+                    }
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the masks / LDS writes (and their vmcnt wait) after the MFMAs
-        if (more) store_tile(cur ^ 1, kbeg + (kt + 1) * BK);
+        if (more && JAMIE_GEMM_ABL != 3) store_tile(cur ^ 1, kbeg + (kt + 1) * BK);
         __syncthreads();
     }
 
@@ -337,7 +377,7 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     memset(&g, 0, sizeof(g));
     g.count = count;
     int tiles = 0;
-    bool fast = true;
+    bool fast = true, big = true;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];
         GemmDev& d = g.p[i];
@@ -358,7 +398,8 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.a_vec = ((s.lda % 4) == 0 && ((uintptr_t)s.A % 16) == 0) ? 1 : 0;
         d.b_vec = ((s.ldb % 4) == 0 && ((uintptr_t)s.B % 16) == 0) ? 1 : 0;
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
-        tiles += d.tiles_m * d.tiles_n * d.splitk;
+        d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        tiles += d.n_tiles;
         // operand extents in bytes, last row rounded up to a whole float4 (stays inside the ld-strided storage)
         const long long a_rows_n = A_KC ? s.M : s.K, a_cols = A_KC ? s.K : s.M;
         const long long b_rows_n = B_KC ? s.N : s.K, b_cols = B_KC ? s.K : s.N;
@@ -366,13 +407,17 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         const long long bb = ((b_rows_n - 1) * s.ldb + (b_cols + 3) / 4 * 4) * 4;
         if (!d.a_vec || !d.b_vec || s.a_rows || ab >= 0xFFFFFFF0LL || bb >= 0xFFFFFFF0LL) fast = false;
         d.a_bytes = (unsigned)ab; d.b_bytes = (unsigned)bb;
+        if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
     if (tiles == 0) return 0;
-    if (fast)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, true>), dim3(tiles),
+    if (fast && big)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, true, 1>), dim3(tiles),
+                           dim3(WM * WN * 64), 0, st, g);
+    else if (fast)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, true, 0>), dim3(tiles),
                            dim3(WM * WN * 64), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, false>), dim3(tiles),
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, false, 0>), dim3(tiles),
                            dim3(WM * WN * 64), 0, st, g);
     return jamie_launch_status("jamie_gemm_f32");
 }
@@ -389,6 +434,7 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
         case 3: return launch_cfg<128, 64, 32, 2, 2, A_KC, B_KC>(pr, count, st);
         case 4: return launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC>(pr, count, st);
         case 5: return launch_cfg<32, 128, 32, 1, 4, A_KC, B_KC>(pr, count, st);
+        case 6: return launch_cfg<64, 64, 64, 2, 2, A_KC, B_KC>(pr, count, st);
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
 }
@@ -438,9 +484,9 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[6][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}};
+    static const int T[7][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 5 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 6 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }
