@@ -123,7 +123,7 @@ def main():
     if world > 1:
         jd.broadcast_flat(model.flat)
     eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world)
-    allreduce = jd.GradAllReduce() if world > 1 else None
+    allreduce = jd.OverlappedGradAllReduce() if world > 1 else None
     idx = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
     rep = min(dims) < B
     corr = None

@@ -17,10 +17,15 @@ def init_from_env(backend=None):
         return 0, 1, 0
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
+    # test hooks: JAMIE_DIST_BACKEND=gloo and JAMIE_SHARE_GPU=1 let two ranks share cuda:0 on a 1-GPU box
+    # (the real multi-GPU path is RCCL = backend "nccl", one GPU per rank)
+    backend = os.environ.get('JAMIE_DIST_BACKEND', backend)
+    if os.environ.get('JAMIE_SHARE_GPU') == '1':
+        local = 0
     if not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend)
     return rank, world, local
@@ -56,6 +61,50 @@ class GradAllReduce:
                  for s in range(0, n, step)]
         for w in works:
             w.wait()
+
+
+class OverlappedGradAllReduce:
+    """The same single logical all-reduce, issued region by region while the backward pass is still running:
+    `region_done(flat[a:b])` is called right after the kernels that produce that contiguous region were
+    launched (RCCL orders the collective after them on the device and runs it on its own stream);
+    `finish()` waits for all of them before the gradient norm.  Adjacent regions are merged until a
+    bucket reaches `min_bytes`: xGMI is point-to-point, a few large messages beat many small ones."""
+
+    def __init__(self, group=None, min_bytes=32 << 20):
+        self.group = group
+        self.min_bytes = min_bytes
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.works = []
+        self.pending = None          # (flat, lo, hi) not yet issued
+
+    def region_done(self, flat, lo, hi):
+        if self.world == 1:
+            return
+        if self.pending is not None and self.pending[2] == lo:       # forward-adjacent
+            lo = self.pending[1]
+        elif self.pending is not None and self.pending[1] == hi:     # backward-adjacent (the usual case)
+            hi = self.pending[2]
+        elif self.pending is not None:
+            self._issue(*self.pending)
+        self.pending = (flat, lo, hi)
+        if (hi - lo) * flat.element_size() >= self.min_bytes:
+            self._issue(*self.pending)
+            self.pending = None
+
+    def _issue(self, flat, lo, hi):
+        self.works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        if self.pending is not None:
+            self._issue(*self.pending)
+            self.pending = None
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def __call__(self, flat):          # non-overlapped use
+        self.region_done(flat, 0, flat.numel())
+        self.finish()
 
 
 def broadcast_flat(flat, src=0, group=None):

@@ -245,7 +245,13 @@ class TrainEngine:
         for i in range(2):
             nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
 
-    def forward_backward(self, corr=None, Fblk=None, noise=None):
+    def _region(self, ar, name):
+        """Tell an overlapping all-reduce that the gradients of parameter region `name` have been launched."""
+        if ar is not None and hasattr(ar, 'region_done'):
+            lo, hi = self.m.layout.regions[name]
+            ar.region_done(self.grad, lo, hi)
+
+    def forward_backward(self, corr=None, Fblk=None, noise=None, allreduce=None):
         """Forward, losses and backward for the batch already in the workspace.  `corr` None = identity,
         `Fblk` None = 0; `noise` (explicit masks / eps, for parity tests) None = Philox streams."""
         B, L = self.B, self.L
@@ -276,23 +282,29 @@ class TrainEngine:
         for i, d in enumerate(self.dims):
             nv.colsum(self.ws[i]['dxhat'], B, d, d, self.g[f'm{i}.dec2.b'], accumulate=acc)
         self._dw_gemm('dxhat', 'e2', 'dec2')
+        self._region(allreduce, 'dec2')
         self._dx_gemm('dxhat', 'dec2', 'de2', 'd_e2')
         self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1)   # de2[0] <- dg2p
         self._dw_gemm('de2', 'e1', 'dec1')
+        self._region(allreduce, 'dec1')
         self._dx_gemm('de2', 'dec1', 'de1', 'd_e1')
         self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
         self._dw_gemm('de1', 'comb', 'dec0')
+        self._region(allreduce, 'dec0')
         self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
         nv.latent_bwd(lat)                                                      # dml, dsigma, losses
         for i, d in enumerate(self.dims):
             nv.colsum(self.ws[i]['dml'], B, 2 * L, 2 * L, self.g[f'm{i}.head.b'], accumulate=acc)
         self._dw_gemm('dml', 'a2', 'head')
+        self._region(allreduce, 'head')
         self._dx_gemm('dml', 'head', 'da2', 'd_a2')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
         self._dw_gemm('da2', 'a1', 'enc1')
+        self._region(allreduce, 'enc1')
         self._dx_gemm('da2', 'enc1', 'da1', 'd_a1')
         self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
         self._dw_gemm('da1', 'x', 'enc0')
+        self._region(allreduce, 'enc0')
         self.m.num_batches_tracked += 1
 
     def optimizer_step(self):
@@ -302,9 +314,14 @@ class TrainEngine:
                      self.state)
 
     def step(self, corr=None, Fblk=None, noise=None, allreduce=None):
-        self.forward_backward(corr, Fblk, noise)
+        """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
+        `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
+        self.forward_backward(corr, Fblk, noise, allreduce)
         if allreduce is not None:
-            allreduce(self.grad)
+            if hasattr(allreduce, 'finish'):
+                allreduce.finish()
+            else:
+                allreduce(self.grad)
         self.optimizer_step()
 
     def read_losses(self):

@@ -176,7 +176,7 @@ class JAMIE:
         allreduce = None
         if self.distributed:
             rank, world, _ = jd.init_from_env()
-            allreduce = jd.GradAllReduce()
+            allreduce = jd.OverlappedGradAllReduce()
         # ---- P / F (never densified for the identity) ----
         P_dense = None
         if self.P is None:

@@ -31,12 +31,11 @@ def _align4(n):
 class ParamLayout:
     """Offsets of every parameter tensor inside the flat buffer.
 
-    Per modality i (d = input_dim[i], L = output_dim), in order of use:
-      enc0.W [2d,d] enc0.b [2d] bn0.g bn0.b [2d] | enc1.W [d,2d] enc1.b [d] bn1.g bn1.b [d] |
-      head.W [2L,d] (rows 0..L-1 = fc_mus, L..2L-1 = fc_vars) head.b [2L] |
-      dec0.W [d,L] dec0.b [d] bn2.g bn2.b [d] | dec1.W [2d,d] dec1.b [2d] bn3.g bn3.b [2d] |
-      dec2.W [d,2d] dec2.b [d]
-    then sigma [M].  The two heads of a modality are adjacent so that mu and logvar come out of one GEMM.
+    Layer-major; inside a layer, modality by modality (d = input_dim[i], L = output_dim):
+      enc0: W [2d,d] b [2d] bn0.g bn0.b [2d] | enc1: W [d,2d] b [d] bn1.g bn1.b [d] |
+      head: sigma [M], then W [2L,d] (rows 0..L-1 = fc_mus, L..2L-1 = fc_vars) b [2L] |
+      dec0: W [d,L] b [d] bn2.g bn2.b [d] | dec1: W [2d,d] b [2d] bn3.g bn3.b [2d] | dec2: W [d,2d] b [d]
+    The two heads of a modality are adjacent so that mu and logvar come out of one GEMM.
     """
 
     def __init__(self, input_dim, output_dim):
@@ -53,15 +52,24 @@ class ParamLayout:
             self.entries[name] = (off, tuple(shape))
             off += _align4(n)
 
-        for i, d in enumerate(input_dim):
-            p = f'm{i}.'
-            add(p + 'enc0.W', 2 * d, d); add(p + 'enc0.b', 2 * d); add(p + 'bn0.g', 2 * d); add(p + 'bn0.b', 2 * d)
-            add(p + 'enc1.W', d, 2 * d); add(p + 'enc1.b', d); add(p + 'bn1.g', d); add(p + 'bn1.b', d)
-            add(p + 'head.W', 2 * L, d); add(p + 'head.b', 2 * L)
-            add(p + 'dec0.W', d, L); add(p + 'dec0.b', d); add(p + 'bn2.g', d); add(p + 'bn2.b', d)
-            add(p + 'dec1.W', 2 * d, d); add(p + 'dec1.b', 2 * d); add(p + 'bn3.g', 2 * d); add(p + 'bn3.b', 2 * d)
-            add(p + 'dec2.W', d, 2 * d); add(p + 'dec2.b', d)
-        add('sigma', self.M)
+        # layer-major order: the backward pass finishes layers from the END of the buffer towards the start,
+        # so the data-parallel all-reduce can start on contiguous tail regions while earlier layers are still
+        # in their backward GEMMs (`regions`, in backward completion order).
+        layers = [('enc0', lambda d: [('enc0.W', (2 * d, d)), ('enc0.b', (2 * d,)), ('bn0.g', (2 * d,)), ('bn0.b', (2 * d,))]),
+                  ('enc1', lambda d: [('enc1.W', (d, 2 * d)), ('enc1.b', (d,)), ('bn1.g', (d,)), ('bn1.b', (d,))]),
+                  ('head', lambda d: [('head.W', (2 * L, d)), ('head.b', (2 * L,))]),
+                  ('dec0', lambda d: [('dec0.W', (d, L)), ('dec0.b', (d,)), ('bn2.g', (d,)), ('bn2.b', (d,))]),
+                  ('dec1', lambda d: [('dec1.W', (2 * d, d)), ('dec1.b', (2 * d,)), ('bn3.g', (2 * d,)), ('bn3.b', (2 * d,))]),
+                  ('dec2', lambda d: [('dec2.W', (d, 2 * d)), ('dec2.b', (d,))])]
+        self.regions = {}
+        for lname, spec in layers:
+            start = off
+            if lname == 'head':
+                add('sigma', self.M)          # sigma's gradient is produced with the heads' (latent backward)
+            for i, d in enumerate(input_dim):
+                for nm, shape in spec(d):
+                    add(f'm{i}.{nm}', *shape)
+            self.regions[lname] = (start, off)
         self.total = off
         # BN running statistics (not optimised): separate flat buffer
         self.bn_entries = OrderedDict()

@@ -303,3 +303,69 @@ def test_facade_fit_transform_matches_oracle_loop(jam):
     np.testing.assert_array_equal(jm2.transform(data)[1], tr[1])
     # aligned cells should be closer than random pairs after training on a shared latent
     assert jm.test_closer(emb) < 0.35
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py's multi-rank path end to end (row shards, parameter broadcast, gradient all-reduce, barrier,
+    MAX over ranks, one JSON line) with two ranks on cuda:0 over gloo: everything except RCCL itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JAMIE_DIST_BACKEND='gloo', JAMIE_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29577', os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--steps', '6', '--warmup', '2', '--config', 'c1'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and 'cpu_baseline' not in out
+    assert np.isfinite(out['final_loss'])
+
+
+def test_data_parallel_ranks_stay_identical(tmp_path):
+    """Two ranks (sharing cuda:0, gloo) training on different shards keep bit-identical parameters after
+    several steps: the all-reduced gradient and the 1/world average give every rank the same update."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'dp.py'
+    script.write_text(f'''
+import sys, torch, numpy as np
+sys.path.insert(0, {root!r})
+from jamie_amd import distributed as jd, _native as nv
+from jamie_amd.engine import TrainEngine
+from jamie_amd.model import edModelVar
+rank, world, local = jd.init_from_env()
+dev = torch.device('cuda', local)
+torch.manual_seed(100 + rank)                     # different initial weights per rank ...
+model = edModelVar((96, 64), 8, device=dev)
+jd.broadcast_flat(model.flat)                     # ... until rank 0's are broadcast
+eng = TrainEngine(model, 64, seed=1 + rank, world_size=world)
+ar = jd.GradAllReduce(n_buckets=3)
+g = torch.Generator(device=dev).manual_seed(50 + rank)
+data = [torch.randn(512, d, generator=g, device=dev) for d in (96, 64)]
+idx = [torch.zeros(64, dtype=torch.int32, device=dev) for _ in range(2)]
+for s in range(5):
+    nv.sample_indices(idx[0], 512, 0, False, eng.state, 200)
+    idx[1].copy_(idx[0])
+    eng.load_batch(data, idx)
+    eng.step(None, None, None, ar)
+flat = model.flat.clone()
+others = [torch.zeros_like(flat) for _ in range(world)]
+torch.distributed.all_gather(others, flat)
+assert torch.equal(others[0], others[1]), (others[0] - others[1]).abs().max()
+assert torch.isfinite(flat).all()
+print('DP OK', rank)
+torch.distributed.destroy_process_group()
+''')
+    env = dict(os.environ, JAMIE_DIST_BACKEND='gloo', JAMIE_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29578', str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.stdout.count('DP OK') == 2
