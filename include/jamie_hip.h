@@ -79,6 +79,25 @@ int jamie_gemm_f32_cfg(const jamie_gemm_problem* problems /*host*/, int count, i
 int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm /*host*/, int* bn /*host*/);
 
 /* ---------------------------------------------------------------------------------------------
+ * bf16 compute mode (BASELINE config 2: bf16 compute / fp32 master weights).  Same products as jamie_gemm_f32,
+ * every one expressed as C[M,N] (fp32) = A[M,K] * B[N,K]^T with both operands K-contiguous bf16 (A, B of the
+ * problem struct point to bf16; lda/ldb in elements; K, lda, ldb multiples of 8; epilogues STORE and MSE):
+ *   forward A = a [B,in], B = W [out,in];  dX: A = dy [B,out], B = W^T [in,out];  dW: A = dy^T [out,B], B = a^T [in,B].
+ * jamie_cast_transpose produces the bf16 / bf16-transposed copies from fp32 (optionally summing split-K slabs).
+ * ------------------------------------------------------------------------------------------- */
+int jamie_gemm_bf16(const jamie_gemm_problem* problems /*host*/, int count, int cfg, void* stream);
+int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm /*host*/, int* bn /*host*/);
+
+typedef struct {
+    const float* src;           /* [R, C] fp32, leading dimension ld, nslab slabs slab_stride apart (summed)   */
+    void* dst;                  /* bf16 [R, C] (ldd) or NULL                                                    */
+    void* dstT;                 /* bf16 [C, R] (ldt) or NULL                                                    */
+    int R, C, ld, ldd, ldt, nslab;
+    long long slab_stride;
+} jamie_cast_problem;
+int jamie_cast_transpose(const jamie_cast_problem* problems /*host*/, int count /* <= 16 */, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * BatchNorm1d(train) + LeakyReLU + Dropout, forward and backward, one column strip per workgroup.
  * Replaces native_batch_norm / leaky_relu / bernoulli_ + mul (model.py:152-154,162-164,193-195,198-200)
  * and their backward.  h may arrive as `nslab` split-K slabs (summed here; slab 0 receives the sum).
@@ -156,7 +175,8 @@ int jamie_optim_blocks(long long n);   /* number of partials jamie_grad_sqnorm w
 int jamie_grad_sqnorm(const float* g, long long n, float* partials, int n_partials, uint64_t* state,
                       void* stream);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
-                    int n_partials, const float* hyper, const uint64_t* state, void* stream);
+                    int n_partials, const float* hyper, const uint64_t* state,
+                    void* p_bf16 /* optional bf16 copy of the updated parameters (same layout) or NULL */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batch assembly (jamie.py:552-604).

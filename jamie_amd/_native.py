@@ -30,6 +30,12 @@ class GemmProblem(C.Structure):
                 ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float)]
 
 
+class CastProblem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('dstT', C.c_void_p),
+                ('R', C.c_int), ('C', C.c_int), ('ld', C.c_int), ('ldd', C.c_int), ('ldt', C.c_int),
+                ('nslab', C.c_int), ('slab_stride', C.c_longlong)]
+
+
 class BnFwdProblem(C.Structure):
     _fields_ = [('h', C.c_void_p), ('nslab', C.c_int), ('slab_stride', C.c_longlong),
                 ('gamma', C.c_void_p), ('beta', C.c_void_p),
@@ -70,6 +76,9 @@ EXPORTS = {
     'jamie_gemm_f32': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
     'jamie_gemm_f32_cfg': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'jamie_gemm_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'jamie_gemm_bf16': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
+    'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'jamie_cast_transpose': (C.c_int, [C.POINTER(CastProblem), C.c_int, C.c_void_p]),
     'jamie_bn_act_fwd': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_void_p]),
     'jamie_bn_act_bwd': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -79,7 +88,7 @@ EXPORTS = {
     'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
     'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
-                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'jamie_gather_rows': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p]),
     'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
@@ -117,6 +126,54 @@ def load():
 def _check(rc):
     if rc != 0:
         raise JamieHipError(f'libjamie_hip error {rc}: {load().jamie_last_error().decode()}')
+
+
+# ---------------------------------------------------------------------------------------------------
+# launch plans: the training step is a fixed sequence of C-ABI calls on static buffers, so it is recorded once
+# and replayed with one foreign call per launch (building the ctypes descriptors costs ~10x the call itself).
+# ---------------------------------------------------------------------------------------------------
+_rec = None
+
+
+def begin_record():
+    global _rec
+    _rec = []
+
+
+def end_record():
+    global _rec
+    plan, _rec = _rec, None
+    return plan
+
+
+def record_callable(fn):
+    """Insert a Python callable (event record, collective, ...) into the plan being recorded; returns True if
+    a recording is active (the caller should then NOT run it itself unless it wants it executed now too)."""
+    if _rec is not None:
+        _rec.append((fn, None))
+        return True
+    return False
+
+
+def replay(plan):
+    st = _stream()
+    lib_err = None
+    for fn, args in plan:
+        if args is None:
+            fn()
+        else:
+            rc = fn(*args[:-1], st)          # the stream is the last argument of every launch entry point
+            if rc:
+                lib_err = rc
+    if lib_err:
+        _check(lib_err)
+
+
+def _call(name, *args):
+    fn = getattr(load(), name)
+    if _rec is not None:
+        _rec.append((fn, args))
+    _check(fn(*args))
 
 
 def _stream():
@@ -157,7 +214,7 @@ def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_s
 
 def gemm(problems, layout, cfg=-1):
     arr = (GemmProblem * len(problems))(*problems)
-    _check(load().jamie_gemm_f32_cfg(arr, len(problems), layout, cfg, _stream()))
+    _call('jamie_gemm_f32_cfg', arr, len(problems), layout, cfg, _stream())
 
 
 def gemm_tile(layout, max_m, max_n, max_k, cfg=-1):
@@ -166,22 +223,50 @@ def gemm_tile(layout, max_m, max_n, max_k, cfg=-1):
     return bm.value, bn.value
 
 
+def gemm_bf16(problems, cfg=-1):
+    arr = (GemmProblem * len(problems))(*problems)
+    _call('jamie_gemm_bf16', arr, len(problems), cfg, _stream())
+
+
+def gemm_bf16_tile(max_m, max_n, cfg=-1):
+    bm, bn = C.c_int(), C.c_int()
+    _check(load().jamie_gemm_bf16_tile(max_m, max_n, cfg, C.byref(bm), C.byref(bn)))
+    return bm.value, bn.value
+
+
+def cast_problem(src, dst=None, dstT=None, nslab=1, slab_stride=0):
+    """fp32 [R, C] (contiguous 2-D view; slabs `slab_stride` elements apart) -> bf16 dst [R, C] / dstT [C, R]."""
+    p = CastProblem()
+    R, Cc = src.shape[-2], src.shape[-1]
+    p.src, p.dst, p.dstT = ptr(src), ptr(dst), ptr(dstT)
+    p.R, p.C, p.ld, p.ldd, p.ldt, p.nslab, p.slab_stride = R, Cc, Cc, Cc, R, nslab, slab_stride
+    p._keep = (src, dst, dstT)
+    return p
+
+
+def cast_transpose(problems):
+    for i in range(0, len(problems), 16):
+        chunk = problems[i:i + 16]
+        arr = (CastProblem * len(chunk))(*chunk)
+        _call('jamie_cast_transpose', arr, len(chunk), _stream())
+
+
 def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01):
     arr = (BnFwdProblem * len(problems))(*problems)
-    _check(load().jamie_bn_act_fwd(arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), _stream()))
+    _call('jamie_bn_act_fwd', arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), _stream())
 
 
 def bn_act_bwd(problems, p_drop, rng, slope=0.01):
     arr = (BnBwdProblem * len(problems))(*problems)
-    _check(load().jamie_bn_act_bwd(arr, len(problems), p_drop, slope, ptr(rng), _stream()))
+    _call('jamie_bn_act_bwd', arr, len(problems), p_drop, slope, ptr(rng), _stream())
 
 
 def latent_fwd(desc, rng):
-    _check(load().jamie_latent_fwd(C.byref(desc), ptr(rng), _stream()))
+    _call('jamie_latent_fwd', C.pointer(desc), ptr(rng), _stream())
 
 
 def latent_bwd(desc):
-    _check(load().jamie_latent_bwd(C.byref(desc), _stream()))
+    _call('jamie_latent_bwd', C.pointer(desc), _stream())
 
 
 def optim_blocks(n):
@@ -189,27 +274,25 @@ def optim_blocks(n):
 
 
 def grad_sqnorm(g, partials, state):
-    _check(load().jamie_grad_sqnorm(ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream()))
+    _call('jamie_grad_sqnorm', ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream())
 
 
-def clip_adam(p, g, m, v, partials, hyper, state):
-    _check(load().jamie_clip_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),
-                                  ptr(hyper), ptr(state), _stream()))
+def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None):
+    _call('jamie_clip_adam', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),
+          ptr(hyper), ptr(state), ptr(p_bf16), _stream())
 
 
 def gather_rows(src, idx, dst):
-    _check(load().jamie_gather_rows(ptr(src), src.shape[0], src.shape[1], ptr(idx), idx.numel(), ptr(dst),
-                                    _stream()))
+    _call('jamie_gather_rows', ptr(src), src.shape[0], src.shape[1], ptr(idx), idx.numel(), ptr(dst), _stream())
 
 
 def sample_indices(idx, N, offset, replace, rng, rng_stream):
-    _check(load().jamie_sample_indices(ptr(idx), idx.numel(), N, offset, int(replace), ptr(rng), rng_stream,
-                                       _stream()))
+    _call('jamie_sample_indices', ptr(idx), idx.numel(), N, offset, int(replace), ptr(rng), rng_stream, _stream())
 
 
 def corr_from_indices(idx0, idx1, corr):
-    _check(load().jamie_corr_from_indices(ptr(idx0), ptr(idx1), idx0.numel(), ptr(corr), _stream()))
+    _call('jamie_corr_from_indices', ptr(idx0), ptr(idx1), idx0.numel(), ptr(corr), _stream())
 
 
 def colsum(X, M, N, ld, out, nslab=1, slab_stride=0, accumulate=False):
-    _check(load().jamie_colsum(ptr(X), M, N, ld, nslab, slab_stride, ptr(out), int(accumulate), _stream()))
+    _call('jamie_colsum', ptr(X), M, N, ld, nslab, slab_stride, ptr(out), int(accumulate), _stream())

@@ -1,0 +1,379 @@
+// bf16 GEMM on v_mfma_f32_32x32x16_bf16 with fp32 accumulation/output for JAMIE's Linear layers, gfx950.
+//
+// bf16 compute mode of the training step (BASELINE config 2: "bf16 compute / fp32 master"): the same
+// products as gemm_f32.hip (reference model.py:151,161,180,185,192,197,207; jamie.py:734), but every product is
+// expressed as C[M,N] = A[M,K] * B[N,K]^T with BOTH operands K-contiguous bf16:
+//     forward   y  = a   W^T      A = a    [B, in]     B = W    [out, in]
+//     dX        dx = dy  W        A = dy   [B, out]    B = W^T  [in, out]     (bf16 transposed weight copy)
+//     dW        dW = dy^T a       A = dy^T [out, B]    B = a^T  [in, B]       (bf16 transposed activations)
+// The producers (cast_transpose / bn_act kernels) write the bf16 and bf16-transposed copies, so ONE kernel
+// shape serves all three and each MFMA lane fetches its 8 k-values with a single ds_read_b128.
+//
+// Tile BM x BN x BK, WM x WN waves, each wave TM x TN tiles of 32x32 (C/D map as in gemm_f32.hip).  LDS rows
+// are padded to BK*2 + 16 bytes (16 * odd): conflict-free ds_read_b128.  Staging, double buffering, fragment
+// prefetch, grouped launch, XCD mapping, split-K slabs and epilogues are those of gemm_f32.hip.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmBDev {
+    const unsigned short* A; const unsigned short* B; float* C; const float* bias;
+    const float* aux0; float* partial;
+    long long slab_stride;
+    int M, N, K, lda, ldb, ldc, aux_ld;
+    int splitk, kchunk, tiles_m, tiles_n, n_tiles;
+    int epi, accumulate;
+    unsigned a_bytes, b_bytes;
+    float scale, pscale;
+};
+struct GemmBGroup { GemmBDev p[JAMIE_MAX_GROUP]; int count; };
+
+#define JB_OOB 0xFFFFFFF0u
+
+template <int BM, int BN, int BK, int WM, int WN, int TAG>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int LDB = BK * 2 + 16;                 // LDS row stride in bytes
+    constexpr int CH = BK / 8;                       // 16-byte chunks per row
+    constexpr int A_SZ = BM * LDB, B_SZ = BN * LDB;  // bytes
+    constexpr int LA = BM * CH / NT, LB = BN * CH / NT;
+    static_assert(LA >= 1 && LB >= 1 && (BM * CH) % NT == 0 && (BN * CH) % NT == 0 && BK % 16 == 0, "tile/thread mismatch");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_SZ + B_SZ)];
+    __shared__ float red[WM * WN];
+
+    // ---- block -> (problem, tile): per-problem XCD chunks (see gemm_f32.hip) ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    int pi = 0, t = 0, rot = 0;
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+        if (i < g.count) {
+            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
+            const int j = (xcd - rot) & 7;
+            const int cp = qp + (j < rp ? 1 : 0);
+            if (slot >= 0 && slot < cp) {
+                pi = i;
+                t = j * qp + min(j, rp) + slot;
+                slot = -1;
+            } else if (slot >= 0) {
+                slot -= cp;
+            }
+            rot = (rot + rp) & 7;
+        }
+    }
+    const GemmBDev& P = g.p[pi];
+    const int tm_i = t % P.tiles_m;
+    const int tn_i = (t / P.tiles_m) % P.tiles_n;
+    const int ks = t / (P.tiles_m * P.tiles_n);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int kbeg = ks * P.kchunk;
+    const int kend = min(P.K, kbeg + P.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
+    const int r = lane & 31, h = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (int)P.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (int)P.b_bytes, 0x00020000);
+    unsigned a_off[LA], b_off[LB];
+    int a_k[LA], b_k[LB], a_lds[LA], b_lds[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int f = tid + j * NT, row = f / CH, c = f % CH;
+        const int gm = m0 + row;
+        a_off[j] = gm < P.M ? ((unsigned)gm * (unsigned)P.lda + (unsigned)c * 8u) * 2u : JB_OOB;
+        a_k[j] = c * 8;
+        a_lds[j] = row * LDB + c * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int f = tid + j * NT, row = f / CH, c = f % CH;
+        const int gn = n0 + row;
+        b_off[j] = gn < P.N ? ((unsigned)gn * (unsigned)P.ldb + (unsigned)c * 8u) * 2u : JB_OOB;
+        b_k[j] = c * 8;
+        b_lds[j] = row * LDB + c * 16;
+    }
+
+    u32x4 ra[LA], rb[LB];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const bool ok = a_off[j] != JB_OOB && k0 + a_k[j] < kend;
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, ok ? (int)(a_off[j] + (unsigned)k0 * 2u) : (int)JB_OOB, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const bool ok = b_off[j] != JB_OOB && k0 + b_k[j] < kend;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, ok ? (int)(b_off[j] + (unsigned)k0 * 2u) : (int)JB_OOB, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* As = smem + buf * (A_SZ + B_SZ);
+        unsigned char* Bs = As + A_SZ;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) *reinterpret_cast<u32x4*>(As + a_lds[j]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) *reinterpret_cast<u32x4*>(Bs + b_lds[j]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nk > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kbeg + (kt + 1) * BK);
+        const unsigned char* As = smem + cur * (A_SZ + B_SZ);
+        const unsigned char* Bs = As + A_SZ;
+        bf16x8 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int buf, int s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[buf][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * LDB + s * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[buf][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * LDB + s * 32 + h * 16);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
+    float* Cout = P.C + (long long)ks * P.slab_stride;
+    const bool add_bias = (P.bias != nullptr) && ks == 0;
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + r;
+        if (n >= P.N) continue;
+        const float bv = add_bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= P.M) continue;
+                float v = acc[i][j][e] + bv;
+                float* cp = Cout + (long long)m * P.ldc + n;
+                if (P.epi == JAMIE_EPI_STORE) {
+                    if (P.accumulate) v += *cp;
+                    *cp = v;
+                } else {  // JAMIE_EPI_MSE
+                    const float d = v - P.aux0[(long long)m * P.aux_ld + n];
+                    local += d * d;
+                    *cp = d * P.scale;
+                }
+            }
+        }
+    }
+    if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
+    GemmBGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int tiles = 0;
+    bool big = true;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        GemmBDev& d = g.p[i];
+        d.A = (const unsigned short*)s.A; d.B = (const unsigned short*)s.B; d.C = s.C; d.bias = s.bias;
+        d.aux0 = s.aux0; d.partial = s.partial; d.slab_stride = s.slab_stride;
+        d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.aux_ld = s.aux_ld;
+        d.splitk = s.splitk < 1 ? 1 : s.splitk;
+        int kc = (s.K + d.splitk - 1) / d.splitk;
+        kc = ((kc + BK - 1) / BK) * BK;
+        d.kchunk = kc;
+        d.tiles_m = (s.M + BM - 1) / BM;
+        d.tiles_n = (s.N + BN - 1) / BN;
+        d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        tiles += d.n_tiles;
+        d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
+        d.a_bytes = (unsigned)(((long long)(s.M - 1) * s.lda + s.K) * 2);
+        d.b_bytes = (unsigned)(((long long)(s.N - 1) * s.ldb + s.K) * 2);
+        if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
+    }
+    if (tiles == 0) return 0;
+    if (big)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WM, WN, 1>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WM, WN, 0>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+    return jamie_launch_status("jamie_gemm_bf16");
+}
+
+static const int BT[5][2] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
+
+// measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
+// (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
+static int pick_cfg_b(int max_m, int max_n) { (void)max_m; (void)max_n; return 1; }
+
+extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg, void* stream) {
+    JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
+    int max_m = 0, max_n = 0;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        JAMIE_ARG(s.A && s.B && s.C, "null operand");
+        JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
+        JAMIE_ARG(s.ldc >= s.N && s.lda >= s.K && s.ldb >= s.K, "leading dimensions");
+        JAMIE_ARG(s.K % 8 == 0 && s.lda % 8 == 0 && s.ldb % 8 == 0, "bf16 operands need K, lda, ldb multiples of 8");
+        JAMIE_ARG(((uintptr_t)s.A % 16) == 0 && ((uintptr_t)s.B % 16) == 0, "bf16 operands must be 16-byte aligned");
+        JAMIE_ARG(((long long)(s.M - 1) * s.lda + s.K) * 2 < 0xFFFFFFF0LL && ((long long)(s.N - 1) * s.ldb + s.K) * 2 < 0xFFFFFFF0LL,
+                  "operands must stay below 4 GiB");
+        JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.epi == JAMIE_EPI_MSE, "bf16 GEMM epilogues: STORE, MSE");
+        JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.splitk <= 1, "fused epilogues need splitk == 1");
+        JAMIE_ARG(s.splitk <= 1 || !s.accumulate, "split-K slabs cannot accumulate");
+        JAMIE_ARG(s.epi != JAMIE_EPI_MSE || (s.aux0 && s.aux_ld >= s.N), "MSE epilogue needs aux0 = X");
+        JAMIE_ARG(s.splitk <= 1 || s.slab_stride >= (long long)s.M * s.ldc, "slab_stride too small");
+        JAMIE_ARG(s.a_rows == nullptr, "row gather is not supported in the bf16 GEMM");
+        if (s.M > max_m) max_m = s.M;
+        if (s.N > max_n) max_n = s.N;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg < 0) cfg = pick_cfg_b(max_m, max_n);
+    switch (cfg) {
+        case 0: return launch_b<128, 128, 64, 2, 2>(pr, count, st);
+        case 1: return launch_b<64, 64, 64, 2, 2>(pr, count, st);
+        case 2: return launch_b<128, 64, 64, 2, 2>(pr, count, st);
+        case 3: return launch_b<64, 128, 64, 2, 2>(pr, count, st);
+        case 4: return launch_b<128, 128, 32, 2, 2>(pr, count, st);
+        default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
+    }
+}
+
+extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
+    if (cfg < 0) cfg = pick_cfg_b(max_m, max_n);
+    if (cfg > 4 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
+    *bm = BT[cfg][0]; *bn = BT[cfg][1];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 [R, C] (sum of slabs) -> bf16 [R, C] and / or bf16 transposed [C, R]: 64x64 tiles through LDS so that both
+// the reads and the transposed writes move whole 128-byte lines.  Up to 16 matrices per launch (the weights).
+// ------------------------------------------------------------------------------------------------
+#define CT_MAX 16
+struct CastDev { const float* src; unsigned short* dst; unsigned short* dstT; long long slab_stride; int R, C, ld, ldd, ldt, nslab, blk_begin, tiles_c; };
+struct CastGroup { CastDev p[CT_MAX]; int count; };
+
+__global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
+    // 64 x 64 tile per workgroup: float4 reads (a wave = 4 rows x 256 B), 8-byte bf16x4 row-major stores, the
+    // transposed copy through a padded LDS tile as 8-byte stores of 4 consecutive rows (16 lanes = 128 B).
+    __shared__ float tile[64][65];
+    int pi = 0;
+    for (int i = 1; i < CT_MAX; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
+    const CastDev& P = g.p[pi];
+    const int b = blockIdx.x - P.blk_begin;
+    const int r0 = (b / P.tiles_c) * 64, c0 = (b % P.tiles_c) * 64;
+    const int q = threadIdx.x & 15, rr0 = threadIdx.x >> 4;          // 16 column quads x 16 rows per pass
+    const bool vec = (P.ld % 4 == 0) && (((uintptr_t)P.src & 15) == 0) && (P.slab_stride % 4 == 0);
+    const bool vecd = P.dst && (P.ldd % 4 == 0) && (((uintptr_t)P.dst & 7) == 0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int rr = rr0 + 16 * pass, r = r0 + rr, c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < P.R) {
+            for (int s = 0; s < P.nslab; ++s) {
+                const float* sp = P.src + s * P.slab_stride + (long long)r * P.ld + c;
+                if (vec && c + 3 < P.C) {
+                    const float4 u = *reinterpret_cast<const float4*>(sp);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                } else {
+                    if (c < P.C) v.x += sp[0];
+                    if (c + 1 < P.C) v.y += sp[1];
+                    if (c + 2 < P.C) v.z += sp[2];
+                    if (c + 3 < P.C) v.w += sp[3];
+                }
+            }
+        }
+        tile[rr][4 * q] = v.x; tile[rr][4 * q + 1] = v.y; tile[rr][4 * q + 2] = v.z; tile[rr][4 * q + 3] = v.w;
+        if (P.dst && r < P.R) {
+            const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)v.x), b1 = __builtin_bit_cast(unsigned short, (__bf16)v.y);
+            const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)v.z), b3 = __builtin_bit_cast(unsigned short, (__bf16)v.w);
+            unsigned short* dp = P.dst + (long long)r * P.ldd + c;
+            if (vecd && c + 3 < P.C) {
+                *reinterpret_cast<uint2*>(dp) = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+            } else {
+                if (c < P.C) dp[0] = b0;
+                if (c + 1 < P.C) dp[1] = b1;
+                if (c + 2 < P.C) dp[2] = b2;
+                if (c + 3 < P.C) dp[3] = b3;
+            }
+        }
+    }
+    if (!P.dstT) return;
+    __syncthreads();
+    const bool vect = (P.ldt % 4 == 0) && (((uintptr_t)P.dstT & 7) == 0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int cc = rr0 + 16 * pass, c = c0 + cc, r = r0 + 4 * q;      // 4 consecutive rows of column c
+        if (c >= P.C) continue;
+        const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q][cc]);
+        const unsigned short b1 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + 1][cc]);
+        const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + 2][cc]);
+        const unsigned short b3 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + 3][cc]);
+        unsigned short* dp = P.dstT + (long long)c * P.ldt + r;
+        if (vect && r + 3 < P.R) {
+            *reinterpret_cast<uint2*>(dp) = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+        } else {
+            if (r < P.R) dp[0] = b0;
+            if (r + 1 < P.R) dp[1] = b1;
+            if (r + 2 < P.R) dp[2] = b2;
+            if (r + 3 < P.R) dp[3] = b3;
+        }
+    }
+}
+
+extern "C" int jamie_cast_transpose(const jamie_cast_problem* pr, int count, void* stream) {
+    JAMIE_ARG(pr && count >= 1 && count <= CT_MAX, "1 <= count <= 16");
+    CastGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const jamie_cast_problem& s = pr[i];
+        JAMIE_ARG(s.src && (s.dst || s.dstT) && s.R > 0 && s.C > 0 && s.ld >= s.C && s.nslab >= 1, "bad cast problem");
+        JAMIE_ARG(!s.dst || s.ldd >= s.C, "ldd < C");
+        JAMIE_ARG(!s.dstT || s.ldt >= s.R, "ldt < R");
+        CastDev& d = g.p[i];
+        d.src = s.src; d.dst = (unsigned short*)s.dst; d.dstT = (unsigned short*)s.dstT; d.slab_stride = s.slab_stride;
+        d.R = s.R; d.C = s.C; d.ld = s.ld; d.ldd = s.ldd; d.ldt = s.ldt; d.nslab = s.nslab;
+        d.blk_begin = blocks; d.tiles_c = (s.C + 63) / 64;
+        blocks += ((s.R + 63) / 64) * d.tiles_c;
+    }
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return jamie_launch_status("jamie_cast_transpose");
+}

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* partials, int n_partials,
-                                                        const float* hyper, const uint64_t* state) {
+                                                        const float* hyper, const uint64_t* state,
+                                                        unsigned short* __restrict__ p_bf16) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
@@ -67,10 +68,18 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
         upd(pp.z, gg.z, mm.z, vv.z);
         upd(pp.w, gg.w, mm.w, vv.w);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (p_bf16) {   // bf16 copy of the updated master weights for the bf16-compute GEMMs (+2 B/parameter)
+            const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)pp.x), b1 = __builtin_bit_cast(unsigned short, (__bf16)pp.y);
+            const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)pp.z), b3 = __builtin_bit_cast(unsigned short, (__bf16)pp.w);
+            reinterpret_cast<uint2*>(p_bf16)[i] = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+        }
     }
     if (blockIdx.x == 0) {
         const long long i = (n4 << 2) + threadIdx.x;
-        if (i < n) upd(p[i], g[i], m[i], v[i]);
+        if (i < n) {
+            upd(p[i], g[i], m[i], v[i]);
+            if (p_bf16) p_bf16[i] = __builtin_bit_cast(unsigned short, (__bf16)p[i]);
+        }
     }
 }
 
@@ -92,13 +101,14 @@ extern "C" int jamie_grad_sqnorm(const float* g, long long n, float* partials, i
 }
 
 extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
-                               int n_partials, const float* hyper, const uint64_t* state, void* stream) {
+                               int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
     JAMIE_ARG(p && g && m && v && partials && hyper && state && n > 0, "null pointer / empty");
     JAMIE_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                   ((uintptr_t)v % 16) == 0, "buffers must be 16-byte aligned");
     JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
+    JAMIE_ARG(p_bf16 == nullptr || ((uintptr_t)p_bf16 % 8) == 0, "p_bf16 must be 8-byte aligned");
     hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       partials, n_partials, hyper, state);
+                       partials, n_partials, hyper, state, (unsigned short*)p_bf16);
     return jamie_launch_status("jamie_clip_adam");
 }
 

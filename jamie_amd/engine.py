@@ -41,14 +41,23 @@ def kl_anneal(epoch, min_epochs, epoch_DNN):
 
 class TrainEngine:
     def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
-                 world_size=1, general_corr=True, use_F=False):
+                 world_size=1, compute_dtype='f32'):
+        """compute_dtype 'f32': exact-fp32 MFMA GEMMs (the parity configuration).  'bf16': bf16 MFMA GEMMs with
+        fp32 accumulation, fp32 master weights / optimiser / BatchNorm / losses (BASELINE config 2); needs every
+        feature count, the latent size and the batch size to be multiples of 8."""
         nv.require_gpu()
+        if compute_dtype not in ('f32', 'bf16'):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        self.bf16 = compute_dtype == 'bf16'
+        self.compute_dtype = compute_dtype
         self.m = model
         self.dev = model.device
         self.B = B = int(batch_size)
         self.dims = model.input_dim
         self.L = L = model.output_dim
         self.p_drop = model.dropout
+        if self.bf16 and any(v % 8 for v in list(self.dims) + [L, B]):
+            raise ValueError('bf16 compute needs feature counts, latent size and batch size that are multiples of 8')
         self.cosine = dist_method == 'cosine'
         if dist_method not in ('euclidean', 'cosine'):
             raise ValueError("dist_method must be 'euclidean' or 'cosine' (jamie.py:483-502)")
@@ -108,9 +117,26 @@ class TrainEngine:
             for k, nn in (('bn0', 2 * d), ('bn1', d), ('bn2', d), ('bn3', 2 * d)):
                 w[k + '.mean'] = torch.empty(nn, **f32); w[k + '.invstd'] = torch.empty(nn, **f32)
             w['idx'] = torch.zeros(B, dtype=torch.int32, device=self.dev)
+            if self.bf16:
+                bf = dict(device=self.dev, dtype=torch.bfloat16)
+                for k, nf in (('x', d), ('a1', 2 * d), ('a2', d), ('comb', L), ('e1', d), ('e2', 2 * d), ('dxhat', d),
+                              ('de2', 2 * d), ('de1', d), ('dml', 2 * L), ('da2', d), ('da1', 2 * d)):
+                    w[k + '_bf'] = torch.empty(B, nf, **bf)
+                    w[k + '_T'] = torch.empty(nf, B, **bf)
             self.ws.append(w)
         # dec2 (MSE epilogue) uses the 64x128 tile config unless N <= 64
-        bm_t, bn_t = nv.gemm_tile(nv.NT, B, max(self.dims), 2 * max(self.dims))   # tile of the grouped launch
+        if self.bf16:
+            # bf16 copies of the weights: same flat layout, plus K-contiguous transposes for the dX products
+            self.wbf_flat = torch.zeros(model.layout.total, device=self.dev, dtype=torch.bfloat16)
+            self.wbf = model.layout.views(self.wbf_flat)
+            self.wT = {}
+            for i, d in enumerate(self.dims):
+                for lin in ('enc1', 'head', 'dec0', 'dec1', 'dec2'):
+                    nout, nin = model.p[f'm{i}.{lin}.W'].shape
+                    self.wT[f'm{i}.{lin}'] = torch.empty(nin, nout, device=self.dev, dtype=torch.bfloat16)
+            self.refresh_weights_bf16()
+        bm_t, bn_t = (nv.gemm_bf16_tile(B, max(self.dims)) if self.bf16 else
+                      nv.gemm_tile(nv.NT, B, max(self.dims), 2 * max(self.dims)))   # tile of the grouped launch
         self.rec_tiles = [math.ceil(B / bm_t) * math.ceil(d / bn_t) for d in self.dims]
         self.rec_partials = torch.zeros(sum(self.rec_tiles), **f32)
         self.rsum = torch.empty(B, **f32); self.qsum = torch.empty(B, **f32)
@@ -128,24 +154,60 @@ class TrainEngine:
         self.losses[5] = float('inf')
 
     # ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----
-    def enable_kernel_timing(self, label):
-        self._timing = {label: []}
+    def enable_kernel_timing(self, *labels):
+        self._timing = {label: [] for label in labels}
+
+    def _ev(self, label, which):
+        """Record a HIP event on the launch stream (works both eagerly and as a step of a replayed plan)."""
+        def rec():
+            if self._timing is None or label not in self._timing:
+                return
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            lst = self._timing[label]
+            if which == 0:
+                lst.append([e, None])
+            elif lst and lst[-1][1] is None:
+                lst[-1][1] = e
+        if not nv.record_callable(rec):
+            rec()
 
     def _launch(self, label, fn):
-        if self._timing is None or label not in self._timing:
-            return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        self._ev(label, 0)
         fn()
-        e1.record()
-        self._timing[label].append((e0, e1))
+        self._ev(label, 1)
 
     def kernel_timing_ms(self, label):
         if self._timing is None or not self._timing.get(label):
             return None
         torch.cuda.synchronize()
-        t = [a.elapsed_time(b) for a, b in self._timing[label]]
+        t = [a.elapsed_time(b) for a, b in self._timing[label] if b is not None]
         return float(np.mean(t))
+
+    # ---- bf16 compute mode: bf16 / bf16-transposed copies of GEMM operands ----
+    def refresh_weights_bf16(self, transposes_only=False):
+        """bf16 copy of every weight matrix (written by the Adam kernel itself during training) and the
+        K-contiguous transposed copies the dX products read."""
+        probs = []
+        for i, d in enumerate(self.dims):
+            for lin in ('enc0', 'enc1', 'head', 'dec0', 'dec1', 'dec2'):
+                W = self.m.p[f'm{i}.{lin}.W']
+                wt = self.wT.get(f'm{i}.{lin}')
+                if transposes_only and wt is None:
+                    continue
+                probs.append(nv.cast_problem(W, None if transposes_only else self.wbf[f'm{i}.{lin}.W'], wt))
+        nv.cast_transpose(probs)
+
+    def _cast(self, key):
+        """fp32 activation / gradient `key` ([B, n] or slab 0 of [S, B, n]) -> bf16 [B, n] and bf16 [n, B]."""
+        if not self.bf16:
+            return
+        probs = []
+        for w in self.ws:
+            src = w[key]
+            src2 = src[0] if src.dim() == 3 else src
+            probs.append(nv.cast_problem(src2, w[key + '_bf'], w[key + '_T']))
+        nv.cast_transpose(probs)
 
     # ---- pieces ----
     def _mask(self, noise, kind, i, j):
@@ -191,10 +253,13 @@ class TrainEngine:
             w, P = self.ws[i], self.m.p
             a, W, out = w[a_key], P[f'm{i}.{lin}.W'], w[out_key]
             nout, nin = W.shape
+            if self.bf16:
+                a, W = w[a_key + '_bf'], self.wbf[f'm{i}.{lin}.W']
             probs.append(nv.gemm_problem(a, W, out, self.B, nout, nin, nin, nin, nout,
                                          bias=P[f'm{i}.{lin}.b'] if with_bias else None,
                                          splitk=w['sk'][sk_key], slab_stride=self.B * nout))
-        self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') else lin, lambda: nv.gemm(probs, nv.NT))
+        self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') else lin,
+                     (lambda: nv.gemm_bf16(probs)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
 
     def _dx_gemm(self, dy_key, lin, out_key, sk_key):
         """dx[B, in_f] (slabs) = dy[B, out_f] W."""
@@ -203,9 +268,16 @@ class TrainEngine:
             w, P = self.ws[i], self.m.p
             dy, W, out = w[dy_key], P[f'm{i}.{lin}.W'], w[out_key]
             nout, nin = W.shape
-            probs.append(nv.gemm_problem(dy, W, out, self.B, nin, nout, nout, nin, nin,
-                                         splitk=w['sk'][sk_key], slab_stride=self.B * nin))
-        nv.gemm(probs, nv.NN)
+            if self.bf16:     # dx = dy W  ==  dy (W^T)^T with the K-contiguous transposed copy
+                probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], out, self.B, nin, nout,
+                                             nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+            else:
+                probs.append(nv.gemm_problem(dy, W, out, self.B, nin, nout, nout, nin, nin,
+                                             splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+        if self.bf16:
+            nv.gemm_bf16(probs)
+        else:
+            nv.gemm(probs, nv.NN)
 
     def _dw_gemm(self, dy_key, a_key, lin):
         """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer."""
@@ -214,8 +286,15 @@ class TrainEngine:
             w = self.ws[i]
             dy, a, dW = w[dy_key], w[a_key], self.g[f'm{i}.{lin}.W']
             nout, nin = dW.shape
-            probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
-        nv.gemm(probs, nv.TN)
+            if self.bf16:     # dW = dy^T a  ==  (dy^T) (a^T)^T, both [features, B] copies are K(=batch)-contiguous
+                probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B,
+                                             nin, accumulate=self.accumulate))
+            else:
+                probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
+        if self.bf16:
+            nv.gemm_bf16(probs)
+        else:
+            nv.gemm(probs, nv.TN)
 
     def _latent_desc(self, corr, Fblk, noise):
         B, L = self.B, self.L
@@ -244,12 +323,21 @@ class TrainEngine:
         """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors."""
         for i in range(2):
             nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
+        self._cast('x')
 
     def _region(self, ar, name):
         """Tell an overlapping all-reduce that the gradients of parameter region `name` have been launched."""
         if ar is not None and hasattr(ar, 'region_done'):
             lo, hi = self.m.layout.regions[name]
-            ar.region_done(self.grad, lo, hi)
+            fn = lambda: ar.region_done(self.grad, lo, hi)   # noqa: E731
+            nv.record_callable(fn)
+            fn()
+
+    def set_batch(self, X):
+        """Use the given [B, d_i] fp32 matrices as the batch (tests; the training loop uses `load_batch`)."""
+        for i in range(2):
+            self.ws[i]['x'].copy_(X[i])
+        self._cast('x')
 
     def forward_backward(self, corr=None, Fblk=None, noise=None, allreduce=None):
         """Forward, losses and backward for the batch already in the workspace.  `corr` None = identity,
@@ -258,25 +346,32 @@ class TrainEngine:
         # ---------------- forward ----------------
         self._fwd_gemm('x', 'enc0', 'h1', 'enc0')
         self._bn_fwd('bn0', 'h1', 'a1', 10, noise, 'enc_masks', 0)
+        self._cast('a1')
         self._fwd_gemm('a1', 'enc1', 'h2', 'enc1')
         self._bn_fwd('bn1', 'h2', 'a2', 11, noise, 'enc_masks', 1)
+        self._cast('a2')
         self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)      # bias added in the latent kernel
         lat = self._latent_desc(corr, Fblk, noise)
         nv.latent_fwd(lat, self.state)
+        self._cast('comb')
         self._fwd_gemm('comb', 'dec0', 'g1', 'dec0')
         self._bn_fwd('bn2', 'g1', 'e1', 12, noise, 'dec_masks', 0)
+        self._cast('e1')
         self._fwd_gemm('e1', 'dec1', 'g2', 'dec1')
         self._bn_fwd('bn3', 'g2', 'e2', 13, noise, 'dec_masks', 1)
+        self._cast('e2')
         probs, off = [], 0
         for i, d in enumerate(self.dims):                                 # x_hat GEMM + fused MSE
             w, P = self.ws[i], self.m.p
             W = P[f'm{i}.dec2.W']
-            probs.append(nv.gemm_problem(w['e2'], W, w['dxhat'], B, d, 2 * d, 2 * d, 2 * d, d,
+            probs.append(nv.gemm_problem(w['e2_bf'] if self.bf16 else w['e2'], self.wbf[f'm{i}.dec2.W'] if self.bf16 else W,
+                                         w['dxhat'], B, d, 2 * d, 2 * d, 2 * d, d,
                                          bias=P[f'm{i}.dec2.b'], epi=nv.EPI_MSE, aux=(w['x'], None, None, None),
                                          aux_ld=d, partial=self.rec_partials[off:off + self.rec_tiles[i]],
                                          scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
             off += self.rec_tiles[i]
-        self._launch('enc_gemm', lambda: nv.gemm(probs, nv.NT))
+        self._launch('enc_gemm', (lambda: nv.gemm_bf16(probs)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
+        self._cast('dxhat')
         # ---------------- backward ----------------
         acc = self.accumulate
         for i, d in enumerate(self.dims):
@@ -285,24 +380,29 @@ class TrainEngine:
         self._region(allreduce, 'dec2')
         self._dx_gemm('dxhat', 'dec2', 'de2', 'd_e2')
         self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1)   # de2[0] <- dg2p
+        self._cast('de2')
         self._dw_gemm('de2', 'e1', 'dec1')
         self._region(allreduce, 'dec1')
         self._dx_gemm('de2', 'dec1', 'de1', 'd_e1')
         self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
+        self._cast('de1')
         self._dw_gemm('de1', 'comb', 'dec0')
         self._region(allreduce, 'dec0')
         self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
         nv.latent_bwd(lat)                                                      # dml, dsigma, losses
+        self._cast('dml')
         for i, d in enumerate(self.dims):
             nv.colsum(self.ws[i]['dml'], B, 2 * L, 2 * L, self.g[f'm{i}.head.b'], accumulate=acc)
         self._dw_gemm('dml', 'a2', 'head')
         self._region(allreduce, 'head')
         self._dx_gemm('dml', 'head', 'da2', 'd_a2')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
+        self._cast('da2')
         self._dw_gemm('da2', 'a1', 'enc1')
         self._region(allreduce, 'enc1')
         self._dx_gemm('da2', 'enc1', 'da1', 'd_a1')
         self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
+        self._cast('da1')
         self._dw_gemm('da1', 'x', 'enc0')
         self._region(allreduce, 'enc0')
         self.m.num_batches_tracked += 1
@@ -310,19 +410,42 @@ class TrainEngine:
     def optimizer_step(self):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step)."""
         nv.grad_sqnorm(self.grad, self.norm_partials, self.state)
-        nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.norm_partials, self.hyper,
-                     self.state)
+        self._launch('adam', lambda: nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq,
+                                                   self.norm_partials, self.hyper, self.state,
+                                                   self.wbf_flat if self.bf16 else None))
+        if self.bf16:
+            self.refresh_weights_bf16(transposes_only=True)
 
     def step(self, corr=None, Fblk=None, noise=None, allreduce=None):
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
         `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
         self.forward_backward(corr, Fblk, noise, allreduce)
         if allreduce is not None:
-            if hasattr(allreduce, 'finish'):
-                allreduce.finish()
-            else:
-                allreduce(self.grad)
+            fn = allreduce.finish if hasattr(allreduce, 'finish') else (lambda: allreduce(self.grad))
+            nv.record_callable(fn)
+            fn()
         self.optimizer_step()
+
+    # ---- recorded launch plan: one foreign call per launch, no descriptor rebuilding (host cost ~3 us/launch) ----
+    def make_plan(self, data, idx, n_rows, replace=False, allreduce=None):
+        """Record one full step (device sampler -> gather -> step) on static buffers and return the plan.
+        The recording step is a real step.  'diag' sampling: both modalities use the same index tensor."""
+        nv.begin_record()
+        try:
+            nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
+            self.load_batch(data, [idx, idx])
+            corr = None
+            if replace:
+                nv.corr_from_indices(idx, idx, self.corr)
+                corr = self.corr
+            self.step(corr, None, None, allreduce)
+        finally:
+            plan = nv.end_record()
+        return plan
+
+    def run_plan(self, plan):
+        nv.replay(plan)
+        self.m.num_batches_tracked += 1
 
     def read_losses(self):
         """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""

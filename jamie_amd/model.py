@@ -25,7 +25,8 @@ def identity(x):
 
 
 def _align4(n):
-    return (n + 3) // 4 * 4
+    # 8 elements: 32-byte boundaries for the fp32 views and 16-byte boundaries for the bf16 copy of the same layout
+    return (n + 7) // 8 * 8
 
 
 class ParamLayout:

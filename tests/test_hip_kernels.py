@@ -462,3 +462,70 @@ def test_sampler_without_replacement(nv):
     nv.sample_indices(idx3, 100, 0, True, state, 200)
     v = idx3.cpu().numpy()
     assert v.min() >= 0 and v.max() < 100 and len(set(v.tolist())) < 512
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 compute mode
+# ------------------------------------------------------------------------------------------------
+def _bf16(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('R,C,nslab', [(64, 64, 1), (100, 72, 2), (512, 2000, 1), (33, 200, 3)])
+def test_cast_transpose(nv, R, C, nslab):
+    g = torch.Generator().manual_seed(R + C)
+    src = torch.randn(nslab, R, C, generator=g)
+    s = dev(src)
+    dst = torch.zeros(R, C, dtype=torch.bfloat16, device='cuda')
+    dstT = torch.zeros(C, R, dtype=torch.bfloat16, device='cuda')
+    nv.cast_transpose([nv.cast_problem(s, dst, dstT, nslab=nslab, slab_stride=R * C)])
+    ref = src.sum(0).to(torch.bfloat16)
+    assert torch.equal(dst.cpu(), ref)
+    assert torch.equal(dstT.cpu(), ref.t())
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (512, 256, 128), (128, 72, 200), (40, 136, 24), (512, 64, 1000),
+                                   (130, 264, 264), (256, 1000, 512)])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 2, 3, 4])
+def test_gemm_bf16(nv, M, N, K, cfg):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias = _bf16(torch.randn(M, K, generator=g)), _bf16(torch.randn(N, K, generator=g)), torch.randn(N, generator=g)
+    out = torch.full((M, N), float('nan'), device='cuda')
+    A, W, bd = dev(a), dev(w), dev(bias)
+    nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N, bias=bd)], cfg)
+    ref = a.double() @ w.double().t() + bias.double()
+    close(out, ref, rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)     # exact bf16 products, fp32 accumulation
+
+
+def test_gemm_bf16_identity_asymmetric(nv):
+    n = 96
+    B = _bf16(torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)       # exactly representable
+    out = torch.zeros(n, n, device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(_bf16(torch.eye(n))), dev(B.t().contiguous()), out, n, n, n, n, n, n)])
+    assert torch.equal(out.cpu(), B.float())
+
+
+def test_gemm_bf16_splitk_grouped_mse(nv):
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 200, 48, 1000
+    a, w = _bf16(torch.randn(M, K, generator=g)), _bf16(torch.randn(N, K, generator=g))
+    a2, w2 = _bf16(torch.randn(64, 72, generator=g)), _bf16(torch.randn(136, 72, generator=g))
+    slabs = torch.full((3, M, N), float('nan'), device='cuda')
+    o2 = torch.zeros(64, 136, device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(a), dev(w), slabs, M, N, K, K, K, N, splitk=3, slab_stride=M * N),
+                  nv.gemm_problem(dev(a2), dev(w2), o2, 64, 136, 72, 72, 72, 136)])
+    close(slabs.sum(0), a.double() @ w.double().t(), rtol=1e-5, atol=2e-4)
+    close(o2, a2.double() @ w2.double().t(), rtol=1e-5, atol=1e-4)
+    import math
+    B, d, K = 100, 152, 80
+    e2, W, b, X = (_bf16(torch.randn(B, K, generator=g)), _bf16(torch.randn(d, K, generator=g)),
+                   torch.randn(d, generator=g), torch.randn(B, d, generator=g))
+    bm, bn = nv.gemm_bf16_tile(B, d)
+    part = torch.zeros(math.ceil(B / bm) * math.ceil(d / bn), device='cuda')
+    out = torch.zeros(B, d, device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(e2), dev(W), out, B, d, K, K, K, d, bias=dev(b), epi=nv.EPI_MSE,
+                                  aux=(dev(X), None, None, None), aux_ld=d, partial=part, scale=2.0 / (B * d),
+                                  pscale=1.0 / (B * d))])
+    diff = e2.double() @ W.double().t() + b.double() - X.double()
+    close(out, diff * 2.0 / (B * d), rtol=1e-5, atol=1e-7)
+    close(part.sum(), (diff ** 2).mean(), rtol=1e-5, atol=0)

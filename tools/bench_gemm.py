@@ -39,7 +39,7 @@ cases = [
 cfgs = [int(c) for c in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
 for name, layout, shapes in cases:
     for cfg in cfgs:
-        for sk in ((1, 2) if layout != nv.TN else (1,)):
+        for sk in ((1, 2, 4) if layout != nv.TN else (1,)):
             try:
                 ms, tf = run(layout, shapes, cfg, sk)
                 print(f'{name} cfg {cfg} splitk {sk}: {ms*1e3:8.1f} us  {tf:7.1f} TFLOP/s', flush=True)

@@ -1,0 +1,32 @@
+"""GPU microbenchmark: bf16 MFMA GEMM (NT, both operands K-contiguous) on the config-2 layer shapes, grouped."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from jamie_amd import _native as nv
+nv.require_gpu()
+B, d = 512, (2000, 1000)
+def T(*s): return torch.randn(*s, device='cuda').to(torch.bfloat16)
+def run(shapes, cfg, sk, iters=20):
+    probs, fl = [], 0
+    for (M, N, K) in shapes:
+        A, Bm = T(M, K), T(N, K)
+        Cm = torch.empty(sk, M, N, device='cuda')
+        probs.append(nv.gemm_problem(A, Bm, Cm, M, N, K, K, K, N, splitk=sk, slab_stride=M * N))
+        fl += 2.0 * M * N * K
+    for _ in range(3): nv.gemm_bf16(probs, cfg)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): nv.gemm_bf16(probs, cfg)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, fl / ms / 1e9
+cases = [('fwd d->2d ', [(B, 2 * x, x) for x in d]), ('fwd 2d->d ', [(B, x, 2 * x) for x in d]),
+         ('dW  2dxd  ', [(2 * x, x, B) for x in d]), ('dW  dx2d  ', [(x, 2 * x, B) for x in d]),
+         ('sq 4096   ', [(4096, 4096, 4096)])]
+for name, shapes in cases:
+    for cfg in (0, 1, 2, 3, 4):
+        for sk in (1, 2, 4):
+            if 'dW' in name and sk > 1: continue
+            ms, tf = run(shapes, cfg, sk)
+            print(f'{name} cfg {cfg} splitk {sk}: {ms*1e3:8.1f} us  {tf:7.1f} TFLOP/s', flush=True)
