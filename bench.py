@@ -60,7 +60,8 @@ def cpu_baseline(dims, L, B, budget_s=20.0):
     """The CPU oracle (plain-PyTorch restatement of the reference step, pinned to the reference by the
     golden fixtures) timed on this box's host cores: same dims, fp32, B = 512, default dropout."""
     from oracle import jamie_oracle as orc
-    threads = torch.get_num_threads()
+    threads = int(os.environ.get("JAMIE_CPU_THREADS", "0")) or min(torch.get_num_threads(), 64)
+    torch.set_num_threads(threads)
     torch.manual_seed(666)
     P, Bf = orc.init_state(dims, L)
     for v in P.values():
@@ -81,15 +82,31 @@ def cpu_baseline(dims, L, B, budget_s=20.0):
         noise = orc.draw_noise(dims, L, B, p)
         orc.train_step(P, Bf, opt, X, eye, zero, noise, p, 0.5)
     one()                                     # warm-up (first step dropped)
+    # the oracle scales poorly past a few dozen threads on many-core hosts (memory-bound elementwise ops and
+    # dropout masks): probe a few thread counts briefly and time the sample with the fastest, stated in `cores`
+    if not os.environ.get('JAMIE_CPU_THREADS'):
+        best = (0.0, threads)
+        for t in sorted({8, 16, 24, 32, 48, threads}):
+            if t > (os.cpu_count() or t):
+                continue
+            torch.set_num_threads(t)
+            one()
+            t0 = time.perf_counter()
+            one(); one()
+            rate = 2 * B / (time.perf_counter() - t0)
+            if rate > best[0]:
+                best = (rate, t)
+        threads = best[1]
+        torch.set_num_threads(threads)
     t0 = time.perf_counter()
     steps = 0
-    while steps < 40 and (time.perf_counter() - t0 < budget_s or steps < 3):
+    while steps < 60 and (time.perf_counter() - t0 < budget_s or steps < 3):
         one()
         steps += 1
     dt = time.perf_counter() - t0
     return {'value': B * steps / dt, 'unit': 'cells/s', 'cores': threads, 'kind': 'port',
             'sample': f'{steps} steps of B={B} at dims={tuple(dims)}, L={L}, N capped at {n}, fp32, '
-                      f'{dt:.1f} s on {threads} torch threads ({os.cpu_count()} logical CPUs)'}
+                      f'{dt:.1f} s on {threads} torch threads (fastest of the probed counts; {os.cpu_count()} logical CPUs)'}
 
 
 def main():
@@ -102,7 +119,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'],
                     help='GEMM operand type: bf16 (BASELINE config 2; fp32 accumulate/master) or f32 (parity config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--cpu-budget', type=float, default=15.0)
     args = ap.parse_args()
 
     from jamie_amd import distributed as jd

@@ -110,6 +110,8 @@ typedef struct {
     float* out;                                      /* [B,N] activation after dropout              */
     const uint8_t* mask;                             /* explicit 0/1 keep mask [B,N] or NULL (RNG)  */
     int B, N; int rng_stream;
+    void* out_bf16;                                  /* optional bf16 [B,N] copy of `out` (out may be NULL) */
+    void* outT_bf16;                                 /* optional bf16 transposed [N,B] copy (B <= 512, B % 8 == 0) */
 } jamie_bnact_fwd_problem;
 
 int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* problems /*host*/, int count, float p_drop,
@@ -122,6 +124,8 @@ typedef struct {
     float* dgamma; float* dbeta; float* dbias_lin;   /* [N] each; dbias_lin = colsum(dh) or NULL    */
     const uint8_t* mask;
     int B, N; int rng_stream; int accumulate;        /* accumulate: d{gamma,beta,bias} += */
+    void* dh_bf16; void* dhT_bf16;                   /* optional bf16 [B,N] / transposed [N,B] copies of dh */
+    int skip_f32;                                    /* 1: do not write the fp32 dh (bf16 copies only)     */
 } jamie_bnact_bwd_problem;
 
 int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* problems /*host*/, int count, float p_drop,
@@ -159,6 +163,10 @@ typedef struct {
     float* losses;                   /* out: device float[8]: KL, Rec, CosSim, F (weighted), total, running min(total) */
     int cosine;                      /* dist_method == 'cosine' (jamie.py:484-494)                    */
     int rng_stream;
+    /* optional external upstream gradients [B,L] (autograd seam: the caller computes its own losses on the
+       forward outputs, reference jamie.py:611-734); added to the internally derived ones; NULL = none.
+       An external d(combined) is passed as one more `dcomb` slab.                                     */
+    const float* dz_ext[2]; const float* dmu_ext[2]; const float* dlv_ext /* last modality's logvar */;
 } jamie_latent;
 
 int jamie_latent_fwd(const jamie_latent* a /*host*/, const uint64_t* rng, void* stream);

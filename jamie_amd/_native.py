@@ -42,7 +42,8 @@ class BnFwdProblem(C.Structure):
                 ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
                 ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p),
                 ('out', C.c_void_p), ('mask', C.c_void_p),
-                ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int)]
+                ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int),
+                ('out_bf16', C.c_void_p), ('outT_bf16', C.c_void_p)]
 
 
 class BnBwdProblem(C.Structure):
@@ -51,7 +52,8 @@ class BnBwdProblem(C.Structure):
                 ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p),
                 ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dbias_lin', C.c_void_p),
                 ('mask', C.c_void_p),
-                ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int), ('accumulate', C.c_int)]
+                ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int), ('accumulate', C.c_int),
+                ('dh_bf16', C.c_void_p), ('dhT_bf16', C.c_void_p), ('skip_f32', C.c_int)]
 
 
 class Latent(C.Structure):
@@ -66,7 +68,8 @@ class Latent(C.Structure):
                 ('H', C.c_void_p * 2), ('ch', C.c_void_p * 2), ('fte', C.c_void_p),
                 ('dml', C.c_void_p * 2), ('dsigma', C.c_void_p),
                 ('rec_partials', C.c_void_p), ('n_rec_partials', C.c_int), ('losses', C.c_void_p),
-                ('cosine', C.c_int), ('rng_stream', C.c_int)]
+                ('cosine', C.c_int), ('rng_stream', C.c_int),
+                ('dz_ext', C.c_void_p * 2), ('dmu_ext', C.c_void_p * 2), ('dlv_ext', C.c_void_p)]
 
 
 EXPORTS = {

@@ -23,6 +23,7 @@
 struct BnFwdDev {
     float* h; const float* gamma; const float* beta; float* rmean; float* rvar;
     float* smean; float* sinvstd; float* out; const uint8_t* mask;
+    unsigned short* out_bf; unsigned short* outT_bf;
     long long slab_stride;
     int nslab, B, N, rng_stream, blk_begin;
 };
@@ -31,8 +32,9 @@ struct BnFwdGroup { BnFwdDev p[JAMIE_MAX_GROUP]; int count; };
 struct BnBwdDev {
     float* da; const float* h; const float* gamma; const float* beta; const float* smean;
     const float* sinvstd; float* dgamma; float* dbeta; float* dbias; const uint8_t* mask;
+    unsigned short* dh_bf; unsigned short* dhT_bf;
     long long slab_stride;
-    int nslab, B, N, rng_stream, accumulate, blk_begin;
+    int nslab, B, N, rng_stream, accumulate, blk_begin, skip_f32;
 };
 struct BnBwdGroup { BnBwdDev p[JAMIE_MAX_GROUP]; int count; };
 
@@ -60,10 +62,41 @@ __device__ __forceinline__ Philox4 drop_rand(const uint64_t* rng, int stream, in
     return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)col << 24) | ((uint64_t)rp << 16) | (uint64_t)g);
 }
 
+// bf16 outputs of a cached strip (thread (c, rp) holds rows rp + 16 j of column c in val[j]):
+//   row-major  [B, N]: 2-byte stores (16 columns = 32-byte segments per row);
+//   transposed [N, B]: the strip is 16 whole rows of the transposed matrix; staged through LDS (row stride 514
+//   elements: conflict-free 2-byte writes) and written as 16-byte stores, 1 KiB contiguous per column.
+#define BN_TS 514
+__device__ __forceinline__ void strip_out_bf16(const float (&val)[BN_MAXR], unsigned short* out_bf, unsigned short* outT_bf,
+                                               unsigned short* tl, int B, int N, int col0, int c, int rp, bool cok) {
+    const int col = col0 + c;
+    if (out_bf && cok) {
+#pragma unroll
+        for (int j = 0; j < BN_MAXR; ++j) {
+            const int row = rp + j * BN_RP;
+            if (row < B) out_bf[(long long)row * N + col] = __builtin_bit_cast(unsigned short, (__bf16)val[j]);
+        }
+    }
+    if (!outT_bf) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BN_MAXR; ++j) tl[c * BN_TS + rp + j * BN_RP] = __builtin_bit_cast(unsigned short, (__bf16)val[j]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + 256 * i, cc = q >> 6, r8 = (q & 63) * 8;
+        if (col0 + cc < N && r8 < B) {        // B is a multiple of 8 in bf16 mode
+            const unsigned* sp = reinterpret_cast<const unsigned*>(tl + cc * BN_TS + r8);
+            *reinterpret_cast<uint4*>(outT_bf + (long long)(col0 + cc) * B + r8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    }
+}
+
 template <bool CACHED>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                          float slope, const uint64_t* rng) {
     __shared__ float sh[BN_RP][BN_CW + 1];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[CACHED ? BN_CW * BN_TS : 8];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
@@ -119,15 +152,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
     }
     const float var = col_reduce(sq, sh, rp, c) / (float)B;   // biased
     const float invstd = rsqrtf(var + eps);
-    if (!cok) return;
-    if (rp == 0) {
+    if (!CACHED && !cok) return;
+    if (cok && rp == 0) {
         P.smean[col] = mean;
         P.sinvstd[col] = invstd;
         const float unb = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
         P.rmean[col] = (1.f - momentum) * P.rmean[col] + momentum * mean;
         P.rvar[col] = (1.f - momentum) * P.rvar[col] + momentum * unb;
     }
-    const float ga = P.gamma[col], be = P.beta[col];
+    const float ga = cok ? P.gamma[col] : 0.f, be = cok ? P.beta[col] : 0.f;
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thr = jamie_drop_threshold(p_drop);
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
 #pragma unroll
             for (int j = 0; j < BN_MAXR; ++j) {
                 const int row = rp + j * BN_RP;
-                mk[j] = buf_u8(m_rs, row < B ? (unsigned)row * (unsigned)N + (unsigned)col : BN_OOB);
+                mk[j] = buf_u8(m_rs, (row < B && cok) ? (unsigned)row * (unsigned)N + (unsigned)col : BN_OOB);
             }
         }
         Philox4 r;
@@ -146,17 +179,23 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
         for (int j = 0; j < BN_MAXR; ++j) {
             const int row = rp + j * BN_RP;
             if (drop && !P.mask && (j & 3) == 0) r = drop_rand(rng, P.rng_stream, col, rp, j >> 2);
-            if (row < B) {
+            float y = 0.f;
+            if (row < B && cok) {
                 const long long o = (long long)row * N + col;
                 if (nslab > 1) P.h[o] = v[j];
-                float y = (v[j] - mean) * invstd * ga + be;
+                y = (v[j] - mean) * invstd * ga + be;
                 y = y > 0.f ? y : slope * y;
                 if (drop) {
                     const bool keep = P.mask ? (mk[j] != 0) : (r.v[j & 3] >= thr);
                     y = keep ? y * keep_scale : 0.f;
                 }
-                P.out[o] = y;
+                if (P.out) P.out[o] = y;
             }
+            v[j] = y;
+        }
+        if constexpr (CACHED) {
+            if (P.out_bf || P.outT_bf)
+                strip_out_bf16(v, P.out_bf, P.outT_bf, tl, B, N, ((int)blockIdx.x - P.blk_begin) * BN_CW, c, rp, cok);
         }
     } else {
         for (int row = rp; row < B; row += BN_RP) {
@@ -174,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
                 else keep = drop_rand(rng, P.rng_stream, col, rp, j >> 2).v[j & 3] >= thr;
                 y = keep ? y * keep_scale : 0.f;
             }
-            P.out[o] = y;
+            if (P.out) P.out[o] = y;
         }
     }
 }
@@ -183,6 +222,7 @@ template <bool CACHED>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_drop, float slope,
                                                          const uint64_t* rng) {
     __shared__ float sh[BN_RP][BN_CW + 1];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[CACHED ? BN_CW * BN_TS : 8];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
@@ -282,11 +322,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
 #pragma unroll
         for (int j = 0; j < BN_MAXR; ++j) {
             const int row = rp + j * BN_RP;
+            float dh = 0.f;
             if (cok && row < B) {
-                const float dh = gi * (dyv[j] - k1 - xnv[j] * k2);
-                P.da[(long long)row * N + col] = dh;
+                dh = gi * (dyv[j] - k1 - xnv[j] * k2);
+                if (!P.skip_f32) P.da[(long long)row * N + col] = dh;
                 s3 += dh;
             }
+            dyv[j] = dh;
+        }
+        if constexpr (CACHED) {
+            if (P.dh_bf || P.dhT_bf)
+                strip_out_bf16(dyv, P.dh_bf, P.dhT_bf, tl, B, N, ((int)blockIdx.x - P.blk_begin) * BN_CW, c, rp, cok);
         }
     } else {
         if (cok)
@@ -323,7 +369,7 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     bool need_rng = false;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_fwd_problem& s = pr[i];
-        JAMIE_ARG(s.h && s.gamma && s.beta && s.running_mean && s.running_var && s.save_mean && s.save_invstd && s.out,
+        JAMIE_ARG(s.h && s.gamma && s.beta && s.running_mean && s.running_var && s.save_mean && s.save_invstd,
                   "null pointer");
         JAMIE_ARG(s.B >= 1 && s.N >= 1 && s.nslab >= 1, "B, N, nslab >= 1");
         JAMIE_ARG(s.nslab == 1 || s.slab_stride >= (long long)s.B * s.N, "slab_stride too small");
@@ -332,6 +378,10 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
         BnFwdDev& d = g.p[i];
         d.h = s.h; d.gamma = s.gamma; d.beta = s.beta; d.rmean = s.running_mean; d.rvar = s.running_var;
         d.smean = s.save_mean; d.sinvstd = s.save_invstd; d.out = s.out; d.mask = s.mask;
+        d.out_bf = (unsigned short*)s.out_bf16; d.outT_bf = (unsigned short*)s.outT_bf16;
+        JAMIE_ARG((!s.out_bf16 && !s.outT_bf16) || (s.B <= BN_MAXR * BN_RP && s.B % 8 == 0),
+                  "fused bf16 outputs need B <= 512 and B % 8 == 0");
+        JAMIE_ARG(s.out || s.out_bf16 || s.outT_bf16, "no output requested");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.blk_begin = blocks;
         blocks += (s.N + BN_CW - 1) / BN_CW;
@@ -367,6 +417,10 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
         BnBwdDev& d = g.p[i];
         d.da = s.da; d.h = s.h; d.gamma = s.gamma; d.beta = s.beta; d.smean = s.save_mean;
         d.sinvstd = s.save_invstd; d.dgamma = s.dgamma; d.dbeta = s.dbeta; d.dbias = s.dbias_lin; d.mask = s.mask;
+        d.dh_bf = (unsigned short*)s.dh_bf16; d.dhT_bf = (unsigned short*)s.dhT_bf16; d.skip_f32 = s.skip_f32;
+        JAMIE_ARG((!s.dh_bf16 && !s.dhT_bf16) || (s.B <= BN_MAXR * BN_RP && s.B % 8 == 0),
+                  "fused bf16 outputs need B <= 512 and B % 8 == 0");
+        JAMIE_ARG(!s.skip_f32 || s.dh_bf16 || s.dhT_bf16, "skip_f32 without a bf16 output");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.accumulate = s.accumulate; d.blk_begin = blocks;
         blocks += (s.N + BN_CW - 1) / BN_CW;

@@ -234,7 +234,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-static const int BT[5][2] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
+static const int BT[7][2] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {128, 128}, {64, 64}, {128, 64}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
@@ -269,13 +269,15 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         case 2: return launch_b<128, 64, 64, 2, 2>(pr, count, st);
         case 3: return launch_b<64, 128, 64, 2, 2>(pr, count, st);
         case 4: return launch_b<128, 128, 32, 2, 2>(pr, count, st);
+        case 5: return launch_b<64, 64, 128, 2, 2>(pr, count, st);
+        case 6: return launch_b<128, 64, 128, 2, 2>(pr, count, st);
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
 }
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n);
-    if (cfg > 4 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
+    if (cfg > 6 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
     *bm = BT[cfg][0]; *bn = BT[cfg][1];
     return 0;
 }

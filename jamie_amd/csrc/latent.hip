@@ -24,6 +24,7 @@ struct LatDev {
     float* H[2]; float* ch[2]; float* fte; float* dml[2]; float* dsigma;
     const float* rec_partials; int n_rec_partials; float* losses;
     int cosine; int rng_stream;
+    const float* dz_ext[2]; const float* dmu_ext[2]; const float* dlv_ext;
 };
 
 static LatDev to_dev(const jamie_latent* a) {
@@ -43,6 +44,8 @@ static LatDev to_dev(const jamie_latent* a) {
     d.fte = a->fte; d.dsigma = a->dsigma;
     d.rec_partials = a->rec_partials; d.n_rec_partials = a->n_rec_partials; d.losses = a->losses;
     d.cosine = a->cosine; d.rng_stream = a->rng_stream;
+    for (int i = 0; i < 2; ++i) { d.dz_ext[i] = a->dz_ext[i]; d.dmu_ext[i] = a->dmu_ext[i]; }
+    d.dlv_ext = a->dlv_ext;
     return d;
 }
 
@@ -261,11 +264,13 @@ __global__ __launch_bounds__(256) void latent_bwd_b_kernel(LatDev a) {
         for (int i = 0; i < 2; ++i) {
             float gz, gc;
             align_grads(a, i, e, b, l, w_al, invBL, gz, gc);
-            const float dz = s[i] * (a.H[i][e] + a.ch[i][e]) + gz;
+            // external upstream gradients (autograd seam: the caller's own losses on z / mu / logvar_last)
+            const float dz = s[i] * (a.H[i][e] + a.ch[i][e]) + gz + (a.dz_ext[i] ? a.dz_ext[i][e] : 0.f);
             const float lv = a.lv[i][e];
-            const float dmu = dz + kl_scale * a.mu[i][e] * invBL;
+            const float dmu = dz + kl_scale * a.mu[i][e] * invBL + (a.dmu_ext[i] ? a.dmu_ext[i][e] : 0.f);
             float dlv = dz * a.eps[i][e] * 0.5f * expf(0.5f * lv);
             if (i == 1 && b < 2) dlv += kl_scale * (-0.5f) * (1.f - expf(lv)) / (float)L;
+            if (i == 1 && a.dlv_ext) dlv += a.dlv_ext[e];
             a.dml[i][(long long)b * 2 * L + l] = dmu;
             a.dml[i][(long long)b * 2 * L + L + l] = dlv;
         }

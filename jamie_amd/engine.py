@@ -50,6 +50,8 @@ class TrainEngine:
             raise ValueError("compute_dtype must be 'f32' or 'bf16'")
         self.bf16 = compute_dtype == 'bf16'
         self.compute_dtype = compute_dtype
+        # BN kernels emit the bf16 / transposed copies themselves when the strip is register-resident (B <= 512)
+        self.fuse_bf16 = self.bf16 and int(batch_size) <= 512
         self.m = model
         self.dev = model.device
         self.B = B = int(batch_size)
@@ -110,7 +112,8 @@ class TrainEngine:
             w['dxhat'] = torch.empty(B, d, **f32)
             w['de2'] = torch.empty(sk['d_e2'], B, 2 * d, **f32)
             w['de1'] = torch.empty(sk['d_e1'], B, d, **f32)
-            w['dcomb'] = torch.empty(sk['d_comb'], B, L, **f32)
+            w['dcomb'] = torch.empty(sk['d_comb'] + 1, B, L, **f32)   # +1 slab: external d(combined) (autograd seam)
+            w['xhat'] = None                                           # allocated on first forward_only()
             w['dml'] = torch.empty(B, 2 * L, **f32)
             w['da2'] = torch.empty(1, B, d, **f32)
             w['da1'] = torch.empty(sk['d_a1'], B, 2 * d, **f32)
@@ -200,7 +203,7 @@ class TrainEngine:
 
     def _cast(self, key):
         """fp32 activation / gradient `key` ([B, n] or slab 0 of [S, B, n]) -> bf16 [B, n] and bf16 [n, B]."""
-        if not self.bf16:
+        if not self.bf16 or (self.fuse_bf16 and key in ('a1', 'a2', 'e1', 'e2', 'de2', 'de1', 'da2', 'da1')):
             return
         probs = []
         for w in self.ws:
@@ -227,6 +230,8 @@ class TrainEngine:
             pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
             pr.out, pr.mask = nv.ptr(w[out_key]), nv.ptr(self._mask(noise, kind, i, j))
             pr.B, pr.N, pr.rng_stream = self.B, h.shape[2], stream_base + 8 * i
+            if self.fuse_bf16:      # bf16 + transposed bf16 copies straight from the strip; no fp32 activation
+                pr.out, pr.out_bf16, pr.outT_bf16 = None, nv.ptr(w[out_key + '_bf']), nv.ptr(w[out_key + '_T'])
             probs.append(pr)
         nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE)
 
@@ -243,6 +248,8 @@ class TrainEngine:
             pr.dbias_lin = nv.ptr(self.g[f'm{i}.{lin}.b'])
             pr.mask = nv.ptr(self._mask(noise, kind, i, j))
             pr.B, pr.N, pr.rng_stream, pr.accumulate = self.B, h.shape[2], stream_base + 8 * i, int(self.accumulate)
+            if self.fuse_bf16:
+                pr.dh_bf16, pr.dhT_bf16, pr.skip_f32 = nv.ptr(w[da_key + '_bf']), nv.ptr(w[da_key + '_T']), 1
             probs.append(pr)
         nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE)
 
@@ -311,7 +318,7 @@ class TrainEngine:
         d.sigma, d.corr, d.Fblk, d.hyper = nv.ptr(self.m.p['sigma']), nv.ptr(corr), nv.ptr(Fblk), nv.ptr(self.hyper)
         d.rsum, d.qsum, d.fc1, d.fte = nv.ptr(self.rsum), nv.ptr(self.qsum), nv.ptr(self.fc1), nv.ptr(self.fte)
         d.partials = nv.ptr(self.lat_partials)
-        d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['dcomb'].shape[0], B * L
+        d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
         d.dsigma = nv.ptr(self.g['sigma'])
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses = nv.ptr(self.losses)
@@ -342,6 +349,36 @@ class TrainEngine:
     def forward_backward(self, corr=None, Fblk=None, noise=None, allreduce=None):
         """Forward, losses and backward for the batch already in the workspace.  `corr` None = identity,
         `Fblk` None = 0; `noise` (explicit masks / eps, for parity tests) None = Philox streams."""
+        lat = self._forward(corr, Fblk, noise, True)
+        self._backward(lat, noise, allreduce)
+
+    def forward_only(self, corr=None, noise=None):
+        """Train-mode forward without losses (autograd seam): fills z, comb, mu, lv, xhat; returns the latent
+        descriptor to hand to `backward_external`."""
+        return self._forward(corr, None, noise, False)
+
+    def backward_external(self, lat, dz, dcomb, dxhat, dmu, dlv_last, noise=None):
+        """Backward from caller-supplied gradients of the forward outputs (lists per modality; None = zero)."""
+        B, L = self.B, self.L
+        keep = []
+        for i in range(2):
+            w = self.ws[i]
+            w['dxhat'].copy_(dxhat[i]) if dxhat[i] is not None else w['dxhat'].zero_()
+            ext = w['dcomb'][w['sk']['d_comb']]
+            ext.copy_(dcomb[i]) if dcomb[i] is not None else ext.zero_()
+            for name, src in (('dz_ext', dz[i]), ('dmu_ext', dmu[i])):
+                t = None if src is None else src.contiguous()
+                keep.append(t)
+                getattr(lat, name)[i] = nv.ptr(t)
+        t = None if dlv_last is None else dlv_last.contiguous()
+        keep.append(t)
+        lat.dlv_ext = nv.ptr(t)
+        lat.dcomb_nslab = self.ws[0]['sk']['d_comb'] + 1
+        self._cast('dxhat')
+        self._backward(lat, noise, None)
+        return keep
+
+    def _forward(self, corr, Fblk, noise, fused_losses):
         B, L = self.B, self.L
         # ---------------- forward ----------------
         self._fwd_gemm('x', 'enc0', 'h1', 'enc0')
@@ -360,6 +397,12 @@ class TrainEngine:
         self._fwd_gemm('e1', 'dec1', 'g2', 'dec1')
         self._bn_fwd('bn3', 'g2', 'e2', 13, noise, 'dec_masks', 1)
         self._cast('e2')
+        if not fused_losses:                                              # plain x_hat (autograd seam)
+            for w, d in zip(self.ws, self.dims):
+                if w['xhat'] is None:
+                    w['xhat'] = torch.empty(1, B, d, device=self.dev, dtype=torch.float32)
+            self._fwd_gemm('e2', 'dec2', 'xhat', 'dec0')
+            return lat
         probs, off = [], 0
         for i, d in enumerate(self.dims):                                 # x_hat GEMM + fused MSE
             w, P = self.ws[i], self.m.p
@@ -372,7 +415,10 @@ class TrainEngine:
             off += self.rec_tiles[i]
         self._launch('enc_gemm', (lambda: nv.gemm_bf16(probs)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
         self._cast('dxhat')
-        # ---------------- backward ----------------
+        return lat
+
+    def _backward(self, lat, noise, allreduce):
+        B, L = self.B, self.L
         acc = self.accumulate
         for i, d in enumerate(self.dims):
             nv.colsum(self.ws[i]['dxhat'], B, d, d, self.g[f'm{i}.dec2.b'], accumulate=acc)

@@ -464,3 +464,67 @@ def test_plan_replay_equals_eager_steps(jam, mode):
         assert int(eng.state[1].item()) == 6 and model.num_batches_tracked == 6
         flats.append(model.flat.clone())
     assert torch.equal(flats[0], flats[1])
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_facade_device_sampler_plan_path(jam, mode):
+    """sampler='device' + identity P takes the recorded-plan fast path; bf16 compute through the facade."""
+    import io
+    import contextlib
+    rng = np.random.default_rng(4)
+    N, dims = 600, (72, 40)
+    Z = rng.standard_normal((N, 5))
+    data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
+    with contextlib.redirect_stdout(io.StringIO()):
+        jm = jam.JAMIE(output_dim=8, batch_size=64, epoch_DNN=25, min_epochs=10, pca_dim=None, use_f_tilde=False,
+                       log_DNN=10 ** 9, sampler='device', compute_dtype=mode)
+        emb = jm.fit_transform(dataset=data)
+    assert jm.engine.compute_dtype == mode and int(jm.engine.state[1].item()) == 25 * (N // 64)
+    assert len(jm.loss_history['Rec']) == 25 and jm.loss_history['Rec'][-1] < jm.loss_history['Rec'][0]
+    assert np.isfinite(emb[0]).all() and jm.test_closer(emb) < 0.35
+
+
+def test_autograd_model_class_seam_matches_oracle(jam):
+    """The reference's own seam: a `model_class` whose train-mode forward returns autograd tensors, with the
+    losses formed OUTSIDE by torch ops (here the oracle's restatement of jamie.py:618-668 on GPU tensors),
+    `.backward()`, `clip_grad_norm_` and `torch.optim.Adam` on `model.parameters()` — dropout 0 so that the only
+    noise is eps; compare one step's losses and gradients with the CPU oracle given the same eps."""
+    from jamie_amd.compat import edModelVarTorch
+    dims, L, B = (48, 40), 8, 64
+    torch.manual_seed(2)
+    model = edModelVarTorch(dims, L, dropout=0.0)
+    torch.manual_seed(2)
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(5)
+    X = [torch.randn(B, d, generator=g) for d in dims]
+    idx = torch.randint(0, 40, (B,), generator=g)
+    corr = orc.p_block(None, idx.numpy(), idx.numpy())
+    Fblk = torch.zeros(B, B)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    zs, comb, xhat, mus, lv = model(*[x.cuda() for x in X], corr=corr.cuda())
+    eps = [model._engines[B].ws[i]['eps'].cpu().clone() for i in range(2)]     # the Philox draw of this forward
+    ls = orc.losses([x.cuda() for x in X], zs, comb, xhat, mus, lv, Fblk.cuda(), 0.7)
+    sum(ls).backward()
+    noise = {'enc_masks': [(None, None)] * 2, 'dec_masks': [(None, None)] * 2, 'eps': eps}
+    st = orc.train_step(P, Bf, None, X, corr, Fblk, noise, 0., 0.7, do_step=False, return_grads=True)
+    np.testing.assert_allclose([float(l.detach()) for l in ls], st['losses'], rtol=2e-4, atol=1e-6)
+    views = model.inner.layout.views(model.flat.grad)
+    for ref, (mine, sl) in model.inner.layout.reference_names().items():
+        if orc.is_dead_bias(ref):
+            continue
+        got = (views[mine] if sl is None else views[mine][sl]).cpu().numpy()
+        want = st['grads'][ref].numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-5 * max(1e-6, float(np.abs(want).max())) + 1e-7,
+                                   err_msg=ref)
+    before = model.flat.detach().clone()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
+    opt.step()
+    opt.zero_grad()
+    assert not torch.equal(before, model.flat.detach())
+    assert torch.equal(model.inner.flat, model.flat.detach())        # the kernels see the optimiser's update
+    model.eval()
+    out = model(*[x.cuda() for x in X], corr=corr.cuda())
+    assert out[0][0].shape == (B, L) and torch.equal(out[0][0], out[3][0])   # eval: zs == mus

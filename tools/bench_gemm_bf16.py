@@ -6,26 +6,30 @@ from jamie_amd import _native as nv
 nv.require_gpu()
 B, d = 512, (2000, 1000)
 def T(*s): return torch.randn(*s, device='cuda').to(torch.bfloat16)
-def run(shapes, cfg, sk, iters=20):
-    probs, fl = [], 0
-    for (M, N, K) in shapes:
-        A, Bm = T(M, K), T(N, K)
-        Cm = torch.empty(sk, M, N, device='cuda')
-        probs.append(nv.gemm_problem(A, Bm, Cm, M, N, K, K, K, N, splitk=sk, slab_stride=M * N))
-        fl += 2.0 * M * N * K
-    for _ in range(3): nv.gemm_bf16(probs, cfg)
+NBUF = int(os.environ.get('NBUF', '1'))     # > 1: rotate through distinct operand sets (cold L2 / Infinity Cache)
+def run(shapes, cfg, sk, iters=24):
+    sets, fl = [], 0
+    for b in range(NBUF):
+        probs = []
+        for (M, N, K) in shapes:
+            A, Bm = T(M, K), T(N, K)
+            Cm = torch.empty(sk, M, N, device='cuda')
+            probs.append(nv.gemm_problem(A, Bm, Cm, M, N, K, K, K, N, splitk=sk, slab_stride=M * N))
+        sets.append(probs)
+    fl = sum(2.0 * M * N * K for (M, N, K) in shapes)
+    for i in range(3): nv.gemm_bf16(sets[i % NBUF], cfg)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): nv.gemm_bf16(probs, cfg)
+    for i in range(iters): nv.gemm_bf16(sets[i % NBUF], cfg)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms, fl / ms / 1e9
 cases = [('fwd d->2d ', [(B, 2 * x, x) for x in d]), ('fwd 2d->d ', [(B, x, 2 * x) for x in d]),
          ('dW  2dxd  ', [(2 * x, x, B) for x in d]), ('dW  dx2d  ', [(x, 2 * x, B) for x in d]),
-         ('sq 4096   ', [(4096, 4096, 4096)])]
+         ('dX  2d->d ', [(B, x, 2 * x) for x in d])]
 for name, shapes in cases:
-    for cfg in (0, 1, 2, 3, 4):
+    for cfg in (1, 2, 3, 5, 6):
         for sk in (1, 2, 4):
             if 'dW' in name and sk > 1: continue
             ms, tf = run(shapes, cfg, sk)

@@ -9,7 +9,8 @@ tag, name = sys.argv[1], sys.argv[2]          # e.g. prof3 r01_c2_f32_v3
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', tag)
 dst = os.path.join(root, 'profiles')
-KERNEL = 'gemm_f32_kernel<64, 64, 32, 2, 2, true, true, true, 1>'
+bench = json.load(open(os.path.join(src, 'bench.json')))
+KERNEL = 'gemm_f32_kernel<64, 64, 32, 2, 2, true, true, true, 1>' if bench['dtype'] == 'f32' else 'clip_adam_kernel'
 def avg_counter(d, counter):
     f = glob.glob(os.path.join(src, d, '*', '*_counter_collection.csv'))[0]
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
@@ -19,13 +20,12 @@ st = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(st)))
 with open(os.path.join(dst, name + '_kernel_stats.csv'), 'w') as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-bench = json.load(open(os.path.join(src, 'bench.json')))
 fetch, n1 = avg_counter('pmc_fetch', 'FETCH_SIZE')
 write, n2 = avg_counter('pmc_write', 'WRITE_SIZE')
 hbm = (2 * fetch + write) * 1024
 tr_path = os.path.join(dst, 'traffic.json')
 tr = json.load(open(tr_path)) if os.path.exists(tr_path) else {}
-cfg = bench['config']['workload'].split(':')[0]
+cfg = bench['config']['workload'].split(':')[0] + '_' + bench['dtype']
 tr[cfg] = {'kernel': KERNEL, 'hbm_bytes_per_launch': hbm, 'fetch_size_kib_raw': fetch, 'write_size_kib_raw': write,
            'launches_averaged': [n1, n2], 'correction': 'FETCH_SIZE x2 (gfx950), KiB -> bytes', 'source': name}
 json.dump(tr, open(tr_path, 'w'), indent=1)
@@ -34,7 +34,7 @@ json.dump(bench, open(os.path.join(dst, name + '_bench.json'), 'w'), indent=1)
 k = [r for r in rows if KERNEL in r['Name']]
 print('bench ms/step', bench['ms_per_step'], 'cells/s', bench['value'])
 print('rocprof avg us for kernel:', float(k[0]['AverageNs']) / 1e3 if k else None, 'bench avg_launch_ms', bench['roofline']['avg_launch_ms'])
-print('traffic bytes/launch', hbm, 'algorithmic weight bytes', 4 * sum(2 * d * d for d in bench['config']['features']))
+print('traffic bytes/launch', hbm, 'algorithmic bytes/launch', bench['roofline'].get('bytes_per_launch', 4 * sum(2 * d * d for d in bench['config']['features'])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:14]:
     print(f"{r['Name'][:86]:86s} {r['Calls']:>5s} {float(r['AverageNs'])/1e3:8.1f}us {float(r['Percentage']):6.2f}%")
