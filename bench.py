@@ -182,8 +182,10 @@ def main():
         #         4*B*sum(d^2) FLOP) against the exact-fp32 MFMA peak;
         #   bf16: the step is HBM-bound on optimiser traffic; the dominant kernel is clip+Adam:
         #         28 bytes per parameter (read p, g, m, v; write p, m, v) against the HBM peak.
-        gemm_ms = eng.kernel_timing_ms('enc_gemm')
-        adam_ms = eng.kernel_timing_ms('adam')
+        timing_detail = {'enc_gemm': eng.kernel_timing_ms('enc_gemm', 'all'), 'adam': eng.kernel_timing_ms('adam', 'all')}
+        # event pairs bracket one launch each; a host hiccup between the two records (GC, scheduler) shows up as a
+        # multi-millisecond outlier in a handful of the samples, so the per-launch duration is the MEDIAN
+        gemm_ms, adam_ms = timing_detail['enc_gemm']['median'], timing_detail['adam']['median']
         gemm_flop = 4.0 * B * sum(d * d for d in dims)
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -221,6 +223,7 @@ def main():
                        'parallelism': f'dp{world}', 'parameters': model.num_parameters(),
                        'flop_per_cell': flops_per_cell(dims, L)},
             'roofline': roof,
+            'kernel_event_timing_ms': timing_detail,
             'final_loss': total,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -32,7 +32,11 @@ struct GemmBGroup { GemmBDev p[JAMIE_MAX_GROUP]; int count; };
 
 #define JB_OOB 0xFFFFFFF0u
 
-template <int BM, int BN, int BK, int WM, int WN, int TAG>
+// D = register prefetch depth: the global loads of tiles kt+1 .. kt+D are in flight while tile kt is multiplied.  With
+// a 64x64x64 tile a k-step is only 128 MFMA cycles per wave, far less than one HBM round trip, so D = 1 pays one
+// memory latency per k-step; D = 3 divides that by three (counted vmcnt waits come from the compiler: the loads are
+// builtins in program order).
+template <int BM, int BN, int BK, int WM, int WN, int TAG, int D>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -99,27 +103,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
         b_lds[j] = row * LDB + c * 16;
     }
 
-    u32x4 ra[LA], rb[LB];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            const bool ok = a_off[j] != JB_OOB && k0 + a_k[j] < kend;
-            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, ok ? (int)(a_off[j] + (unsigned)k0 * 2u) : (int)JB_OOB, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < LB; ++j) {
-            const bool ok = b_off[j] != JB_OOB && k0 + b_k[j] < kend;
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, ok ? (int)(b_off[j] + (unsigned)k0 * 2u) : (int)JB_OOB, 0, 0);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* As = smem + buf * (A_SZ + B_SZ);
-        unsigned char* Bs = As + A_SZ;
-#pragma unroll
-        for (int j = 0; j < LA; ++j) *reinterpret_cast<u32x4*>(As + a_lds[j]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < LB; ++j) *reinterpret_cast<u32x4*>(Bs + b_lds[j]) = rb[j];
-    };
+    u32x4 ra[D][LA], rb[D][LB];
+#define JB_LOAD(ST, K0)                                                                                              \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < LA; ++j) {                                                              \
+            const bool ok = a_off[j] != JB_OOB && (K0) + a_k[j] < kend;                                               \
+            ra[ST][j] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, ok ? (int)(a_off[j] + (unsigned)(K0) * 2u) : (int)JB_OOB, 0, 0); \
+        }                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < LB; ++j) {                                                              \
+            const bool ok = b_off[j] != JB_OOB && (K0) + b_k[j] < kend;                                               \
+            rb[ST][j] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, ok ? (int)(b_off[j] + (unsigned)(K0) * 2u) : (int)JB_OOB, 0, 0); \
+        }                                                                                                             \
+    }
+#define JB_STORE(ST, BUF)                                                                                            \
+    {                                                                                                                 \
+        unsigned char* As_ = smem + (BUF) * (A_SZ + B_SZ);                                                            \
+        unsigned char* Bs_ = As_ + A_SZ;                                                                              \
+        _Pragma("unroll") for (int j = 0; j < LA; ++j) *reinterpret_cast<u32x4*>(As_ + a_lds[j]) = ra[ST][j];        \
+        _Pragma("unroll") for (int j = 0; j < LB; ++j) *reinterpret_cast<u32x4*>(Bs_ + b_lds[j]) = rb[ST][j];        \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -129,42 +131,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (nk > 0) {
-        load_tile(kbeg);
-        store_tile(0);
-    }
+    // prologue: tiles 0 .. D-1 in flight; tile 0 to LDS
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < nk) JB_LOAD(u, kbeg + u * BK)
+    if (nk > 0) JB_STORE(0, 0)
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kbeg + (kt + 1) * BK);
-        const unsigned char* As = smem + cur * (A_SZ + B_SZ);
-        const unsigned char* Bs = As + A_SZ;
-        bf16x8 af[2][TM], bf[2][TN];
-        auto read_frags = [&](int buf, int s) {
+    for (int kt0 = 0; kt0 < nk; kt0 += D) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[buf][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * LDB + s * 32 + h * 16);
+        for (int u = 0; u < D; ++u) {
+            const int kt = kt0 + u;
+            if (kt < nk) {
+                const int cur = kt & 1;
+                // register stage u held tile kt (already in LDS): refill it with tile kt + D
+                if (kt + D < nk) JB_LOAD(u, kbeg + (kt + D) * BK)
+                const unsigned char* As = smem + cur * (A_SZ + B_SZ);
+                const unsigned char* Bs = As + A_SZ;
+                bf16x8 af[2][TM], bf[2][TN];
+                auto read_frags = [&](int buf, int s) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[buf][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * LDB + s * 32 + h * 16);
-        };
-        read_frags(0, 0);
+                    for (int i = 0; i < TM; ++i)
+                        af[buf][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * LDB + s * 32 + h * 16);
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < TN; ++j)
+                        bf[buf][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * LDB + s * 32 + h * 16);
+                };
+                read_frags(0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int s = 0; s < BK / 16; ++s) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) JB_STORE((u + 1) % D, cur ^ 1)     // tile kt+1 lives in register stage (u+1) % D
+                __syncthreads();
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
     }
+#undef JB_LOAD
+#undef JB_STORE
 
     // ---- epilogue (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
     float* Cout = P.C + (long long)ks * P.slab_stride;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int D>
 static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     GemmBGroup g;
     memset(&g, 0, sizeof(g));
@@ -228,13 +239,13 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     }
     if (tiles == 0) return 0;
     if (big)
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WM, WN, 1>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WM, WN, 1, D>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WM, WN, 0>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WM, WN, 0, D>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-static const int BT[7][2] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {128, 128}, {64, 64}, {128, 64}};
+static const int BT[7][2] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {64, 64}, {64, 64}, {64, 64}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
@@ -264,13 +275,13 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
     hipStream_t st = (hipStream_t)stream;
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n);
     switch (cfg) {
-        case 0: return launch_b<128, 128, 64, 2, 2>(pr, count, st);
-        case 1: return launch_b<64, 64, 64, 2, 2>(pr, count, st);
-        case 2: return launch_b<128, 64, 64, 2, 2>(pr, count, st);
-        case 3: return launch_b<64, 128, 64, 2, 2>(pr, count, st);
-        case 4: return launch_b<128, 128, 32, 2, 2>(pr, count, st);
-        case 5: return launch_b<64, 64, 128, 2, 2>(pr, count, st);
-        case 6: return launch_b<128, 64, 128, 2, 2>(pr, count, st);
+        case 0: return launch_b<128, 128, 64, 2, 2, 2>(pr, count, st);
+        case 1: return launch_b<64, 64, 64, 2, 2, 3>(pr, count, st);
+        case 2: return launch_b<128, 64, 64, 2, 2, 2>(pr, count, st);
+        case 3: return launch_b<64, 128, 64, 2, 2, 2>(pr, count, st);
+        case 4: return launch_b<64, 64, 64, 2, 2, 1>(pr, count, st);
+        case 5: return launch_b<64, 64, 64, 2, 2, 2>(pr, count, st);
+        case 6: return launch_b<64, 64, 64, 2, 2, 4>(pr, count, st);
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
 }

@@ -180,12 +180,15 @@ class TrainEngine:
         fn()
         self._ev(label, 1)
 
-    def kernel_timing_ms(self, label):
+    def kernel_timing_ms(self, label, stat='mean'):
         if self._timing is None or not self._timing.get(label):
             return None
         torch.cuda.synchronize()
-        t = [a.elapsed_time(b) for a, b in self._timing[label] if b is not None]
-        return float(np.mean(t))
+        t = np.array([a.elapsed_time(b) for a, b in self._timing[label] if b is not None])
+        if stat == 'all':
+            return {'mean': float(t.mean()), 'median': float(np.median(t)), 'p90': float(np.percentile(t, 90)),
+                    'max': float(t.max()), 'n': int(t.size)}
+        return float(t.mean())
 
     # ---- bf16 compute mode: bf16 / bf16-transposed copies of GEMM operands ----
     def refresh_weights_bf16(self, transposes_only=False):
