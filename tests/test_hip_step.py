@@ -528,3 +528,59 @@ def test_autograd_model_class_seam_matches_oracle(jam):
     model.eval()
     out = model(*[x.cuda() for x in X], corr=corr.cuda())
     assert out[0][0].shape == (B, L) and torch.equal(out[0][0], out[3][0])   # eval: zs == mus
+
+
+def _quiet(fn):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn()
+
+
+def test_facade_dense_F_pf_ratio_loss_weights_and_replacement(jam):
+    """Facade paths that need B x B blocks: dense F (`match_result`) mixed with P through PF_Ratio, loss weights,
+    and duplicate indices (min(features) < batch_size -> replace=True, non-identity corr)."""
+    rng = np.random.default_rng(11)
+    N, dims = 96, (24, 20)
+    Z = rng.standard_normal((N, 4))
+    data = [Z @ rng.standard_normal((4, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
+    Fm = np.abs(rng.standard_normal((N, N))) * (rng.random((N, N)) < .2)
+    np.random.seed(1)
+    jm = jam.JAMIE(output_dim=4, batch_size=32, epoch_DNN=15, min_epochs=6, pca_dim=None, use_f_tilde=True,
+                   match_result=[Fm], PF_Ratio=.5, loss_weights=[1, 2, 3, 4], log_DNN=10 ** 9)
+    emb = _quiet(lambda: jm.fit_transform(dataset=data))
+    assert jm.sampling_method == 'diag' and emb[0].shape == (N, 4) and np.isfinite(emb[1]).all()
+    assert len(jm.loss_history['F']) == 15 and all(np.isfinite(v).all() for v in jm.loss_history.values())
+    assert jm.loss_history['F'][-1] > 0          # F != 0: the F loss is live
+    # identity P given densely is recognised (no hybrid sampling), and an explicit dense P = I equals P = None
+    np.random.seed(1)
+    jm2 = jam.JAMIE(output_dim=4, batch_size=32, epoch_DNN=3, min_epochs=6, pca_dim=None, use_f_tilde=False,
+                    log_DNN=10 ** 9)
+    _quiet(lambda: jm2.fit_transform(dataset=data, P=np.eye(N)))
+    assert jm2.sampling_method == 'diag'
+    with pytest.raises(NotImplementedError):
+        P = np.eye(N); P[0, 0] = 0; P[0, 1] = 1
+        _quiet(lambda: jam.JAMIE(output_dim=4, batch_size=32, epoch_DNN=1, pca_dim=None, use_f_tilde=False
+                                 ).fit_transform(dataset=data, P=P))
+    with pytest.raises(NotImplementedError):
+        jam.JAMIE(output_dim=4).fit_transform(dataset=data)          # use_f_tilde=True without match_result
+
+
+def test_facade_unequal_rows_zeros_sampler_and_small_n(jam):
+    """Unequal row counts -> P = 0 -> 'zeros' sampler with corr = 0; N < batch_size -> batch_size = N
+    (reference jamie.py:511-514); PCA preprocessing (`pca_dim`) with the global scaler."""
+    rng = np.random.default_rng(12)
+    data = [rng.standard_normal((40, 24)), rng.standard_normal((56, 20))]
+    np.random.seed(2)
+    jm = jam.JAMIE(output_dim=4, batch_size=16, epoch_DNN=4, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9)
+    emb = _quiet(lambda: jm.fit_transform(dataset=data))
+    assert jm.sampling_method == 'zeros' and emb[0].shape == (40, 4) and emb[1].shape == (56, 4)
+    assert jm.loss_history['CosSim'][-1] == pytest.approx(0.0, abs=1e-6)      # corr = 0 -> comb = z
+    data2 = [rng.standard_normal((50, 30)), rng.standard_normal((50, 26))]
+    np.random.seed(3)
+    jm = jam.JAMIE(output_dim=4, batch_size=512, epoch_DNN=3, pca_dim=[8, None], use_f_tilde=False, log_DNN=10 ** 9)
+    emb = _quiet(lambda: jm.fit_transform(dataset=data2))
+    assert jm.batch_size == 50 and jm.model.input_dim == [8, 26] and emb[0].shape == (50, 4)
+    imp = jm.modal_predict(data2[1], 1)            # back through the PCA inverse of modality 0
+    assert imp.shape == (50, 30) and np.isfinite(imp).all()
+    assert jm.transform(data2)[0].shape == (50, 4)
