@@ -428,12 +428,13 @@ def test_corr_from_indices(nv):
 
 
 def test_colsum(nv):
-    X = torch.randn(3, 130, 50)
+    X = torch.randn(3, 130, 50, generator=torch.Generator().manual_seed(8))
+    Xd = dev(X)
     out = torch.zeros(50, device='cuda')
-    nv.colsum(dev(X), 130, 50, 50, out, nslab=3, slab_stride=130 * 50)
-    close(out, X.double().sum((0, 1)), 1e-5, 1e-5)
-    nv.colsum(dev(X), 130, 50, 50, out, nslab=3, slab_stride=130 * 50, accumulate=True)
-    close(out, 2 * X.double().sum((0, 1)), 1e-5, 1e-5)
+    nv.colsum(Xd, 130, 50, 50, out, nslab=3, slab_stride=130 * 50)
+    close(out, X.double().sum((0, 1)), 1e-5, 1e-4)           # 390 fp32 terms per column
+    nv.colsum(Xd, 130, 50, 50, out, nslab=3, slab_stride=130 * 50, accumulate=True)
+    close(out, 2 * X.double().sum((0, 1)), 1e-5, 2e-4)
 
 
 def test_sampler_without_replacement(nv):
