@@ -191,8 +191,16 @@ class JAMIE:
                     P_dense - torch.eye(self.row[0], device=dev)).sum() == 0:
                 method, P_dense = 'diag', None
             elif torch.abs(P_dense).sum() != 0:
-                raise NotImplementedError("partial correspondence ('hybrid' sampling, reference jamie.py:523-579) "
-                                          'is the next scope row (SURVEY.md §8(f) rank 2)')
+                # partial correspondence (reference jamie.py:523-530), CORRECTED: the reference sets
+                # `num_corr = len(corr_samples[0])` (== 2, the pair width) and indexes `corr_samples[i]` (the i-th
+                # pair) per modality, so it never samples the known pairs as intended; here num_corr is the number
+                # of known pairs and column i of the pair list feeds modality i.
+                if world > 1:
+                    raise NotImplementedError('hybrid sampling with a dense P is single-process')
+                method = 'hybrid'
+                self.corr_samples = np.argwhere(np.asarray(self.P) > 0)
+                self.num_corr = len(self.corr_samples)
+                self.true_ratio = .8                                          # jamie.py:529
             else:
                 method = 'zeros'
         self.sampling_method = method
@@ -253,7 +261,14 @@ class JAMIE:
                         eng.run_plan(plan)
                     continue
                 # ---- sampler (jamie.py:552-583) ----
-                if self.sampler == 'numpy':
+                if method == 'hybrid':                                         # jamie.py:559-573 (corrected)
+                    corr_sample_num = int(min(np.sum(np.random.rand(B) < self.true_ratio), self.num_corr))
+                    pairs = self.corr_samples[np.random.choice(self.num_corr, corr_sample_num, replace=rep)]
+                    for i in range(2):
+                        rest = np.random.choice(rows[i], B - corr_sample_num, replace=rep)
+                        s = np.concatenate([pairs[:, i], rest], axis=0)
+                        idx_dev[i].copy_(torch.from_numpy(s.astype(np.int32)))
+                elif self.sampler == 'numpy':
                     if method == 'diag':
                         s = np.random.choice(range(rows[0]), B, replace=rep)
                         idx_dev[0].copy_(torch.from_numpy(s.astype(np.int32)))

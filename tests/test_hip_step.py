@@ -584,3 +584,24 @@ def test_facade_unequal_rows_zeros_sampler_and_small_n(jam):
     imp = jm.modal_predict(data2[1], 1)            # back through the PCA inverse of modality 0
     assert imp.shape == (50, 30) and np.isfinite(imp).all()
     assert jm.transform(data2)[0].shape == (50, 4)
+
+
+def test_facade_partial_correspondence_hybrid_sampler(jam):
+    """Partially matched cells (the reference's headline use case): P knows the first half of the pairs.  The
+    corrected 'hybrid' sampler draws ~80 % of each batch from the known pairs; alignment of the UNKNOWN half must
+    still improve over an untrained model (shared latent structure)."""
+    rng = np.random.default_rng(21)
+    N, dims = 256, (40, 32)
+    Z = rng.standard_normal((N, 4))
+    data = [Z @ rng.standard_normal((4, d)) + .05 * rng.standard_normal((N, d)) for d in dims]
+    P = np.zeros((N, N))
+    P[np.arange(N // 2), np.arange(N // 2)] = 1
+    np.random.seed(5)
+    jm = jam.JAMIE(output_dim=4, batch_size=64, epoch_DNN=60, min_epochs=20, pca_dim=None, use_f_tilde=False,
+                   log_DNN=10 ** 9)
+    emb = _quiet(lambda: jm.fit_transform(dataset=data, P=P))
+    assert jm.sampling_method == 'hybrid' and jm.num_corr == N // 2
+    assert np.isfinite(emb[0]).all() and len(jm.loss_history['CosSim']) == 60
+    known = _quiet(lambda: jm.test_closer([e[:N // 2] for e in emb]))
+    unknown = _quiet(lambda: jm.test_closer([e[N // 2:] for e in emb]))
+    assert known < 0.25 and unknown < 0.45
