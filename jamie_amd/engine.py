@@ -306,6 +306,27 @@ class TrainEngine:
         else:
             nv.gemm(probs, nv.TN)
 
+    def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key):
+        """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
+        K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch."""
+        if not self.bf16:
+            self._dw_gemm(dy_key, a_key, lin)
+            self._dx_gemm(dy_key, lin, out_key, sk_key)
+            return
+        probs = []
+        for i, d in enumerate(self.dims):
+            w = self.ws[i]
+            dW = self.g[f'm{i}.{lin}.W']
+            nout, nin = dW.shape
+            probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
+                                         accumulate=self.accumulate))
+        for i, d in enumerate(self.dims):
+            w = self.ws[i]
+            nout, nin = self.g[f'm{i}.{lin}.W'].shape
+            probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
+                                         nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+        nv.gemm_bf16(probs)
+
     def _latent_desc(self, corr, Fblk, noise):
         B, L = self.B, self.L
         d = nv.Latent()
@@ -425,31 +446,26 @@ class TrainEngine:
         acc = self.accumulate
         for i, d in enumerate(self.dims):
             nv.colsum(self.ws[i]['dxhat'], B, d, d, self.g[f'm{i}.dec2.b'], accumulate=acc)
-        self._dw_gemm('dxhat', 'e2', 'dec2')
+        self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
         self._region(allreduce, 'dec2')
-        self._dx_gemm('dxhat', 'dec2', 'de2', 'd_e2')
         self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1)   # de2[0] <- dg2p
         self._cast('de2')
-        self._dw_gemm('de2', 'e1', 'dec1')
+        self._bwd_gemms('de2', 'dec1', 'e1', 'de1', 'd_e1')
         self._region(allreduce, 'dec1')
-        self._dx_gemm('de2', 'dec1', 'de1', 'd_e1')
         self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
         self._cast('de1')
-        self._dw_gemm('de1', 'comb', 'dec0')
+        self._bwd_gemms('de1', 'dec0', 'comb', 'dcomb', 'd_comb')
         self._region(allreduce, 'dec0')
-        self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
         nv.latent_bwd(lat)                                                      # dml, dsigma, losses
         self._cast('dml')
         for i, d in enumerate(self.dims):
             nv.colsum(self.ws[i]['dml'], B, 2 * L, 2 * L, self.g[f'm{i}.head.b'], accumulate=acc)
-        self._dw_gemm('dml', 'a2', 'head')
+        self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
         self._region(allreduce, 'head')
-        self._dx_gemm('dml', 'head', 'da2', 'd_a2')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
         self._cast('da2')
-        self._dw_gemm('da2', 'a1', 'enc1')
+        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1')
         self._region(allreduce, 'enc1')
-        self._dx_gemm('da2', 'enc1', 'da1', 'd_a1')
         self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
         self._cast('da1')
         self._dw_gemm('da1', 'x', 'enc0')

@@ -558,10 +558,10 @@ def test_facade_dense_F_pf_ratio_loss_weights_and_replacement(jam):
                     log_DNN=10 ** 9)
     _quiet(lambda: jm2.fit_transform(dataset=data, P=np.eye(N)))
     assert jm2.sampling_method == 'diag'
-    with pytest.raises(NotImplementedError):
-        P = np.eye(N); P[0, 0] = 0; P[0, 1] = 1
-        _quiet(lambda: jam.JAMIE(output_dim=4, batch_size=32, epoch_DNN=1, pca_dim=None, use_f_tilde=False
-                                 ).fit_transform(dataset=data, P=P))
+    P = np.eye(N); P[0, 0] = 0; P[0, 1] = 1                 # not the identity any more -> partial correspondence
+    jm3 = jam.JAMIE(output_dim=4, batch_size=32, epoch_DNN=1, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9)
+    _quiet(lambda: jm3.fit_transform(dataset=data, P=P))
+    assert jm3.sampling_method == 'hybrid'
     with pytest.raises(NotImplementedError):
         jam.JAMIE(output_dim=4).fit_transform(dataset=data)          # use_f_tilde=True without match_result
 
