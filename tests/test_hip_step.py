@@ -605,3 +605,56 @@ def test_facade_partial_correspondence_hybrid_sampler(jam):
     known = _quiet(lambda: jm.test_closer([e[:N // 2] for e in emb]))
     unknown = _quiet(lambda: jm.test_closer([e[N // 2:] for e in emb]))
     assert known < 0.25 and unknown < 0.45
+
+
+def test_full_size_config2_step_vs_oracle(jam):
+    """BASELINE config 2 at its full per-step size (B = 512, 2000 + 1000 features, latent 32, 40.3 M parameters,
+    default dropout 0.6): ONE fp32 step against the CPU oracle with identical explicit noise — losses, every
+    gradient tensor (relative L2), the clip norm and the post-step weights; then size-independent properties of
+    the same engine: the gradient-norm partials reproduce ||g||, the bias gradients of BN-fed Linears are ~0
+    (column sums of a BatchNorm backward), and the BN running statistics follow the momentum rule."""
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    B, dims, L, p = 512, (2000, 1000), 32, 0.6
+    torch.manual_seed(666)
+    model = edModelVar(dims, L)
+    assert model.dropout == p and model.num_parameters() == 40345130
+    torch.manual_seed(666)
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    eng = TrainEngine(model, B)
+    opt = orc.Adam(P.values(), 1e-3)
+    rng = np.random.default_rng(0)
+    Z = rng.standard_normal((B, 16)).astype(np.float32)
+    X = [torch.from_numpy(Z @ rng.standard_normal((16, d)).astype(np.float32)
+                          + .1 * rng.standard_normal((B, d)).astype(np.float32)) for d in dims]
+    X = [(x - x.mean(0)) / x.std(0) for x in X]
+    torch.manual_seed(42)
+    noise = orc.draw_noise(dims, L, B, p)
+    st = orc.train_step(P, Bf, opt, X, torch.eye(B), torch.zeros(B, B), noise, p, 0.5, return_grads=True)
+    eng.set_batch([x.cuda() for x in X])
+    eng.set_kl_anneal(0.5)
+    eng.forward_backward(None, None, _noise_to_dev(noise, p))
+    ls, total, _ = eng.read_losses()
+    np.testing.assert_allclose(ls, st['losses'], rtol=2e-4, atol=1e-6)
+    for ref, (mine, sl) in model.layout.reference_names().items():
+        got = (eng.g[mine] if sl is None else eng.g[mine][sl]).cpu().numpy()
+        if orc.is_dead_bias(ref):
+            assert np.abs(got).max() < 1e-4, ref                      # column sums of a BN backward
+            continue
+        assert_mostly_close(got, st['grads'][ref].numpy(), rtol=0, atol=0, max_bad_frac=1.0, rel_l2=2e-3, msg=ref)
+    gnorm_ref = float(torch.sqrt(sum((g.double() ** 2).sum() for g in st['grads'].values())))
+    eng.optimizer_step()
+    assert abs(float(torch.sqrt(eng.norm_partials.double().sum())) - gnorm_ref) < 1e-4 * gnorm_ref
+    assert abs(float(eng.grad.double().norm()) - gnorm_ref) < 1e-4 * gnorm_ref
+    sd = model.state_dict()
+    for k, v in P.items():
+        if orc.is_dead_bias(k):
+            continue
+        assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=2e-4,
+                            rel_l2=1e-4, msg=k)
+    for k, v in Bf.items():
+        if 'num_batches' in k:
+            continue
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
