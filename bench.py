@@ -135,6 +135,8 @@ def main():
 
     n_cells, dims, L = CONFIGS[args.config]
     B = args.batch
+    if args.dtype == 'bf16' and any(v % 8 for v in list(dims) + [L, B]):
+        args.dtype = 'f32'          # bf16 operands need multiples of 8 (config 1 has 100 features): fp32 path
     lo, hi = jd.shard_bounds(n_cells, rank, world)
     data = synth_shard(hi - lo, dims, 1000 + rank, dev)
     torch.manual_seed(666)

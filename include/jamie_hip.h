@@ -201,6 +201,9 @@ int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1, int B, flo
 /* out[n] (+)= sum_m X[m,n]  (bias gradients of the non-BN Linear layers) */
 int jamie_colsum(const float* X, int M, int N, int ld, int nslab, long long slab_stride, float* out,
                  int accumulate, void* stream);
+typedef struct { const float* X; float* out; int M, N, ld, nslab; long long slab_stride; int accumulate; } jamie_colsum_problem;
+/* the same for up to JAMIE_MAX_GROUP matrices in one launch (the modalities) */
+int jamie_colsum_group(const jamie_colsum_problem* problems /*host*/, int count, void* stream);
 
 #ifdef __cplusplus
 }

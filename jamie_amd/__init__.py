@@ -18,6 +18,9 @@ def __getattr__(name):
     if name in ('edModelVar', 'ParamLayout'):
         from . import model
         return getattr(model, name)
+    if name in ('edModelVarTorch',):
+        from .compat import edModelVarTorch
+        return edModelVarTorch
     if name in ('TrainEngine',):
         from .engine import TrainEngine
         return TrainEngine

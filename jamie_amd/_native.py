@@ -36,6 +36,11 @@ class CastProblem(C.Structure):
                 ('nslab', C.c_int), ('slab_stride', C.c_longlong)]
 
 
+class ColsumProblem(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('out', C.c_void_p), ('M', C.c_int), ('N', C.c_int), ('ld', C.c_int),
+                ('nslab', C.c_int), ('slab_stride', C.c_longlong), ('accumulate', C.c_int)]
+
+
 class BnFwdProblem(C.Structure):
     _fields_ = [('h', C.c_void_p), ('nslab', C.c_int), ('slab_stride', C.c_longlong),
                 ('gamma', C.c_void_p), ('beta', C.c_void_p),
@@ -97,6 +102,7 @@ EXPORTS = {
     'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
                                        C.c_int, C.c_void_p]),
     'jamie_corr_from_indices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_colsum_group': (C.c_int, [C.POINTER(ColsumProblem), C.c_int, C.c_void_p]),
     'jamie_colsum': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p,
                                C.c_int, C.c_void_p]),
 }
@@ -295,6 +301,17 @@ def sample_indices(idx, N, offset, replace, rng, rng_stream):
 
 def corr_from_indices(idx0, idx1, corr):
     _call('jamie_corr_from_indices', ptr(idx0), ptr(idx1), idx0.numel(), ptr(corr), _stream())
+
+
+def colsum_group(items, accumulate=False):
+    """items: list of (X [M, N] contiguous fp32, out [N]) - one launch for all (bias gradients of both modalities)."""
+    probs = []
+    for X, out in items:
+        p = ColsumProblem()
+        p.X, p.out, p.M, p.N, p.ld, p.nslab, p.slab_stride, p.accumulate = ptr(X), ptr(out), X.shape[0], X.shape[1], X.shape[1], 1, 0, int(accumulate)
+        probs.append(p)
+    arr = (ColsumProblem * len(probs))(*probs)
+    _call('jamie_colsum_group', arr, len(probs), _stream())
 
 
 def colsum(X, M, N, ld, out, nslab=1, slab_stride=0, accumulate=False):

@@ -157,30 +157,54 @@ extern "C" int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1,
     return jamie_launch_status("jamie_corr_from_indices");
 }
 
-// ---- out[n] (+)= sum_m sum_slabs X[m,n]: 16 columns x 16 row phases per workgroup ----
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ld, int nslab,
-                                                     long long slab_stride, float* out, int accumulate) {
+// ---- out[n] (+)= sum_m sum_slabs X[m,n]: 16 columns x 16 row phases per workgroup; up to 4 matrices per launch ----
+struct ColsumDev { const float* X; float* out; long long slab_stride; int M, N, ld, nslab, accumulate, blk_begin; };
+struct ColsumGroup { ColsumDev p[JAMIE_MAX_GROUP]; int count; };
+
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumGroup g) {
     __shared__ float sh[16][17];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
+    const ColsumDev& P = g.p[pi];
     const int c = threadIdx.x & 15, rp = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + c;
+    const int col = ((int)blockIdx.x - P.blk_begin) * 16 + c;
     float acc = 0.f;
-    if (col < N)
-        for (int s = 0; s < nslab; ++s)
-            for (int m = rp; m < M; m += 16) acc += X[s * slab_stride + (long long)m * ld + col];
+    if (col < P.N)
+        for (int s = 0; s < P.nslab; ++s)
+            for (int m = rp; m < P.M; m += 16) acc += P.X[s * P.slab_stride + (long long)m * P.ld + col];
     sh[rp][c] = acc;
     __syncthreads();
-    if (rp == 0 && col < N) {
+    if (rp == 0 && col < P.N) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += sh[i][c];
-        out[col] = accumulate ? out[col] + t : t;
+        P.out[col] = P.accumulate ? P.out[col] + t : t;
     }
+}
+
+extern "C" int jamie_colsum_group(const jamie_colsum_problem* pr, int count, void* stream) {
+    JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
+    ColsumGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const jamie_colsum_problem& s = pr[i];
+        JAMIE_ARG(s.X && s.out && s.M > 0 && s.N > 0 && s.ld >= s.N && s.nslab >= 1, "null pointer / empty");
+        ColsumDev& d = g.p[i];
+        d.X = s.X; d.out = s.out; d.slab_stride = s.slab_stride; d.M = s.M; d.N = s.N; d.ld = s.ld; d.nslab = s.nslab;
+        d.accumulate = s.accumulate; d.blk_begin = blocks;
+        blocks += (s.N + 15) / 16;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return jamie_launch_status("jamie_colsum_group");
 }
 
 extern "C" int jamie_colsum(const float* X, int M, int N, int ld, int nslab, long long slab_stride, float* out,
                             int accumulate, void* stream) {
-    JAMIE_ARG(X && out && M > 0 && N > 0 && ld >= N && nslab >= 1, "null pointer / empty");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, X, M, N, ld, nslab,
-                       slab_stride, out, accumulate);
-    return jamie_launch_status("jamie_colsum");
+    jamie_colsum_problem p;
+    p.X = X; p.out = out; p.M = M; p.N = N; p.ld = ld; p.nslab = nslab; p.slab_stride = slab_stride; p.accumulate = accumulate;
+    return jamie_colsum_group(&p, 1, stream);
 }

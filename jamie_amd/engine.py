@@ -444,8 +444,7 @@ class TrainEngine:
     def _backward(self, lat, noise, allreduce):
         B, L = self.B, self.L
         acc = self.accumulate
-        for i, d in enumerate(self.dims):
-            nv.colsum(self.ws[i]['dxhat'], B, d, d, self.g[f'm{i}.dec2.b'], accumulate=acc)
+        nv.colsum_group([(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
         self._region(allreduce, 'dec2')
         self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1)   # de2[0] <- dg2p
@@ -458,8 +457,7 @@ class TrainEngine:
         self._region(allreduce, 'dec0')
         nv.latent_bwd(lat)                                                      # dml, dsigma, losses
         self._cast('dml')
-        for i, d in enumerate(self.dims):
-            nv.colsum(self.ws[i]['dml'], B, 2 * L, 2 * L, self.g[f'm{i}.head.b'], accumulate=acc)
+        nv.colsum_group([(self.ws[i]['dml'], self.g[f'm{i}.head.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
         self._region(allreduce, 'head')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
