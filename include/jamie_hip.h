@@ -172,6 +172,26 @@ typedef struct {
 int jamie_latent_fwd(const jamie_latent* a /*host*/, const uint64_t* rng, void* stream);
 int jamie_latent_bwd(const jamie_latent* a /*host*/, void* stream);
 
+/* M-modality latent block (2 <= M <= 4) for fully paired cells: identity correspondence, F = 0, euclidean alignment.
+ * The reference supports two modalities only (jamie.py:420, model.py:251-256); this is the build-defined
+ * generalisation of SURVEY.md §8 row A14 (comb = sum_j sigma_j z_j / sum_j sigma_j; KL rows 0..M-1 of the last
+ * modality's logvar).  For M = 2 it equals jamie_latent_* at corr = NULL.  Pointer arrays are indexed by modality. */
+typedef struct {
+    int B, L, M;
+    const float* ml[4]; int ml_nslab; long long ml_slab_stride;
+    const float* head_bias[4]; const float* eps_in[4];
+    const float* sigma; const float* hyper;
+    float* mu[4]; float* lv[4]; float* z[4]; float* eps[4];
+    float* comb;                     /* [B,L]: identical for every modality                              */
+    float* partials;                 /* fp32 scratch, >= jamie_max_partials() * 17                       */
+    const float* dcomb[4]; int dcomb_nslab; long long dcomb_slab_stride;
+    float* dml[4]; float* dsigma;    /* dsigma [M]                                                        */
+    const float* rec_partials; int n_rec_partials; float* losses;
+    int rng_stream;
+} jamie_latent_m;
+int jamie_latent_m_fwd(const jamie_latent_m* a /*host*/, const uint64_t* rng, void* stream);
+int jamie_latent_m_bwd(const jamie_latent_m* a /*host*/, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Optimiser: global-norm clip + Adam on one flat fp32 buffer
  * (clip_grad_norm_(params, 1) + optim.Adam.step + zero_grad, jamie.py:739-741).

@@ -77,6 +77,19 @@ class Latent(C.Structure):
                 ('dz_ext', C.c_void_p * 2), ('dmu_ext', C.c_void_p * 2), ('dlv_ext', C.c_void_p)]
 
 
+class LatentM(C.Structure):
+    _fields_ = [('B', C.c_int), ('L', C.c_int), ('M', C.c_int),
+                ('ml', C.c_void_p * 4), ('ml_nslab', C.c_int), ('ml_slab_stride', C.c_longlong),
+                ('head_bias', C.c_void_p * 4), ('eps_in', C.c_void_p * 4),
+                ('sigma', C.c_void_p), ('hyper', C.c_void_p),
+                ('mu', C.c_void_p * 4), ('lv', C.c_void_p * 4), ('z', C.c_void_p * 4), ('eps', C.c_void_p * 4),
+                ('comb', C.c_void_p), ('partials', C.c_void_p),
+                ('dcomb', C.c_void_p * 4), ('dcomb_nslab', C.c_int), ('dcomb_slab_stride', C.c_longlong),
+                ('dml', C.c_void_p * 4), ('dsigma', C.c_void_p),
+                ('rec_partials', C.c_void_p), ('n_rec_partials', C.c_int), ('losses', C.c_void_p),
+                ('rng_stream', C.c_int)]
+
+
 EXPORTS = {
     'jamie_last_error': (C.c_char_p, []),
     'jamie_version': (C.c_int, []),
@@ -93,6 +106,8 @@ EXPORTS = {
                                    C.c_void_p]),
     'jamie_latent_fwd': (C.c_int, [C.POINTER(Latent), C.c_void_p, C.c_void_p]),
     'jamie_latent_bwd': (C.c_int, [C.POINTER(Latent), C.c_void_p]),
+    'jamie_latent_m_fwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
+    'jamie_latent_m_bwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p]),
     'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
     'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
@@ -271,11 +286,11 @@ def bn_act_bwd(problems, p_drop, rng, slope=0.01):
 
 
 def latent_fwd(desc, rng):
-    _call('jamie_latent_fwd', C.pointer(desc), ptr(rng), _stream())
+    _call('jamie_latent_m_fwd' if isinstance(desc, LatentM) else 'jamie_latent_fwd', C.pointer(desc), ptr(rng), _stream())
 
 
 def latent_bwd(desc):
-    _call('jamie_latent_bwd', C.pointer(desc), _stream())
+    _call('jamie_latent_m_bwd' if isinstance(desc, LatentM) else 'jamie_latent_bwd', C.pointer(desc), _stream())
 
 
 def optim_blocks(n):

@@ -365,3 +365,207 @@ extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
     hipLaunchKernelGGL(latent_bwd_b_kernel, dim3(nblk), dim3(256), 0, st, d);
     return jamie_launch_status("jamie_latent_bwd");
 }
+
+// =================================================================================================
+// M-modality latent block (M <= JAMIE_MAX_GROUP) for fully paired cells: identity correspondence, F = 0.
+// The reference is hard-wired to two modalities (`assert len(W) == 2`, jamie.py:420; `(i + 1) % 2`,
+// model.py:251-256), so this is the BUILD-DEFINED generalisation proposed in SURVEY.md §8 row A14:
+//     comb     = sum_j sigma_j z_j / sum_j sigma_j                     (the same for every modality)
+//     KL       = sum_i -1/2 [ mean_l(1 + lv_last[i,l] - exp(lv_last[i,l])) - mean_{b,l} mu_i^2 ]   (rows i < M)
+//     CosSim   = 32 * sum_i mean_b ||z_i[b] - comb[b]||^2 / L
+//     F        = mean(comb^2)
+// For M = 2 it coincides with the two-modality kernels above at corr = I (tested).  No oracle in the reference:
+// parity for M = 3 is pinned only against the generalised CPU oracle's autograd.
+// =================================================================================================
+#define LM 4
+enum { SM_MU2 = 0, SM_TROW = 4, SM_AL = 8, SM_F = 12, SM_DSIG = 13, SM_SLOTS = 17 };
+
+struct LatMDev {
+    int B, L, M;
+    const float* ml[LM]; int ml_nslab; long long ml_slab_stride;
+    const float* head_bias[LM]; const float* eps_in[LM];
+    const float* sigma; const float* hyper;
+    float* mu[LM]; float* lv[LM]; float* z[LM]; float* eps[LM]; float* comb;
+    float* partials;
+    const float* dcomb[LM]; int dcomb_nslab; long long dcomb_slab_stride;
+    float* dml[LM]; float* dsigma;
+    const float* rec_partials; int n_rec_partials; float* losses;
+    int rng_stream;
+};
+
+__device__ __forceinline__ void put_partial_m(const LatMDev& a, int slot, float v, float* red) {
+    const float t = block_sum(v, red);
+    if (threadIdx.x == 0) a.partials[slot * JAMIE_MAX_PARTIALS + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void latent_m_fwd_kernel(LatMDev a, const uint64_t* rng) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, M = a.M, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = e < n;
+    const int b = ok ? e / L : 0, l = ok ? e % L : 0;
+    float mu2[LM] = {0.f, 0.f, 0.f, 0.f}, trow[LM] = {0.f, 0.f, 0.f, 0.f}, zz[LM] = {0.f, 0.f, 0.f, 0.f};
+    float num = 0.f, S = 0.f;
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        if (i >= M || !ok) continue;
+        float mu = a.head_bias[i][l], lv = a.head_bias[i][L + l];
+        for (int s = 0; s < a.ml_nslab; ++s) {
+            const float* p = a.ml[i] + s * a.ml_slab_stride + (long long)b * 2 * L;
+            mu += p[l];
+            lv += p[L + l];
+        }
+        float ep;
+        if (a.eps_in[i]) {
+            ep = a.eps_in[i][e];
+        } else {
+            Philox4 r = jamie_rand4(rng, (uint32_t)(a.rng_stream + i), (uint64_t)e);
+            float n1;
+            jamie_box_muller(r.v[0], r.v[1], ep, n1);
+        }
+        const float z = mu + ep * (expf(0.5f * lv) + 1e-7f);
+        a.mu[i][e] = mu; a.lv[i][e] = lv; a.eps[i][e] = ep; a.z[i][e] = z;
+        zz[i] = z;
+        mu2[i] = mu * mu;
+        if (i == M - 1 && b < M) trow[b] = 1.f + lv - expf(lv);
+        const float sg = a.sigma[i];
+        num += sg * z;
+        S += sg;
+    }
+    const float comb = ok ? num / S : 0.f;
+    if (ok) a.comb[e] = comb;
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        if (i >= M) continue;            // uniform
+        put_partial_m(a, SM_MU2 + i, mu2[i], red);
+        put_partial_m(a, SM_TROW + i, trow[i], red);
+        put_partial_m(a, SM_AL + i, ok ? (zz[i] - comb) * (zz[i] - comb) : 0.f, red);
+    }
+    put_partial_m(a, SM_F, comb * comb, red);
+}
+
+__global__ __launch_bounds__(256) void latent_m_bwd_kernel(LatMDev a) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, M = a.M, n = B * L;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = e < n;
+    const float invBL = 1.f / (float)n;
+    const float kl_scale = a.hyper[0], w_al = a.hyper[2], w_f = a.hyper[3];
+    float ds[LM] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const int b = e / L, l = e % L;
+        const float comb = a.comb[e];
+        float S = 0.f, G = w_f * 2.f * comb * invBL;         // F loss acts on combined[0]
+        float ga[LM], zz[LM];
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            if (i >= M) continue;
+            S += a.sigma[i];
+            zz[i] = a.z[i][e];
+            ga[i] = w_al * 2.f * (zz[i] - comb) * invBL;      // d CosSim / d z_i ;  -ga[i] is d / d comb_i
+            G -= ga[i];
+            for (int s = 0; s < a.dcomb_nslab; ++s) G += a.dcomb[i][e + s * a.dcomb_slab_stride];
+        }
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            if (i >= M) continue;
+            const float dz = a.sigma[i] / S * G + ga[i];
+            const float lv = a.lv[i][e];
+            const float dmu = dz + kl_scale * a.mu[i][e] * invBL;
+            float dlv = dz * a.eps[i][e] * 0.5f * expf(0.5f * lv);
+            if (i == M - 1 && b < M) dlv += kl_scale * (-0.5f) * (1.f - expf(lv)) / (float)L;
+            a.dml[i][(long long)b * 2 * L + l] = dmu;
+            a.dml[i][(long long)b * 2 * L + L + l] = dlv;
+            ds[i] = G * (zz[i] - comb) / S;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        if (i >= M) continue;
+        put_partial_m(a, SM_DSIG + i, ds[i], red);
+    }
+    // the last block to finish cannot be known without a counter; block 0 of a SECOND tiny launch finalises
+}
+
+__global__ __launch_bounds__(256) void latent_m_final_kernel(LatMDev a) {
+    __shared__ float red[4];
+    const int B = a.B, L = a.L, M = a.M, n = B * L;
+    const int nblk = (n + 255) / 256;
+    const float invBL = 1.f / (float)n;
+    float tot[SM_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SM_SLOTS; ++sl) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += 256) v += a.partials[sl * JAMIE_MAX_PARTIALS + i];
+        tot[sl] = block_sum(v, red);
+    }
+    float rec = 0.f;
+    for (int i = threadIdx.x; i < a.n_rec_partials; i += 256) rec += a.rec_partials[i];
+    rec = block_sum(rec, red);
+    if (threadIdx.x == 0) {
+        const float kl_scale = a.hyper[0], w_rec = a.hyper[1], w_al = a.hyper[2], w_f = a.hyper[3];
+        float kl = 0.f, al = 0.f;
+        for (int i = 0; i < M; ++i) {
+            kl += -0.5f * (tot[SM_TROW + i] / (float)L - tot[SM_MU2 + i] * invBL);
+            al += tot[SM_AL + i];
+            a.dsigma[i] = tot[SM_DSIG + i];
+        }
+        const float l_kl = kl_scale * kl, l_rec = w_rec * rec, l_al = w_al * al * invBL, l_f = w_f * tot[SM_F] * invBL;
+        const float total = l_kl + l_rec + l_al + l_f;
+        a.losses[0] = l_kl; a.losses[1] = l_rec; a.losses[2] = l_al; a.losses[3] = l_f;
+        a.losses[4] = total;
+        a.losses[5] = fminf(a.losses[5], total);
+    }
+}
+
+static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
+    JAMIE_ARG(a != nullptr, "null descriptor");
+    JAMIE_ARG(a->M >= 2 && a->M <= LM, "2 <= M <= 4");
+    JAMIE_ARG(a->B >= a->M && a->L >= 1, "B >= M (KL uses rows 0..M-1), L >= 1");
+    JAMIE_ARG((long long)a->B * a->L <= 256LL * JAMIE_MAX_PARTIALS, "B*L too large for the partial buffer");
+    JAMIE_ARG(a->sigma && a->hyper && a->partials && a->comb, "null pointer");
+    memset(&d, 0, sizeof(d));
+    d.B = a->B; d.L = a->L; d.M = a->M;
+    for (int i = 0; i < a->M; ++i) {
+        JAMIE_ARG(a->mu[i] && a->lv[i] && a->z[i] && a->eps[i], "null state buffer");
+        d.ml[i] = a->ml[i]; d.head_bias[i] = a->head_bias[i]; d.eps_in[i] = a->eps_in[i];
+        d.mu[i] = a->mu[i]; d.lv[i] = a->lv[i]; d.z[i] = a->z[i]; d.eps[i] = a->eps[i];
+        d.dcomb[i] = a->dcomb[i]; d.dml[i] = a->dml[i];
+    }
+    d.ml_nslab = a->ml_nslab; d.ml_slab_stride = a->ml_slab_stride;
+    d.sigma = a->sigma; d.hyper = a->hyper; d.comb = a->comb; d.partials = a->partials;
+    d.dcomb_nslab = a->dcomb_nslab; d.dcomb_slab_stride = a->dcomb_slab_stride;
+    d.dsigma = a->dsigma; d.rec_partials = a->rec_partials; d.n_rec_partials = a->n_rec_partials;
+    d.losses = a->losses; d.rng_stream = a->rng_stream;
+    return 0;
+}
+
+extern "C" int jamie_latent_m_fwd(const jamie_latent_m* a, const uint64_t* rng, void* stream) {
+    LatMDev d;
+    int rc = latm_to_dev(a, d);
+    if (rc) return rc;
+    bool need_rng = false;
+    for (int i = 0; i < a->M; ++i) {
+        JAMIE_ARG(a->ml[i] && a->head_bias[i], "heads input");
+        if (!a->eps_in[i]) need_rng = true;
+    }
+    JAMIE_ARG(a->ml_nslab >= 1 && (a->ml_nslab == 1 || a->ml_slab_stride >= (long long)a->B * 2 * a->L), "ml slabs");
+    JAMIE_ARG(!need_rng || rng, "rng state required when eps is not given");
+    const int nblk = (a->B * a->L + 255) / 256;
+    hipLaunchKernelGGL(latent_m_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d, rng);
+    return jamie_launch_status("jamie_latent_m_fwd");
+}
+
+extern "C" int jamie_latent_m_bwd(const jamie_latent_m* a, void* stream) {
+    LatMDev d;
+    int rc = latm_to_dev(a, d);
+    if (rc) return rc;
+    for (int i = 0; i < a->M; ++i) JAMIE_ARG(a->dcomb[i] && a->dml[i], "dcomb / dml");
+    JAMIE_ARG(a->dsigma && a->losses && a->dcomb_nslab >= 1, "null output");
+    JAMIE_ARG(a->dcomb_nslab == 1 || a->dcomb_slab_stride >= (long long)a->B * a->L, "dcomb_slab_stride too small");
+    JAMIE_ARG(a->n_rec_partials == 0 || a->rec_partials, "rec_partials");
+    const int nblk = (a->B * a->L + 255) / 256;
+    hipLaunchKernelGGL(latent_m_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(latent_m_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d);
+    return jamie_launch_status("jamie_latent_m_bwd");
+}

@@ -56,6 +56,7 @@ class TrainEngine:
         self.dev = model.device
         self.B = B = int(batch_size)
         self.dims = model.input_dim
+        self.M = len(self.dims)
         self.L = L = model.output_dim
         self.p_drop = model.dropout
         if self.bf16 and any(v % 8 for v in list(self.dims) + [L, B]):
@@ -85,7 +86,7 @@ class TrainEngine:
         self.set_kl_anneal(1.0)
         self.losses = torch.zeros(8, **f32)
         self.reset_best()
-        self.lat_partials = torch.zeros(16 * nv.load().jamie_max_partials(), **f32)
+        self.lat_partials = torch.zeros(20 * nv.load().jamie_max_partials(), **f32)
         # ---- per-modality workspace ----
         self.ws = []
         # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
@@ -120,6 +121,8 @@ class TrainEngine:
             for k, nn in (('bn0', 2 * d), ('bn1', d), ('bn2', d), ('bn3', 2 * d)):
                 w[k + '.mean'] = torch.empty(nn, **f32); w[k + '.invstd'] = torch.empty(nn, **f32)
             w['idx'] = torch.zeros(B, dtype=torch.int32, device=self.dev)
+            if self.M > 2 and i > 0:
+                w['comb'] = self.ws[0]['comb']          # M > 2 (identity corr): one combined embedding for all
             if self.bf16:
                 bf = dict(device=self.dev, dtype=torch.bfloat16)
                 for k, nf in (('x', d), ('a1', 2 * d), ('a2', d), ('comb', L), ('e1', d), ('e2', 2 * d), ('dxhat', d),
@@ -309,7 +312,7 @@ class TrainEngine:
     def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key):
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
         K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch."""
-        if not self.bf16:
+        if not self.bf16 or 2 * self.M > nv.MAX_GROUP:
             self._dw_gemm(dy_key, a_key, lin)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
@@ -327,7 +330,32 @@ class TrainEngine:
                                          nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         nv.gemm_bf16(probs)
 
+    def _latent_desc_m(self, corr, Fblk, noise):
+        """M > 2: fully paired cells only (identity correspondence, F = 0, euclidean alignment)."""
+        if corr is not None or Fblk is not None or self.cosine:
+            raise NotImplementedError('more than two modalities: identity correspondence, F = 0, euclidean only')
+        B, L = self.B, self.L
+        d = nv.LatentM()
+        d.B, d.L, d.M = B, L, self.M
+        for i in range(self.M):
+            w = self.ws[i]
+            d.ml[i] = nv.ptr(w['ml']); d.head_bias[i] = nv.ptr(self.m.p[f'm{i}.head.b'])
+            d.eps_in[i] = nv.ptr(noise['eps'][i]) if noise is not None else None
+            for k in ('mu', 'lv', 'z', 'eps', 'dml'):
+                getattr(d, k)[i] = nv.ptr(w[k])
+            d.dcomb[i] = nv.ptr(w['dcomb'])
+        d.comb = nv.ptr(self.ws[0]['comb'])
+        d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
+        d.sigma, d.hyper, d.partials = nv.ptr(self.m.p['sigma']), nv.ptr(self.hyper), nv.ptr(self.lat_partials)
+        d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
+        d.dsigma = nv.ptr(self.g['sigma'])
+        d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
+        d.losses, d.rng_stream = nv.ptr(self.losses), 100
+        return d
+
     def _latent_desc(self, corr, Fblk, noise):
+        if self.M != 2:
+            return self._latent_desc_m(corr, Fblk, noise)
         B, L = self.B, self.L
         d = nv.Latent()
         d.B, d.L = B, L
@@ -352,7 +380,7 @@ class TrainEngine:
     # ---- the step ----
     def load_batch(self, data, idx):
         """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors."""
-        for i in range(2):
+        for i in range(self.M):
             nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
         self._cast('x')
 
@@ -366,7 +394,7 @@ class TrainEngine:
 
     def set_batch(self, X):
         """Use the given [B, d_i] fp32 matrices as the batch (tests; the training loop uses `load_batch`)."""
-        for i in range(2):
+        for i in range(self.M):
             self.ws[i]['x'].copy_(X[i])
         self._cast('x')
 
@@ -383,6 +411,8 @@ class TrainEngine:
 
     def backward_external(self, lat, dz, dcomb, dxhat, dmu, dlv_last, noise=None):
         """Backward from caller-supplied gradients of the forward outputs (lists per modality; None = zero)."""
+        if self.M != 2:
+            raise NotImplementedError('the autograd seam follows the reference: two modalities')
         B, L = self.B, self.L
         keep = []
         for i in range(2):
@@ -496,7 +526,7 @@ class TrainEngine:
         nv.begin_record()
         try:
             nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
-            self.load_batch(data, [idx, idx])
+            self.load_batch(data, [idx] * self.M)
             corr = None
             if replace:
                 nv.corr_from_indices(idx, idx, self.corr)

@@ -174,7 +174,11 @@ class JAMIE:
         """The training loop, reference jamie.py:416-804."""
         print('-' * 33)
         print('Train coupled autoencoders')
-        assert self.dataset_num == 2, 'Currently only compatible with 2 modalities.'
+        # the reference asserts two modalities (jamie.py:420); 3-4 fully paired ones run the build-defined
+        # generalisation (identity correspondence, F = 0; SURVEY.md §8 A14)
+        assert 2 <= self.dataset_num <= 4, 'Currently only compatible with 2 (reference) to 4 modalities.'
+        if self.dataset_num > 2 and (self.P is not None or self.use_f_tilde or len(set(self.row)) != 1):
+            raise NotImplementedError('more than two modalities need fully paired cells (P=None, use_f_tilde=False)')
         dev = torch.device(self.device)
         rank, world = 0, 1
         allreduce = None
@@ -235,9 +239,11 @@ class JAMIE:
                           world_size=world, compute_dtype=self.compute_dtype)
         eng.accumulate = False
         self.engine = eng
-        rep = min(self.col) < B                                              # jamie.py:553 (sic)
+        rep = min(self.col) < B and self.dataset_num == 2                    # jamie.py:553 (sic); M > 2: never
         need_block = (method == 'diag' and rep) or method == 'zeros' or F_dense is not None or P_dense is not None
-        idx_dev = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        if self.dataset_num > 2 and need_block:
+            raise NotImplementedError('more than two modalities: min(features) must be >= batch_size (no duplicates)')
+        idx_dev = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(self.dataset_num)]
         best_running_loss = np.inf
         streak = 0
         if self.record_loss:
@@ -272,7 +278,8 @@ class JAMIE:
                     if method == 'diag':
                         s = np.random.choice(range(rows[0]), B, replace=rep)
                         idx_dev[0].copy_(torch.from_numpy(s.astype(np.int32)))
-                        idx_dev[1].copy_(idx_dev[0])
+                        for j in range(1, self.dataset_num):
+                            idx_dev[j].copy_(idx_dev[0])
                     else:
                         for i in range(2):
                             s = np.random.choice(range(rows[i]), B, replace=rep)
@@ -280,7 +287,8 @@ class JAMIE:
                 else:
                     nv.sample_indices(idx_dev[0], rows[0], 0, rep, eng.state, 200)
                     if method == 'diag':
-                        idx_dev[1].copy_(idx_dev[0])
+                        for j in range(1, self.dataset_num):
+                            idx_dev[j].copy_(idx_dev[0])
                     else:
                         nv.sample_indices(idx_dev[1], rows[1], 0, rep, eng.state, 201)
                 eng.load_batch(data, idx_dev)
@@ -321,7 +329,7 @@ class JAMIE:
                 if streak >= self.max_steps_without_increment and self.use_early_stop:
                     break
         self.model.eval()
-        out = [self.model.embed(data_all[i], i).cpu().numpy() for i in range(2)]   # jamie.py:794-799
+        out = [self.model.embed(data_all[i], i).cpu().numpy() for i in range(self.dataset_num)]   # jamie.py:794-799
         timer.log('Output')
         print('Finished Mapping!')
         if self.debug:

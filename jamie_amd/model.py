@@ -155,7 +155,8 @@ class _EvalMuHead:
 
 
 class edModelVar:
-    """MI355X counterpart of the reference's `edModelVar` (model.py:116-282), two modalities.
+    """MI355X counterpart of the reference's `edModelVar` (model.py:116-282); two modalities like the reference,
+    or 3-4 fully paired ones (build-defined generalisation).
 
     Constructor arguments follow the reference (`input_dim`, `output_dim`, `preprocessing`,
     `preprocessing_inverse`, `sigma` (unused there too), `dropout`).  Parameters are initialised from the
@@ -167,8 +168,8 @@ class edModelVar:
     def __init__(self, input_dim, output_dim, preprocessing=None, preprocessing_inverse=None, sigma=None,
                  dropout=None, device='cuda'):
         nv.require_gpu()
-        if len(input_dim) != 2:
-            raise NotImplementedError('two modalities (the reference asserts the same, jamie.py:420)')
+        if not 2 <= len(input_dim) <= 4:
+            raise NotImplementedError('2..4 modalities (the reference itself supports exactly two, jamie.py:420)')
         self.input_dim = [int(d) for d in input_dim]
         self.output_dim = int(output_dim)
         self.num_modalities = len(input_dim)
@@ -315,15 +316,18 @@ class edModelVar:
         if self.training:
             raise nv.JamieHipError('train-mode forward is TrainEngine.step(); call .eval() first')
         L = self.output_dim
-        hs = [self._encode_eval(i, X[i]) for i in range(2)]
-        mus = [self._mu_eval(i, hs[i]) for i in range(2)]
-        logvar = self._linear(hs[1], self.p['m1.head.W'][L:], self.p['m1.head.b'][L:])
+        M = self.num_modalities
+        hs = [self._encode_eval(i, X[i]) for i in range(M)]
+        mus = [self._mu_eval(i, hs[i]) for i in range(M)]
+        logvar = self._linear(hs[M - 1], self.p[f'm{M - 1}.head.W'][L:], self.p[f'm{M - 1}.head.b'][L:])
         sig = self.p['sigma']
         if corr is None:
-            comb = [(sig[0] * mus[0] + sig[1] * mus[1]) / (sig[0] + sig[1])] * 2
+            comb = [sum(sig[j] * mus[j] for j in range(M)) / sig.sum()] * M
+        elif M != 2:
+            raise NotImplementedError('a correspondence block is only defined for two modalities')
         else:
             corr = self._dev(corr)
             comb = [(sig[0] * mus[0] + sig[1] * (corr @ mus[1])) / (sig[0] + sig[1] * corr.sum(1, keepdim=True)),
                     (sig[1] * mus[1] + sig[0] * (corr.t() @ mus[0])) / (sig[1] + sig[0] * corr.sum(0).reshape(-1, 1))]
-        X_hat = [self._decode_eval(i, comb[i]) for i in range(2)]
+        X_hat = [self._decode_eval(i, comb[i]) for i in range(M)]
         return mus, comb, X_hat, mus, logvar

@@ -181,8 +181,20 @@ def refactor(P, hs, train, eps, index=None):
     return zs, mus, logvar
 
 
+def combine_identity(P, zs):
+    """BUILD-DEFINED generalisation to M >= 2 fully paired modalities (no counterpart in the reference, which
+    asserts two modalities: jamie.py:420): comb_i = sum_j sigma_j z_j / sum_j sigma_j for every i.  For M = 2 this
+    is model.py:245-259 at corr = I."""
+    sigma = P['sigma']
+    c = sum(sigma[j] * zs[j] for j in range(len(zs))) / sigma[:len(zs)].sum()
+    return [c for _ in zs]
+
+
 def combine(P, zs, corr):
-    """model.py:245-259 (two modalities; `(i + 1) % 2`)."""
+    """model.py:245-259 (two modalities; `(i + 1) % 2`).  `corr=None` = identity, any number of modalities."""
+    if corr is None:
+        return combine_identity(P, zs)
+    assert len(zs) == 2, 'a correspondence block is only defined for two modalities (reference jamie.py:420)'
     sigma = P['sigma']
     out = []
     for i in range(2):
@@ -244,12 +256,13 @@ def losses(X, zs, combined, X_hat, mus, logvars, Fblk, anneal, dist_method='eucl
              for i in range(M))
     l_kl = KL_WEIGHT * anneal * kl
     l_rec = sum((X_hat[i] - X[i]).square().mean(axis=1).mean(axis=0) for i in range(M))
-    d0 = sim_diff(zs[0], combined[0], dist_method)
-    d1 = sim_diff(zs[1], combined[1], dist_method)
-    cos = (torch.diag(d0.square()).mean(axis=0) / zs[0].shape[1]
-           + torch.diag(d1.square()).mean(axis=0) / zs[1].shape[1])
+    cos = sum(torch.diag(sim_diff(zs[i], combined[i], dist_method).square()).mean(axis=0) / zs[i].shape[1]
+              for i in range(M))                       # jamie.py:649-657 (two terms there)
     l_cos = ALIGN_WEIGHT * cos
-    l_f = torch.square(combined[0] - torch.mm(Fblk, combined[1])).mean(axis=1).mean(axis=0)
+    if Fblk is None:                                   # F = 0 (use_f_tilde=False): mean(combined[0]^2)
+        l_f = torch.square(combined[0]).mean(axis=1).mean(axis=0)
+    else:
+        l_f = torch.square(combined[0] - torch.mm(Fblk, combined[1])).mean(axis=1).mean(axis=0)
     return [l_kl, l_rec, l_cos, l_f]
 
 

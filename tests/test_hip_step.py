@@ -658,3 +658,64 @@ def test_full_size_config2_step_vs_oracle(jam):
         if 'num_batches' in k:
             continue
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('B,dims,L,p', [(64, (40, 32, 24), 8, 0.0), (256, (264, 200, 136), 16, 0.6)])
+def test_three_modalities_step_vs_generalised_oracle(jam, B, dims, L, p):
+    """Three fully paired modalities (BASELINE config 4's shape class).  The reference has no 3-modality path
+    (jamie.py:420), so parity is against the generalised oracle only (combine = sigma-weighted mean, KL rows 0..2 of
+    the last modality's logvar): one step's losses, gradients and post-step weights."""
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    torch.manual_seed(31)
+    model = edModelVar(dims, L, dropout=p)
+    torch.manual_seed(31)
+    P, Bf = orc.init_state(dims, L)
+    sd = model.state_dict()
+    for k, v in P.items():
+        assert torch.equal(sd[k].cpu(), v), k
+        v.requires_grad_(True)
+    assert model.num_parameters() == orc.param_count(dims, L)
+    eng = TrainEngine(model, B)
+    opt = orc.Adam(P.values(), 1e-3)
+    g = torch.Generator().manual_seed(2)
+    X = [torch.randn(B, d, generator=g) for d in dims]
+    torch.manual_seed(77)
+    noise = orc.draw_noise(dims, L, B, p)
+    st = orc.train_step(P, Bf, opt, X, None, None, noise, p, 0.6, return_grads=True)
+    eng.set_batch([x.cuda() for x in X])
+    eng.set_kl_anneal(0.6)
+    eng.forward_backward(None, None, _noise_to_dev(noise, p))
+    ls, total, _ = eng.read_losses()
+    np.testing.assert_allclose(ls, st['losses'], rtol=2e-4, atol=1e-6)
+    for ref, (mine, sl) in model.layout.reference_names().items():
+        if orc.is_dead_bias(ref):
+            continue
+        got = (eng.g[mine] if sl is None else eng.g[mine][sl]).cpu().numpy()
+        want = st['grads'][ref].numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-5 * max(1e-6, float(np.abs(want).max())) + 1e-7,
+                                   err_msg=ref)
+    eng.optimizer_step()
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not orc.is_dead_bias(k):
+            assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=1e-3,
+                                rel_l2=1e-3, msg=k)
+    model.eval()
+    out = model(*[x.cuda() for x in X])
+    assert len(out[0]) == 3 and out[2][2].shape == (B, dims[2])
+
+
+def test_three_modalities_facade_and_bf16(jam):
+    rng = np.random.default_rng(8)
+    N, dims = 512, (72, 48, 40)
+    Z = rng.standard_normal((N, 5))
+    data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
+    for mode in ('f32', 'bf16'):
+        np.random.seed(3)
+        jm = jam.JAMIE(output_dim=8, batch_size=32, epoch_DNN=12, min_epochs=6, pca_dim=None, use_f_tilde=False,
+                       log_DNN=10 ** 9, sampler='device', compute_dtype=mode)
+        emb = _quiet(lambda: jm.fit_transform(dataset=data))
+        assert len(emb) == 3 and all(e.shape == (N, 8) and np.isfinite(e).all() for e in emb)
+        assert jm.loss_history['Rec'][-1] < jm.loss_history['Rec'][0]
+        assert jm.modal_predict(data[2], 2).shape == (N, dims[0])          # modality 2 -> (2 + 1) % 3 = 0

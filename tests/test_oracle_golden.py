@@ -157,3 +157,21 @@ def test_identity_P_is_index_equality():
     idx1 = rng.integers(0, N, 20)
     dense = orc.p_block(torch.eye(N), idx0, idx1)
     assert torch.equal(dense, orc.p_block(None, idx0, idx1))
+
+
+def test_m_modality_generalisation_reduces_to_reference_for_two():
+    """The build-defined M-modality combine (identity correspondence) equals the reference's two-modality combine at
+    corr = I, and the generalised loss code gives the same four losses for M = 2 ('M = 2 reduction')."""
+    torch.manual_seed(1)
+    dims, L, B = (12, 10), 3, 16
+    P, Bf = orc.init_state(dims, L)
+    X = [torch.randn(B, d) for d in dims]
+    noise = orc.draw_noise(dims, L, B, 0.)
+    a = orc.forward(P, dict(Bf), X, torch.eye(B), train=True, p=0., noise=noise)
+    b = orc.forward(P, dict(Bf), X, None, train=True, p=0., noise=noise)
+    for u, v in zip(a[1], b[1]):
+        assert torch.allclose(u, v, rtol=1e-6, atol=1e-7)
+    la = orc.losses(X, *a, torch.zeros(B, B), 0.3)
+    lb = orc.losses(X, *b, None, 0.3)
+    for u, v in zip(la, lb):
+        assert torch.allclose(u, v, rtol=1e-6, atol=1e-8)
