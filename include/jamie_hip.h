@@ -167,6 +167,8 @@ typedef struct {
        forward outputs, reference jamie.py:611-734); added to the internally derived ones; NULL = none.
        An external d(combined) is passed as one more `dcomb` slab.                                     */
     const float* dz_ext[2]; const float* dmu_ext[2]; const float* dlv_ext /* last modality's logvar */;
+    /* optional bf16 copies for the bf16 compute mode (NULL = none): comb [B,L] / [L,B], d(mu|logvar) [B,2L] / [2L,B] */
+    void* comb_bf16[2]; void* combT_bf16[2]; void* dml_bf16[2]; void* dmlT_bf16[2];
 } jamie_latent;
 
 int jamie_latent_fwd(const jamie_latent* a /*host*/, const uint64_t* rng, void* stream);

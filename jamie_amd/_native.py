@@ -74,7 +74,9 @@ class Latent(C.Structure):
                 ('dml', C.c_void_p * 2), ('dsigma', C.c_void_p),
                 ('rec_partials', C.c_void_p), ('n_rec_partials', C.c_int), ('losses', C.c_void_p),
                 ('cosine', C.c_int), ('rng_stream', C.c_int),
-                ('dz_ext', C.c_void_p * 2), ('dmu_ext', C.c_void_p * 2), ('dlv_ext', C.c_void_p)]
+                ('dz_ext', C.c_void_p * 2), ('dmu_ext', C.c_void_p * 2), ('dlv_ext', C.c_void_p),
+                ('comb_bf16', C.c_void_p * 2), ('combT_bf16', C.c_void_p * 2),
+                ('dml_bf16', C.c_void_p * 2), ('dmlT_bf16', C.c_void_p * 2)]
 
 
 class LatentM(C.Structure):

@@ -25,7 +25,10 @@ struct LatDev {
     const float* rec_partials; int n_rec_partials; float* losses;
     int cosine; int rng_stream;
     const float* dz_ext[2]; const float* dmu_ext[2]; const float* dlv_ext;
+    unsigned short* comb_bf[2]; unsigned short* combT_bf[2]; unsigned short* dml_bf[2]; unsigned short* dmlT_bf[2];
 };
+
+__device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 static LatDev to_dev(const jamie_latent* a) {
     LatDev d;
@@ -46,6 +49,10 @@ static LatDev to_dev(const jamie_latent* a) {
     d.cosine = a->cosine; d.rng_stream = a->rng_stream;
     for (int i = 0; i < 2; ++i) { d.dz_ext[i] = a->dz_ext[i]; d.dmu_ext[i] = a->dmu_ext[i]; }
     d.dlv_ext = a->dlv_ext;
+    for (int i = 0; i < 2; ++i) {
+        d.comb_bf[i] = (unsigned short*)a->comb_bf16[i]; d.combT_bf[i] = (unsigned short*)a->combT_bf16[i];
+        d.dml_bf[i] = (unsigned short*)a->dml_bf16[i]; d.dmlT_bf[i] = (unsigned short*)a->dmlT_bf16[i];
+    }
     return d;
 }
 
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(256) void latent_combine_kernel(LatDev a) {
         const float c1 = (s1 * z1 + s0 * a.cz[1][e]) / (s1 + s0 * a.qsum[b]);
         a.comb[0][e] = c0;
         a.comb[1][e] = c1;
+        // bf16 compute mode: the decoder's first GEMM and its dW read bf16 [B,L] / [L,B] copies (tiny: B*L elements)
+        const int l = e % L;
+        if (a.comb_bf[0]) { a.comb_bf[0][e] = to_bf16(c0); a.comb_bf[1][e] = to_bf16(c1); }
+        if (a.combT_bf[0]) { a.combT_bf[0][(long long)l * B + b] = to_bf16(c0); a.combT_bf[1][(long long)l * B + b] = to_bf16(c1); }
         if (!a.cosine) {
             al0 = (z0 - c0) * (z0 - c0);
             al1 = (z1 - c1) * (z1 - c1);
@@ -273,6 +284,14 @@ __global__ __launch_bounds__(256) void latent_bwd_b_kernel(LatDev a) {
             if (i == 1 && a.dlv_ext) dlv += a.dlv_ext[e];
             a.dml[i][(long long)b * 2 * L + l] = dmu;
             a.dml[i][(long long)b * 2 * L + L + l] = dlv;
+            if (a.dml_bf[i]) {
+                a.dml_bf[i][(long long)b * 2 * L + l] = to_bf16(dmu);
+                a.dml_bf[i][(long long)b * 2 * L + L + l] = to_bf16(dlv);
+            }
+            if (a.dmlT_bf[i]) {
+                a.dmlT_bf[i][(long long)l * B + b] = to_bf16(dmu);
+                a.dmlT_bf[i][(long long)(L + l) * B + b] = to_bf16(dlv);
+            }
         }
     }
     if (blockIdx.x != 0) return;

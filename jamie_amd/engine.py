@@ -209,7 +209,8 @@ class TrainEngine:
 
     def _cast(self, key):
         """fp32 activation / gradient `key` ([B, n] or slab 0 of [S, B, n]) -> bf16 [B, n] and bf16 [n, B]."""
-        if not self.bf16 or (self.fuse_bf16 and key in ('a1', 'a2', 'e1', 'e2', 'de2', 'de1', 'da2', 'da1')):
+        if not self.bf16 or (self.fuse_bf16 and key in ('a1', 'a2', 'e1', 'e2', 'de2', 'de1', 'da2', 'da1')) \
+                or (self.M == 2 and key in ('comb', 'dml')):
             return
         probs = []
         for w in self.ws:
@@ -375,6 +376,11 @@ class TrainEngine:
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses = nv.ptr(self.losses)
         d.cosine, d.rng_stream = int(self.cosine), 100
+        if self.bf16:        # the latent kernels write the bf16 / transposed copies of comb and d(mu|logvar) themselves
+            for i in range(2):
+                w = self.ws[i]
+                d.comb_bf16[i], d.combT_bf16[i] = nv.ptr(w['comb_bf']), nv.ptr(w['comb_T'])
+                d.dml_bf16[i], d.dmlT_bf16[i] = nv.ptr(w['dml_bf']), nv.ptr(w['dml_T'])
         return d
 
     # ---- the step ----
