@@ -245,7 +245,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-static const int BT[7][2] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {64, 64}, {64, 64}, {64, 64}};
+static const int BT[7][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
@@ -277,8 +277,8 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
     switch (cfg) {
         case 0: return launch_b<128, 128, 64, 2, 2, 2>(pr, count, st);
         case 1: return launch_b<64, 64, 64, 2, 2, 3>(pr, count, st);
-        case 2: return launch_b<128, 64, 64, 2, 2, 2>(pr, count, st);
-        case 3: return launch_b<64, 128, 64, 2, 2, 2>(pr, count, st);
+        case 2: return launch_b<64, 64, 32, 2, 2, 2>(pr, count, st);
+        case 3: return launch_b<32, 64, 64, 1, 2, 2>(pr, count, st);
         case 4: return launch_b<64, 64, 64, 2, 2, 1>(pr, count, st);
         case 5: return launch_b<64, 64, 64, 2, 2, 2>(pr, count, st);
         case 6: return launch_b<64, 64, 64, 2, 2, 4>(pr, count, st);
