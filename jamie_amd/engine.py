@@ -150,6 +150,7 @@ class TrainEngine:
         self.corr = torch.empty(B, B, **f32)
         self.accumulate = False
         self._timing = None
+        self._timing_every, self._timing_step = 1, 0
 
     # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
     def set_kl_anneal(self, anneal):
@@ -160,13 +161,17 @@ class TrainEngine:
         self.losses[5] = float('inf')
 
     # ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----
-    def enable_kernel_timing(self, *labels):
+    def enable_kernel_timing(self, *labels, every=1):
+        """Bracket the launches tagged `labels` with HIP events on every `every`-th step (creating and recording
+        ~10 events per step costs the host 3-10 % on a loaded box, so benchmarks sample)."""
         self._timing = {label: [] for label in labels}
+        self._timing_every = max(1, int(every))
+        self._timing_step = 0
 
     def _ev(self, label, which):
         """Record a HIP event on the launch stream (works both eagerly and as a step of a replayed plan)."""
         def rec():
-            if self._timing is None or label not in self._timing:
+            if self._timing is None or label not in self._timing or self._timing_step % self._timing_every:
                 return
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -545,6 +550,7 @@ class TrainEngine:
     def run_plan(self, plan):
         nv.replay(plan)
         self.m.num_batches_tracked += 1
+        self._timing_step += 1
 
     def read_losses(self):
         """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""
