@@ -14,6 +14,12 @@
 // prefetch, grouped launch, XCD mapping, split-K slabs and epilogues are those of gemm_f32.hip.
 #include "common.h"
 
+// diagnostic ablations (timing only, wrong results): 1 = no global loads in the k-loop, 2 = no MFMAs,
+// 3 = no LDS writes, 4 = no fragment reads (LDS read traffic removed)
+#ifndef JAMIE_GEMMB_ABL
+#define JAMIE_GEMMB_ABL 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
             if (kt < nk) {
                 const int cur = kt & 1;
                 // register stage u held tile kt (already in LDS): refill it with tile kt + D
-                if (kt + D < nk) JB_LOAD(u, kbeg + (kt + D) * BK)
+                if (kt + D < nk && JAMIE_GEMMB_ABL != 1) JB_LOAD(u, kbeg + (kt + D) * BK)
                 const unsigned char* As = smem + cur * (A_SZ + B_SZ);
                 const unsigned char* Bs = As + A_SZ;
                 bf16x8 af[2][TM], bf[2][TN];
@@ -160,22 +166,233 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
 #pragma unroll
                 for (int s = 0; s < BK / 16; ++s) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
+                    if (s + 1 < BK / 16 && JAMIE_GEMMB_ABL != 4) read_frags((s + 1) & 1, s + 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                        {
+#if JAMIE_GEMMB_ABL == 2
+                            asm volatile("" ::"v"(af[s & 1][i]), "v"(bf[s & 1][j]));
+#else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(JAMIE_GEMMB_ABL == 4 ? 0 : s) & 1][i], bf[(JAMIE_GEMMB_ABL == 4 ? 0 : s) & 1][j], acc[i][j], 0, 0, 0);
+#endif
+                        }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (kt + 1 < nk) JB_STORE((u + 1) % D, cur ^ 1)     // tile kt+1 lives in register stage (u+1) % D
+                if (kt + 1 < nk && JAMIE_GEMMB_ABL != 3) JB_STORE((u + 1) % D, cur ^ 1)     // tile kt+1 lives in register stage (u+1) % D
                 __syncthreads();
             }
         }
     }
 #undef JB_LOAD
 #undef JB_STORE
+
+    // ---- epilogue (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
+    float* Cout = P.C + (long long)ks * P.slab_stride;
+    const bool add_bias = (P.bias != nullptr) && ks == 0;
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + r;
+        if (n >= P.N) continue;
+        const float bv = add_bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= P.M) continue;
+                float v = acc[i][j][e] + bv;
+                float* cp = Cout + (long long)m * P.ldc + n;
+                if (P.epi == JAMIE_EPI_STORE) {
+                    if (P.accumulate) v += *cp;
+                    *cp = v;
+                } else {  // JAMIE_EPI_MSE
+                    const float d = v - P.aux0[(long long)m * P.aux_ld + n];
+                    local += d * d;
+                    *cp = d * P.scale;
+                }
+            }
+        }
+    }
+    if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (BK = 64).  Ablations of the register-staged kernel above (tools/ablate_gemm_bf16.sh) show that
+// the global -> VGPR -> ds_write_b128 staging path, not the MFMAs or the fragment reads, sets its time (32 us ->
+// 16 us without it).  Here full k-tiles go global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB = 8 rows x 128 B
+// per wave-instruction, no VGPRs, no ds_write).  The LDS image must then be lane-linear, so rows cannot be padded:
+// bank conflicts are avoided by an XOR swizzle applied on the SOURCE address and on the fragment read
+// (cdna_hip_programming.md rule 21): physical 16-byte chunk = logical chunk ^ ((row >> 1) & 7); with 128-byte rows
+// the 16 rows of every ds_read_b128 lane group then hit 16 distinct slots of the 256-byte bank line.
+// Rows beyond M / N re-read the last valid row (their outputs are never stored); a partial last k-tile is staged
+// through registers with masked buffer loads into the same swizzled image.
+// ------------------------------------------------------------------------------------------------
+// NB LDS buffers: the DMA of tiles kt+1 .. kt+NB-1 is in flight while tile kt is multiplied.  With more than one tile
+// in flight `__syncthreads()` must go (its fence drains vmcnt(0)): raw s_barrier + hand-counted `s_waitcnt vmcnt(N)`,
+// N = 4 glds per wave x DMA tiles younger than the one about to be read (cdna_hip_programming.md 'Pipelining across
+// barriers').  One barrier per k-step: it publishes tile kt (every wave waited for its own pieces) and frees buffer
+// (kt-1) % NB, into which tile kt+NB-1 is then issued.
+template <int BM, int BN, int WM, int WN, int TAG, int NB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup g) {
+    constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_SZ = BM * 128, B_SZ = BN * 128;      // bytes, unpadded 128-byte rows
+    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB pieces per wave
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;    // 16-byte chunks per thread (register tail path)
+    static_assert(PA >= 1 && PB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+    // ONE __shared__ object: a second one beside an LDS-DMA staging array makes hipcc drain vmcnt(0) before the
+    // first ds_read of every k-step (cdna_hip_programming.md, 'Three .s-level traps' (a)); `red` is carved from it
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * (A_SZ + B_SZ) + 64];
+    float* red = reinterpret_cast<float*>(smem + NB * (A_SZ + B_SZ));
+
+    // ---- block -> (problem, tile): per-problem XCD chunks (see gemm_f32.hip) ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    int pi = 0, t = 0, rot = 0;
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+        if (i < g.count) {
+            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
+            const int j = (xcd - rot) & 7;
+            const int cp = qp + (j < rp ? 1 : 0);
+            if (slot >= 0 && slot < cp) {
+                pi = i;
+                t = j * qp + min(j, rp) + slot;
+                slot = -1;
+            } else if (slot >= 0) {
+                slot -= cp;
+            }
+            rot = (rot + rp) & 7;
+        }
+    }
+    const GemmBDev& P = g.p[pi];
+    const int tm_i = t % P.tiles_m;
+    const int tn_i = (t / P.tiles_m) % P.tiles_n;
+    const int ks = t / (P.tiles_m * P.tiles_n);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int kbeg = ks * P.kchunk;
+    const int kend = min(P.K, kbeg + P.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
+    const int r = lane & 31, h = lane >> 5;
+
+
+    const int lrow = lane >> 3, pch = lane & 7;
+    const unsigned short* a_src[PA]; const unsigned short* b_src[PB];
+    int a_dst[PA], b_dst[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int pc = wid + NW * i, row = 8 * pc + lrow;
+        const int gm = min(m0 + row, P.M - 1);
+        a_src[i] = P.A + (long long)gm * P.lda + ((pch ^ ((row >> 1) & 7)) * 8);
+        a_dst[i] = pc * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int pc = wid + NW * i, row = 8 * pc + lrow;
+        const int gn = min(n0 + row, P.N - 1);
+        b_src[i] = P.B + (long long)gn * P.ldb + ((pch ^ ((row >> 1) & 7)) * 8);
+        b_dst[i] = pc * 1024;
+    }
+    const int nfull = (kend - kbeg) / BK;
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto stage = [&](int buf, int kt) {
+        unsigned char* As = smem + buf * (A_SZ + B_SZ);
+        unsigned char* Bs = As + A_SZ;
+        const int k0 = kbeg + kt * BK;
+        if (kt < nfull) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + a_dst[i]), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0), (lptr_t)(Bs + b_dst[i]), 16, 0, 0);
+        } else {   // partial k-tile: masked loads through registers into the same swizzled image
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int f = tid + j * NT, row = f >> 3, c = f & 7;
+                const int gm = min(m0 + row, P.M - 1);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.A + (long long)gm * P.lda + k0 + c * 8);
+                *reinterpret_cast<uint4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const int f = tid + j * NT, row = f >> 3, c = f & 7;
+                const int gn = min(n0 + row, P.N - 1);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.B + (long long)gn * P.ldb + k0 + c * 8);
+                *reinterpret_cast<uint4*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int swz = (r >> 1) & 7;
+    constexpr int GL = PA + PB;                       // glds instructions per wave and tile
+    static_assert(GL * (NB - 1) <= 60, "vmcnt immediate");
+    // prologue: tiles 0 .. NB-2 in flight
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u)
+        if (u < nk) stage(u, u);
+    for (int kt = 0; kt < nk; ++kt) {
+        // wait for MY pieces of tile kt: DMA tiles younger than kt that are already issued = tiles kt+1 .. kt+NB-2
+        // (only full tiles are DMA; a partial last tile went through registers and was waited for by the compiler)
+        const int younger = max(0, min(kt + NB - 2, nfull - 1) - kt);
+        if (kt >= nfull || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GL) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NB - 1 < nk) stage((kt + NB - 1) % NB, kt + NB - 1);
+        const int cur = kt % NB;
+        const unsigned char* As = smem + cur * (A_SZ + B_SZ);
+        const unsigned char* Bs = As + A_SZ;
+        bf16x8 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int buf, int s) {
+            const int off = ((2 * s + h) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[buf][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * 128 + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[buf][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * 128 + off);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
 
     // ---- epilogue (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
     float* Cout = P.C + (long long)ks * P.slab_stride;
@@ -245,20 +462,56 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-static const int BT[7][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}};
+template <int BM, int BN, int WM, int WN, int NB>
+static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
+    constexpr int BK = 64;
+    GemmBGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int tiles = 0;
+    bool big = true;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        GemmBDev& d = g.p[i];
+        d.A = (const unsigned short*)s.A; d.B = (const unsigned short*)s.B; d.C = s.C; d.bias = s.bias;
+        d.aux0 = s.aux0; d.partial = s.partial; d.slab_stride = s.slab_stride;
+        d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.aux_ld = s.aux_ld;
+        d.splitk = s.splitk < 1 ? 1 : s.splitk;
+        int kc = (s.K + d.splitk - 1) / d.splitk;
+        kc = ((kc + BK - 1) / BK) * BK;
+        d.kchunk = kc;
+        d.tiles_m = (s.M + BM - 1) / BM;
+        d.tiles_n = (s.N + BN - 1) / BN;
+        d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        tiles += d.n_tiles;
+        d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
+        if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
+    }
+    if (tiles == 0) return 0;
+    if (big)
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 0, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+    return jamie_launch_status("jamie_gemm_bf16");
+}
+
+static const int BT[12][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
-static int pick_cfg_b(int max_m, int max_n) { (void)max_m; (void)max_n; return 1; }
+// ... and the LDS-DMA variants beat the register-staged one: 3 LDS buffers (cfg 7) when every problem has a long K
+// (forward / dX: 36 vs 40 us cold), 2 buffers (cfg 10) when K is the batch (dW, K = 512: 8 k-steps only)
+static int pick_cfg_b(int max_m, int max_n, int min_k) { (void)max_m; (void)max_n; return min_k >= 1000 ? 7 : 10; }
 
 extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg, void* stream) {
     JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
-    int max_m = 0, max_n = 0;
+    int max_m = 0, max_n = 0, min_k = 1 << 30;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];
         JAMIE_ARG(s.A && s.B && s.C, "null operand");
         JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
         JAMIE_ARG(s.ldc >= s.N && s.lda >= s.K && s.ldb >= s.K, "leading dimensions");
+        if (s.K < min_k) min_k = s.K;
         JAMIE_ARG(s.K % 8 == 0 && s.lda % 8 == 0 && s.ldb % 8 == 0, "bf16 operands need K, lda, ldb multiples of 8");
         JAMIE_ARG(((uintptr_t)s.A % 16) == 0 && ((uintptr_t)s.B % 16) == 0, "bf16 operands must be 16-byte aligned");
         JAMIE_ARG(((long long)(s.M - 1) * s.lda + s.K) * 2 < 0xFFFFFFF0LL && ((long long)(s.N - 1) * s.ldb + s.K) * 2 < 0xFFFFFFF0LL,
@@ -273,7 +526,7 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         if (s.N > max_n) max_n = s.N;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (cfg < 0) cfg = pick_cfg_b(max_m, max_n);
+    if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, min_k);
     switch (cfg) {
         case 0: return launch_b<128, 128, 64, 2, 2, 2>(pr, count, st);
         case 1: return launch_b<64, 64, 64, 2, 2, 3>(pr, count, st);
@@ -282,13 +535,18 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         case 4: return launch_b<64, 64, 64, 2, 2, 1>(pr, count, st);
         case 5: return launch_b<64, 64, 64, 2, 2, 2>(pr, count, st);
         case 6: return launch_b<64, 64, 64, 2, 2, 4>(pr, count, st);
+        case 7: return launch_dma<64, 64, 2, 2, 3>(pr, count, st);
+        case 8: return launch_dma<64, 64, 2, 2, 4>(pr, count, st);
+        case 9: return launch_dma<128, 64, 2, 2, 3>(pr, count, st);
+        case 10: return launch_dma<64, 64, 2, 2, 2>(pr, count, st);
+        case 11: return launch_dma<128, 64, 2, 2, 4>(pr, count, st);
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
 }
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
-    if (cfg < 0) cfg = pick_cfg_b(max_m, max_n);
-    if (cfg > 6 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
+    if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, 1 << 30);
+    if (cfg > 11 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
     *bm = BT[cfg][0]; *bn = BT[cfg][1];
     return 0;
 }

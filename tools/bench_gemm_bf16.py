@@ -29,7 +29,7 @@ cases = [('fwd d->2d ', [(B, 2 * x, x) for x in d]), ('fwd 2d->d ', [(B, x, 2 * 
          ('dW  2dxd  ', [(2 * x, x, B) for x in d]), ('dW  dx2d  ', [(x, 2 * x, B) for x in d]),
          ('dX  2d->d ', [(B, x, 2 * x) for x in d])]
 for name, shapes in cases:
-    for cfg in (1, 2, 3):
+    for cfg in [int(c) for c in os.environ.get('CFGS', '1').split(',')]:
         for sk in (1, 2, 4):
             if 'dW' in name and sk > 1: continue
             ms, tf = run(shapes, cfg, sk)
