@@ -30,7 +30,7 @@ struct GemmBDev {
     long long slab_stride;
     int M, N, K, lda, ldb, ldc, aux_ld;
     int splitk, kchunk, tiles_m, tiles_n, n_tiles;
-    int epi, accumulate;
+    int epi, accumulate, vec;
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
 // N = 4 glds per wave x DMA tiles younger than the one about to be read (cdna_hip_programming.md 'Pipelining across
 // barriers').  One barrier per k-step: it publishes tile kt (every wave waited for its own pieces) and frees buffer
 // (kt-1) % NB, into which tile kt+NB-1 is then issued.
-template <int BM, int BN, int WM, int WN, int TAG, int NB>
+template <int BM, int BN, int WM, int WN, int TAG, int NB, int ILV>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup g) {
     constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -250,8 +250,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
     static_assert(PA >= 1 && PB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
     // ONE __shared__ object: a second one beside an LDS-DMA staging array makes hipcc drain vmcnt(0) before the
     // first ds_read of every k-step (cdna_hip_programming.md, 'Three .s-level traps' (a)); `red` is carved from it
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * (A_SZ + B_SZ) + 64];
-    float* red = reinterpret_cast<float*>(smem + NB * (A_SZ + B_SZ));
+    // (over buffer 0: it is only used after the last k-step's barrier), so NB x 32 KiB tiles can fill the 160 KiB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * (A_SZ + B_SZ)];
+    float* red = reinterpret_cast<float*>(smem);
 
     // ---- block -> (problem, tile): per-problem XCD chunks (see gemm_f32.hip) ----
     const int bid = blockIdx.x;
@@ -308,18 +309,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
     const int nfull = (kend - kbeg) / BK;
     typedef const void __attribute__((address_space(1)))* gptr_t;
     typedef void __attribute__((address_space(3)))* lptr_t;
-    auto stage = [&](int buf, int kt) {
+    // part < 0: the whole tile; part = 0..3 (ILV): the quarter of this wave's pieces issued inside MFMA sub-step `part`
+    auto stage = [&](int buf, int kt, int part) {
         unsigned char* As = smem + buf * (A_SZ + B_SZ);
         unsigned char* Bs = As + A_SZ;
         const int k0 = kbeg + kt * BK;
         if (kt < nfull) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + a_dst[i]), 16, 0, 0);
+                if (part < 0 || (i & 3) == part)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + a_dst[i]), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0), (lptr_t)(Bs + b_dst[i]), 16, 0, 0);
-        } else {   // partial k-tile: masked loads through registers into the same swizzled image
+                if (part < 0 || ((i + PA) & 3) == part)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0), (lptr_t)(Bs + b_dst[i]), 16, 0, 0);
+        } else if (part <= 0) {   // partial k-tile: masked loads through registers into the same swizzled image
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
                 const int f = tid + j * NT, row = f >> 3, c = f & 7;
@@ -349,11 +353,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
 
     const int swz = (r >> 1) & 7;
     constexpr int GL = PA + PB;                       // glds instructions per wave and tile
-    static_assert(GL * (NB - 1) <= 60, "vmcnt immediate");
+    static_assert(GL * (NB - 1) <= 60 && NB <= 6, "vmcnt immediate");
     // prologue: tiles 0 .. NB-2 in flight
 #pragma unroll
     for (int u = 0; u < NB - 1; ++u)
-        if (u < nk) stage(u, u);
+        if (u < nk) stage(u, u, -1);
     for (int kt = 0; kt < nk; ++kt) {
         // wait for MY pieces of tile kt: DMA tiles younger than kt that are already issued = tiles kt+1 .. kt+NB-2
         // (only full tiles are DMA; a partial last tile went through registers and was waited for by the compiler)
@@ -361,11 +365,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
         if (kt >= nfull || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GL) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 4 ? 3 * GL : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 5 ? 4 * GL : 0) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + NB - 1 < nk) stage((kt + NB - 1) % NB, kt + NB - 1);
+        const bool more = kt + NB - 1 < nk;
+        if (!ILV && more && JAMIE_GEMMB_ABL != 7) stage((kt + NB - 1) % NB, kt + NB - 1, -1);
         const int cur = kt % NB;
         const unsigned char* As = smem + cur * (A_SZ + B_SZ);
         const unsigned char* Bs = As + A_SZ;
@@ -382,14 +388,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
         read_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
+            // the prefetch goes AFTER the first MFMA of the sub-step: hipcc puts an uncounted lgkmcnt(0) before that MFMA
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
+            if (JAMIE_GEMMB_ABL != 6 || (kt == 0 && s == 0))
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][0], bf[s & 1][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < BK / 16 && JAMIE_GEMMB_ABL != 6) read_frags((s + 1) & 1, s + 1);
+            if (ILV && more) stage((kt + NB - 1) % NB, kt + NB - 1, s);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                    if (i + j > 0 && (JAMIE_GEMMB_ABL != 6 || (kt == 0 && s == 0)))
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();
@@ -398,6 +410,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
     float* Cout = P.C + (long long)ks * P.slab_stride;
     const bool add_bias = (P.bias != nullptr) && ks == 0;
     float local = 0.f;
+#if JAMIE_GEMMB_ABL == 5
+    {   // diagnostic: no output stores (one conditional store keeps the accumulators alive)
+        float tot = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int e = 0; e < 16; ++e) tot += acc[i][j][e];
+        if (tot == 123.456f) Cout[0] = tot;
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + j * 32 + r;
@@ -418,6 +438,240 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
                     const float d = v - P.aux0[(long long)m * P.aux_ld + n];
                     local += d * d;
                     *cp = d * P.scale;
+                }
+            }
+        }
+    }
+    if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Second LDS-DMA kernel, for the LARGE tiles (256x128 / 128x128 with 64x64 per wave).  Ablations of the kernel above
+// (tools/ablate_gemm_bf16_epi.sh: DMA only / MFMA only / no stores) show (a) global -> LDS moves ~27 B/clk/CU
+// (62-66 GB/s per CU, ~17 TB/s chip-wide) whatever the tile, so the time of a product is (A + B bytes pulled into the
+// CUs) / 17 TB/s: only a larger tile lowers it (256x128 pulls 3/8 of the bytes of 64x64); (b) with one barrier at the
+// top of every k-step the first fragment reads of a tile have no MFMA to hide behind (8 waves: 1570 instead of 1024
+// cycles per k-step); (c) the dword stores of the C/D map (2 x 128 B per instruction) cost 7 us for a 256x128 tile.
+// Hence: the barrier that publishes tile kt+1 sits inside the LAST sub-step of tile kt, followed by the DMA issue of
+// tile kt+NB and the first fragment reads of tile kt+1, all of it covered by that sub-step's MFMAs; and the MFMA
+// operands are swapped (D = W-fragment x a-fragment), which transposes the accumulator map: a lane then holds 4
+// CONSECUTIVE n for one m, stored as one 16-byte access (4x fewer store instructions).
+template <int BM, int BN, int WM, int WN, int TAG, int NB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup g) {
+    constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_SZ = BM * 128, B_SZ = BN * 128, T_SZ = A_SZ + B_SZ;
+    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB pieces per wave
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;    // 16-byte chunks per thread (register tail path)
+    constexpr int GL = PA + PB;
+    static_assert(PA >= 1 && PB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+    static_assert(GL * (NB - 1) <= 63 && NB >= 2 && NB <= 4, "vmcnt immediate");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * T_SZ];
+    float* red = reinterpret_cast<float*>(smem);
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    int pi = 0, t = 0, rot = 0;
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+        if (i < g.count) {
+            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
+            const int j = (xcd - rot) & 7;
+            const int cp = qp + (j < rp ? 1 : 0);
+            if (slot >= 0 && slot < cp) {
+                pi = i;
+                t = j * qp + min(j, rp) + slot;
+                slot = -1;
+            } else if (slot >= 0) {
+                slot -= cp;
+            }
+            rot = (rot + rp) & 7;
+        }
+    }
+    const GemmBDev& P = g.p[pi];
+    const int tm_i = t % P.tiles_m;
+    const int tn_i = (t / P.tiles_m) % P.tiles_n;
+    const int ks = t / (P.tiles_m * P.tiles_n);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int kbeg = ks * P.kchunk;
+    const int kend = min(P.K, kbeg + P.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nfull = (kend - kbeg) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
+    const int r = lane & 31, h = lane >> 5;
+    const int lrow = lane >> 3, pch = lane & 7;
+    const unsigned short* a_src[PA]; const unsigned short* b_src[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = 8 * (wid + NW * i) + lrow;
+        a_src[i] = P.A + (long long)min(m0 + row, P.M - 1) * P.lda + ((pch ^ ((row >> 1) & 7)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = 8 * (wid + NW * i) + lrow;
+        b_src[i] = P.B + (long long)min(n0 + row, P.N - 1) * P.ldb + ((pch ^ ((row >> 1) & 7)) * 8);
+    }
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto stage = [&](int buf, int kt) {
+        unsigned char* As = smem + buf * T_SZ;
+        unsigned char* Bs = As + A_SZ;
+        const int k0 = kbeg + kt * BK;
+        if (kt < nfull) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
+        } else {   // partial k-tile: masked loads through registers into the same swizzled image
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int f = tid + j * NT, row = f >> 3, c = f & 7;
+                const int gm = min(m0 + row, P.M - 1);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.A + (long long)gm * P.lda + k0 + c * 8);
+                *reinterpret_cast<uint4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const int f = tid + j * NT, row = f >> 3, c = f & 7;
+                const int gn = min(n0 + row, P.N - 1);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.B + (long long)gn * P.ldb + k0 + c * 8);
+                *reinterpret_cast<uint4*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+        }
+    };
+    // my pieces of tile `tile` have landed; `last` = youngest tile issued so far (only full tiles are DMA)
+    auto wait_tile = [&](int tile, int last) {
+        const int younger = (tile >= nfull) ? 0 : max(0, min(last, nfull - 1) - tile);
+        if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 2 ? 2 * GL : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 3 ? 3 * GL : 0) : "memory");
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int swz = (r >> 1) & 7;
+    bf16x8 af[2][TM], bf[2][TN];
+    auto read_frags = [&](const unsigned char* As, int fb, int s) {
+        const unsigned char* Bs = As + A_SZ;
+        const int off = ((2 * s + h) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[fb][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * 128 + off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bf[fb][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * 128 + off);
+    };
+
+    // prologue: every buffer in flight, then tile 0 published and its first fragments read
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+        if (u < nk) stage(u, u);
+    wait_tile(0, min(NB, nk) - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* As = smem + cur * T_SZ;
+        const int nxt = (cur + 1 == NB) ? 0 : cur + 1;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            // hipcc waits lgkmcnt(0) (not a counted wait) before the first MFMA of a sub-step while LDS-DMA is
+            // pending, so the prefetch of the next fragments is issued AFTER that MFMA: the wait then only covers
+            // reads that have had a whole sub-step to land
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s & 1][0], af[s & 1][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < BK / 16) {
+                read_frags(As, (s + 1) & 1, s + 1);
+            } else if (kt + 1 < nk) {
+                // tile kt+1 becomes visible and buffer `cur` free (every wave holds its last fragments of tile kt in
+                // registers: lgkmcnt(0)); tile kt+NB goes into it and the first fragments of tile kt+1 are fetched
+                // under the MFMAs of this sub-step
+                wait_tile(kt + 1, min(kt + NB - 1, nk - 1));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + NB < nk) stage(cur, kt + NB);
+                read_frags(smem + nxt * T_SZ, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (i + j > 0)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
+        }
+        cur = nxt;
+    }
+    __syncthreads();
+
+    // ---- epilogue: transposed C/D map -> m = lane & 31, n = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) ----
+    float* Cout = P.C + (long long)ks * P.slab_stride;
+    const bool add_bias = (P.bias != nullptr) && ks == 0;
+    float local = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + r;
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = n0 + wn0 + j * 32 + 8 * q + 4 * h;
+                if (n4 >= P.N) continue;
+                float* cp = Cout + (long long)m * P.ldc + n4;
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (P.vec && n4 + 3 < P.N) {
+                    if (add_bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + n4);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    }
+                    if (P.epi == JAMIE_EPI_STORE) {
+                        if (P.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(cp);
+                            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                        }
+                    } else {  // JAMIE_EPI_MSE
+                        const float4 x = *reinterpret_cast<const float4*>(P.aux0 + (long long)m * P.aux_ld + n4);
+                        v[0] -= x.x; v[1] -= x.y; v[2] -= x.z; v[3] -= x.w;
+                        local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                        v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
+                    }
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n4 + e >= P.N) continue;
+                        float w = v[e] + (add_bias ? P.bias[n4 + e] : 0.f);
+                        if (P.epi == JAMIE_EPI_STORE) {
+                            if (P.accumulate) w += cp[e];
+                            cp[e] = w;
+                        } else {
+                            const float d = w - P.aux0[(long long)m * P.aux_ld + n4 + e];
+                            local += d * d;
+                            cp[e] = d * P.scale;
+                        }
+                    }
                 }
             }
         }
@@ -462,7 +716,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-template <int BM, int BN, int WM, int WN, int NB>
+template <int BM, int BN, int WM, int WN, int NB, int ILV = 0, int V2 = 0>
 static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     constexpr int BK = 64;
     GemmBGroup g;
@@ -488,14 +742,30 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
     if (tiles == 0) return 0;
+    if constexpr (V2) {
+        for (int i = 0; i < count; ++i) {
+            const jamie_gemm_problem& s = pr[i];
+            g.p[i].vec = (s.ldc % 4 == 0) && ((uintptr_t)s.C % 16 == 0) && (s.slab_stride % 4 == 0) &&
+                         (!s.bias || (uintptr_t)s.bias % 16 == 0) &&
+                         (s.epi != JAMIE_EPI_MSE || (s.aux_ld % 4 == 0 && (uintptr_t)s.aux0 % 16 == 0));
+        }
+        if (big)
+            hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+        else
+            hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 0, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+        return jamie_launch_status("jamie_gemm_bf16");
+    }
     if (big)
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 1, NB, ILV>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 0, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 0, NB, ILV>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-static const int BT[12][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64}};
+static const int BT[29][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
+                              {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128},
+                              {64, 64}, {128, 128}, {256, 128}, {256, 128}, {64, 64},
+                              {256, 128}, {128, 128}, {128, 128}, {128, 256}, {64, 64}, {256, 256}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
@@ -540,13 +810,30 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         case 9: return launch_dma<128, 64, 2, 2, 3>(pr, count, st);
         case 10: return launch_dma<64, 64, 2, 2, 2>(pr, count, st);
         case 11: return launch_dma<128, 64, 2, 2, 4>(pr, count, st);
+        case 12: return launch_dma<128, 128, 2, 2, 2>(pr, count, st);
+        case 13: return launch_dma<128, 128, 2, 2, 3>(pr, count, st);
+        case 14: return launch_dma<128, 128, 2, 4, 3>(pr, count, st);
+        case 15: return launch_dma<256, 128, 2, 4, 2>(pr, count, st);
+        case 16: return launch_dma<128, 128, 2, 4, 4>(pr, count, st);
+        case 17: return launch_dma<128, 128, 2, 4, 5>(pr, count, st);
+        case 18: return launch_dma<64, 64, 2, 2, 3, 1>(pr, count, st);
+        case 19: return launch_dma<128, 128, 2, 4, 3, 1>(pr, count, st);
+        case 20: return launch_dma<256, 128, 4, 2, 3>(pr, count, st);
+        case 21: return launch_dma<256, 128, 4, 2, 3, 1>(pr, count, st);
+        case 22: return launch_dma<64, 64, 2, 2, 2, 1>(pr, count, st);
+        case 23: return launch_dma<256, 128, 4, 2, 3, 0, 1>(pr, count, st);
+        case 24: return launch_dma<128, 128, 2, 2, 3, 0, 1>(pr, count, st);
+        case 25: return launch_dma<128, 128, 2, 2, 2, 0, 1>(pr, count, st);
+        case 26: return launch_dma<128, 256, 2, 4, 3, 0, 1>(pr, count, st);
+        case 27: return launch_dma<64, 64, 2, 2, 3, 0, 1>(pr, count, st);
+        case 28: return launch_dma<256, 256, 4, 4, 2, 0, 1>(pr, count, st);
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
 }
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, 1 << 30);
-    if (cfg > 11 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
+    if (cfg > 28 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
     *bm = BT[cfg][0]; *bn = BT[cfg][1];
     return 0;
 }

@@ -33,6 +33,42 @@ def choose_splitk(M, N, K, bm=64, bn=64):
     return int(max(1, min(s, K // (512 if N > 64 else 256))))
 
 
+# ---- bf16 GEMM launch plans (tile configuration + per-problem split-K), from tools/bench_gemm_bf16.py ----
+# The LDS-DMA kernels pull ~17 TB/s from L2 chip-wide whatever the tile (DESIGN.md, bf16 GEMM), so a product's time
+# is the A+B bytes pulled into the CUs: a 256x128 / 128x128 tile moves 3/8 / 1/2 of the bytes of 64x64, but at
+# M = batch = 512 it only fills the 256 CUs when K is split.  Deterministic rules (no run-time tuning: split-K
+# changes the summation order):
+#   rows launch  ([B, N_i] = [B, K_i] x [N_i, K_i]^T, forward and dX):  256x128 tiles when every N_i >= K_i (d -> 2d),
+#                 else 128x128; slices proportional to K_i such that the launch has ~one workgroup per CU
+#                 (config 2: (3, 2) slices -> 256 workgroups; 37.5 -> 30.5 us and 34.2 -> 26.7 us per launch)
+#   dW (+ dX) grouped launch: 128x128 tiles, two LDS buffers (two workgroups per CU); dX slices ~ K_i / 1000
+BF16_CFG_ROWS_WIDE, BF16_CFG_ROWS, BF16_CFG_DW = 23, 24, 25
+BF16_TILE = {23: (256, 128), 24: (128, 128), 25: (128, 128)}
+N_CU = 256
+
+
+def _big_enough(B, shapes):
+    return B >= 128 and all(N >= 256 and K >= 256 for (N, K) in shapes)
+
+
+def plan_bf16_rows(B, shapes):
+    """shapes = [(N_i, K_i)] of one forward / dX launch -> (cfg, [splitk_i]); cfg -1 = the library default."""
+    if not _big_enough(B, shapes):
+        return -1, [choose_splitk(B, N, K) for (N, K) in shapes]
+    cfg = BF16_CFG_ROWS_WIDE if (B >= 256 and all(N >= K for (N, K) in shapes)) else BF16_CFG_ROWS
+    bm, bn = BF16_TILE[cfg]
+    tk = sum(math.ceil(B / bm) * math.ceil(N / bn) * K for (N, K) in shapes)
+    c = N_CU / tk
+    return cfg, [int(max(1, min(round(c * K), 8, K // 256))) for (N, K) in shapes]
+
+
+def plan_bf16_bwd(B, shapes):
+    """shapes = [(N_i, K_i)] of the dX problems grouped with their dW problems -> (cfg, [splitk_i of the dX])."""
+    if not _big_enough(B, shapes):
+        return -1, [choose_splitk(B, N, K) for (N, K) in shapes]
+    return BF16_CFG_DW, [int(max(1, min(round(K / 1000), 4, K // 256))) for (N, K) in shapes]
+
+
 def kl_anneal(epoch, min_epochs, epoch_DNN):
     """jamie.py:630-631."""
     c = (min_epochs / 2) if min_epochs > 0 else (epoch_DNN / 2)
@@ -92,6 +128,18 @@ class TrainEngine:
         # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
         sk_head = min(choose_splitk(B, 2 * L, d) for d in self.dims)
         sk_dcomb = min(choose_splitk(B, L, d) for d in self.dims)
+        # bf16: tile configuration of every large launch + per-modality slab counts (plan_bf16_*)
+        self.gcfg, plan_sk = {}, {}
+        if self.bf16:
+            grouped = 2 * self.M <= nv.MAX_GROUP
+            for key, shp, bwd in (('enc0', [(2 * d, d) for d in self.dims], False),
+                                  ('enc1', [(d, 2 * d) for d in self.dims], False),
+                                  ('dec1', [(2 * d, d) for d in self.dims], False),
+                                  ('d_e2', [(2 * d, d) for d in self.dims], True),
+                                  ('d_e1', [(d, 2 * d) for d in self.dims], True),
+                                  ('d_a1', [(2 * d, d) for d in self.dims], True)):
+                self.gcfg[key], plan_sk[key] = (plan_bf16_bwd if (bwd and grouped) else plan_bf16_rows)(B, shp)
+            self.gcfg['dw'] = BF16_CFG_DW if _big_enough(B, [(d, d) for d in self.dims]) else -1
         for i, d in enumerate(self.dims):
             w = {}
             sk = {'enc0': choose_splitk(B, 2 * d, d), 'enc1': choose_splitk(B, d, 2 * d),
@@ -101,6 +149,8 @@ class TrainEngine:
                   'd_comb': sk_dcomb,                     # dg1p   D1   : [B,d]  x [d,L]
                   'd_a2': 1,                              # dml    Wh   : [B,2L] x [2L,d]
                   'd_a1': choose_splitk(B, 2 * d, d)}     # dh2p   W2   : [B,d]  x [d,2d]
+            for key, v in plan_sk.items():
+                sk[key] = v[i]
             w['sk'] = sk
             w['x'] = torch.empty(B, d, **f32)
             w['h1'] = torch.empty(sk['enc0'], B, 2 * d, **f32); w['a1'] = torch.empty(B, 2 * d, **f32)
@@ -277,8 +327,9 @@ class TrainEngine:
             probs.append(nv.gemm_problem(a, W, out, self.B, nout, nin, nin, nin, nout,
                                          bias=P[f'm{i}.{lin}.b'] if with_bias else None,
                                          splitk=w['sk'][sk_key], slab_stride=self.B * nout))
+        cfg = self.gcfg.get(sk_key, -1)
         self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') else lin,
-                     (lambda: nv.gemm_bf16(probs)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
+                     (lambda: nv.gemm_bf16(probs, cfg)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
 
     def _dx_gemm(self, dy_key, lin, out_key, sk_key):
         """dx[B, in_f] (slabs) = dy[B, out_f] W."""
@@ -294,7 +345,7 @@ class TrainEngine:
                 probs.append(nv.gemm_problem(dy, W, out, self.B, nin, nout, nout, nin, nin,
                                              splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         if self.bf16:
-            nv.gemm_bf16(probs)
+            nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
         else:
             nv.gemm(probs, nv.NN)
 
@@ -311,7 +362,8 @@ class TrainEngine:
             else:
                 probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
         if self.bf16:
-            nv.gemm_bf16(probs)
+            big = all(min(self.g[f'm{i}.{lin}.W'].shape) >= 256 for i in range(self.M))
+            nv.gemm_bf16(probs, self.gcfg['dw'] if big else -1)
         else:
             nv.gemm(probs, nv.TN)
 
@@ -334,7 +386,7 @@ class TrainEngine:
             nout, nin = self.g[f'm{i}.{lin}.W'].shape
             probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
                                          nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
-        nv.gemm_bf16(probs)
+        nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
         """M > 2: fully paired cells only (identity correspondence, F = 0, euclidean alignment)."""

@@ -487,7 +487,7 @@ def test_cast_transpose(nv, R, C, nslab):
 
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (512, 256, 128), (128, 72, 200), (40, 136, 24), (512, 64, 1000),
                                    (130, 264, 264), (256, 1000, 512)])
-@pytest.mark.parametrize('cfg', [-1, 0, 1, 2, 3, 4, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28])
 def test_gemm_bf16(nv, M, N, K, cfg):
     g = torch.Generator().manual_seed(M + N + K)
     a, w, bias = _bf16(torch.randn(M, K, generator=g)), _bf16(torch.randn(N, K, generator=g)), torch.randn(N, generator=g)
