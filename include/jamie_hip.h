@@ -97,6 +97,19 @@ typedef struct {
 } jamie_cast_problem;
 int jamie_cast_transpose(const jamie_cast_problem* problems /*host*/, int count /* <= 16 */, void* stream);
 
+/* Reconstruction loss (jamie.py:637-641) behind a split-K x_hat GEMM: y = sum of `nslab` slabs [R, C] (contiguous,
+ * bias already added by the GEMM), d = (y - x) * scale -> fp32 [R, C] and optional bf16 [R, C] / bf16 [C, R] copies;
+ * partial[t] = pscale * sum (y - x)^2 over 64x64 tile t (tile index = m_tile + tiles_m * n_tile, the order of the
+ * 64x64 GEMM's fused MSE epilogue), ceil(R/64) * ceil(C/64) partials per problem. */
+typedef struct {
+    const float* y; const float* x; float* d;
+    void* d_bf16; void* dT_bf16;        /* optional */
+    float* partial;                     /* optional */
+    int R, C, nslab; long long slab_stride;
+    float scale, pscale;
+} jamie_mse_problem;
+int jamie_mse_cast(const jamie_mse_problem* problems /*host*/, int count /* <= JAMIE_MAX_GROUP */, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d(train) + LeakyReLU + Dropout, forward and backward, one column strip per workgroup.
  * Replaces native_batch_norm / leaky_relu / bernoulli_ + mul (model.py:152-154,162-164,193-195,198-200)

@@ -36,6 +36,12 @@ class CastProblem(C.Structure):
                 ('nslab', C.c_int), ('slab_stride', C.c_longlong)]
 
 
+class MseProblem(C.Structure):
+    _fields_ = [('y', C.c_void_p), ('x', C.c_void_p), ('d', C.c_void_p), ('d_bf16', C.c_void_p), ('dT_bf16', C.c_void_p),
+                ('partial', C.c_void_p), ('R', C.c_int), ('C', C.c_int), ('nslab', C.c_int),
+                ('slab_stride', C.c_longlong), ('scale', C.c_float), ('pscale', C.c_float)]
+
+
 class ColsumProblem(C.Structure):
     _fields_ = [('X', C.c_void_p), ('out', C.c_void_p), ('M', C.c_int), ('N', C.c_int), ('ld', C.c_int),
                 ('nslab', C.c_int), ('slab_stride', C.c_longlong), ('accumulate', C.c_int)]
@@ -102,6 +108,7 @@ EXPORTS = {
     'jamie_gemm_bf16': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
     'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'jamie_cast_transpose': (C.c_int, [C.POINTER(CastProblem), C.c_int, C.c_void_p]),
+    'jamie_mse_cast': (C.c_int, [C.POINTER(MseProblem), C.c_int, C.c_void_p]),
     'jamie_bn_act_fwd': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_void_p]),
     'jamie_bn_act_bwd': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -268,6 +275,22 @@ def cast_problem(src, dst=None, dstT=None, nslab=1, slab_stride=0):
     p.R, p.C, p.ld, p.ldd, p.ldt, p.nslab, p.slab_stride = R, Cc, Cc, Cc, R, nslab, slab_stride
     p._keep = (src, dst, dstT)
     return p
+
+
+def mse_problem(y, x, d, d_bf16=None, dT_bf16=None, partial=None, scale=1.0, pscale=1.0):
+    """y [nslab, R, C] fp32 slabs (contiguous), x / d [R, C] fp32, optional bf16 [R, C] / [C, R] copies of d."""
+    p = MseProblem()
+    nslab = y.shape[0] if y.dim() == 3 else 1
+    R, Cc = x.shape
+    p.y, p.x, p.d, p.d_bf16, p.dT_bf16, p.partial = ptr(y), ptr(x), ptr(d), ptr(d_bf16), ptr(dT_bf16), ptr(partial)
+    p.R, p.C, p.nslab, p.slab_stride, p.scale, p.pscale = R, Cc, nslab, R * Cc, scale, pscale
+    p._keep = (y, x, d, d_bf16, dT_bf16, partial)
+    return p
+
+
+def mse_cast(problems):
+    arr = (MseProblem * len(problems))(*problems)
+    _call('jamie_mse_cast', arr, len(problems), _stream())
 
 
 def cast_transpose(problems):

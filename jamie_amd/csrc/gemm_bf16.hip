@@ -935,3 +935,108 @@ extern "C" int jamie_cast_transpose(const jamie_cast_problem* pr, int count, voi
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     return jamie_launch_status("jamie_cast_transpose");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Reconstruction loss behind a split-K x_hat GEMM (jamie.py:637-641): y = sum of the slabs (bias already in slab 0),
+// d = y - x, partial[tile] = pscale * sum d^2 per 64x64 tile (same tiling / partial count as the fused MSE epilogue
+// of the 64x64 GEMM), and d * scale written as fp32 [R, C] plus the bf16 / bf16-transposed copies the backward
+// products read.  Same 64x64 LDS-transposing layout as cast_transpose_kernel.
+// ------------------------------------------------------------------------------------------------
+struct MseDev { const float* y; const float* x; float* d; unsigned short* dst; unsigned short* dstT; float* partial;
+                long long slab_stride; int R, C, nslab, blk_begin, tiles_c; float scale, pscale; };
+struct MseGroup { MseDev p[JAMIE_MAX_GROUP]; int count; };
+
+__global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
+    __shared__ float tile[64][65];
+    __shared__ float red[4];
+    int pi = 0;
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
+    const MseDev& P = g.p[pi];
+    const int b = blockIdx.x - P.blk_begin;
+    const int r0 = (b % ((P.R + 63) / 64)) * 64, c0 = (b / ((P.R + 63) / 64)) * 64;   // tile order of the GEMM: m fastest
+    const int q = threadIdx.x & 15, rr0 = threadIdx.x >> 4;
+    const bool vec = (P.C % 4 == 0) && (P.slab_stride % 4 == 0);
+    float local = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int rr = rr0 + 16 * pass, r = r0 + rr, c = c0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < P.R && c < P.C) {
+            const long long o = (long long)r * P.C + c;
+            if (vec) {
+                for (int s = 0; s < P.nslab; ++s) {
+                    const float4 u = *reinterpret_cast<const float4*>(P.y + s * P.slab_stride + o);
+                    v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+                }
+                const float4 x = *reinterpret_cast<const float4*>(P.x + o);
+                v[0] -= x.x; v[1] -= x.y; v[2] -= x.z; v[3] -= x.w;
+                local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
+                *reinterpret_cast<float4*>(P.d + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (P.dst) {
+                    const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)v[0]), b1 = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
+                    const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)v[2]), b3 = __builtin_bit_cast(unsigned short, (__bf16)v[3]);
+                    *reinterpret_cast<uint2*>(P.dst + o) = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+                }
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    if (c + e >= P.C) continue;
+                    for (int s = 0; s < P.nslab; ++s) v[e] += P.y[s * P.slab_stride + o + e];
+                    v[e] -= P.x[o + e];
+                    local += v[e] * v[e];
+                    v[e] *= P.scale;
+                    P.d[o + e] = v[e];
+                    if (P.dst) P.dst[o + e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
+                }
+            }
+        }
+        tile[rr][4 * q] = v[0]; tile[rr][4 * q + 1] = v[1]; tile[rr][4 * q + 2] = v[2]; tile[rr][4 * q + 3] = v[3];
+    }
+    const float tot = block_sum(local, red);
+    if (threadIdx.x == 0 && P.partial) P.partial[b] = tot * P.pscale;
+    if (!P.dstT) return;
+    __syncthreads();
+    const bool vect = (P.R % 4 == 0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int cc = rr0 + 16 * pass, c = c0 + cc, r = r0 + 4 * q;
+        if (c >= P.C) continue;
+        const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q][cc]);
+        const unsigned short b1 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + 1][cc]);
+        const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + 2][cc]);
+        const unsigned short b3 = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + 3][cc]);
+        unsigned short* dp = P.dstT + (long long)c * P.R + r;
+        if (vect && r + 3 < P.R) {
+            *reinterpret_cast<uint2*>(dp) = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+        } else {
+            if (r < P.R) dp[0] = b0;
+            if (r + 1 < P.R) dp[1] = b1;
+            if (r + 2 < P.R) dp[2] = b2;
+            if (r + 3 < P.R) dp[3] = b3;
+        }
+    }
+}
+
+extern "C" int jamie_mse_cast(const jamie_mse_problem* pr, int count, void* stream) {
+    JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
+    MseGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const jamie_mse_problem& s = pr[i];
+        JAMIE_ARG(s.y && s.x && s.d && s.R > 0 && s.C > 0 && s.nslab >= 1, "null pointer / empty problem");
+        JAMIE_ARG(((uintptr_t)s.y % 16) == 0 && ((uintptr_t)s.x % 16) == 0 && ((uintptr_t)s.d % 16) == 0 &&
+                      ((uintptr_t)s.d_bf16 % 8) == 0 && ((uintptr_t)s.dT_bf16 % 8) == 0,
+                  "y, x, d must be 16-byte aligned (bf16 outputs 8-byte)");
+        MseDev& d = g.p[i];
+        d.y = s.y; d.x = s.x; d.d = s.d; d.dst = (unsigned short*)s.d_bf16; d.dstT = (unsigned short*)s.dT_bf16;
+        d.partial = s.partial; d.slab_stride = s.slab_stride; d.R = s.R; d.C = s.C; d.nslab = s.nslab;
+        d.scale = s.scale; d.pscale = s.pscale;
+        d.blk_begin = blocks; d.tiles_c = (s.C + 63) / 64;
+        blocks += ((s.R + 63) / 64) * d.tiles_c;
+    }
+    hipLaunchKernelGGL(mse_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return jamie_launch_status("jamie_mse_cast");
+}

@@ -135,6 +135,7 @@ class TrainEngine:
             for key, shp, bwd in (('enc0', [(2 * d, d) for d in self.dims], False),
                                   ('enc1', [(d, 2 * d) for d in self.dims], False),
                                   ('dec1', [(2 * d, d) for d in self.dims], False),
+                                  ('dec2', [(d, 2 * d) for d in self.dims], False),
                                   ('d_e2', [(2 * d, d) for d in self.dims], True),
                                   ('d_e1', [(d, 2 * d) for d in self.dims], True),
                                   ('d_a1', [(2 * d, d) for d in self.dims], True)):
@@ -161,6 +162,8 @@ class TrainEngine:
             w['g1'] = torch.empty(1, B, d, **f32); w['e1'] = torch.empty(B, d, **f32)
             w['g2'] = torch.empty(sk['dec1'], B, 2 * d, **f32); w['e2'] = torch.empty(B, 2 * d, **f32)
             w['dxhat'] = torch.empty(B, d, **f32)
+            if self.gcfg.get('dec2', -1) >= 0:          # bf16: split-K x_hat slabs, MSE in jamie_mse_cast
+                w['xh'] = torch.empty(sk['dec2'], B, d, **f32)
             w['de2'] = torch.empty(sk['d_e2'], B, 2 * d, **f32)
             w['de1'] = torch.empty(sk['d_e1'], B, d, **f32)
             w['dcomb'] = torch.empty(sk['d_comb'] + 1, B, L, **f32)   # +1 slab: external d(combined) (autograd seam)
@@ -519,6 +522,17 @@ class TrainEngine:
                 if w['xhat'] is None:
                     w['xhat'] = torch.empty(1, B, d, device=self.dev, dtype=torch.float32)
             self._fwd_gemm('e2', 'dec2', 'xhat', 'dec0')
+            return lat
+        if self.bf16 and self.gcfg.get('dec2', -1) >= 0:                  # split-K x_hat GEMM, then MSE + casts
+            self._fwd_gemm('e2', 'dec2', 'xh', 'dec2')
+            probs, off = [], 0
+            for i, d in enumerate(self.dims):
+                w = self.ws[i]
+                probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w['dxhat_bf'], w['dxhat_T'],
+                                            partial=self.rec_partials[off:off + self.rec_tiles[i]],
+                                            scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
+                off += self.rec_tiles[i]
+            nv.mse_cast(probs)
             return lat
         probs, off = [], 0
         for i, d in enumerate(self.dims):                                 # x_hat GEMM + fused MSE

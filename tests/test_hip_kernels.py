@@ -530,3 +530,29 @@ def test_gemm_bf16_splitk_grouped_mse(nv):
     diff = e2.double() @ W.double().t() + b.double() - X.double()
     close(out, diff * 2.0 / (B * d), rtol=1e-5, atol=1e-7)
     close(part.sum(), (diff ** 2).mean(), rtol=1e-5, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,C,nslab', [(512, 2000, 3), (512, 1000, 2), (100, 72, 1), (65, 130, 2)])
+def test_mse_cast_matches_torch(nv, R, C, nslab):
+    """jamie_mse_cast: slab sum, (y - x) * scale in fp32 + bf16 + bf16 transposed, per-tile partial sums of squares
+    (reference jamie.py:637-641 behind a split-K x_hat GEMM)."""
+    torch.manual_seed(R + C)
+    y = torch.randn(nslab, R, C, device='cuda')
+    x = torch.randn(R, C, device='cuda')
+    d = torch.empty(R, C, device='cuda')
+    db = torch.empty(R, C, device='cuda', dtype=torch.bfloat16)
+    dT = torch.empty(C, R, device='cuda', dtype=torch.bfloat16)
+    ntile = ((R + 63) // 64) * ((C + 63) // 64)
+    part = torch.zeros(ntile, device='cuda')
+    scale, pscale = 2.0 / (R * C), 1.0 / (R * C)
+    nv.mse_cast([nv.mse_problem(y, x, d, db, dT, partial=part, scale=scale, pscale=pscale)])
+    torch.cuda.synchronize()
+    diff = y.sum(0) - x
+    assert torch.allclose(d, diff * scale, rtol=1e-6, atol=1e-9)
+    assert torch.equal(db, d.to(torch.bfloat16))
+    assert torch.equal(dT, d.to(torch.bfloat16).t().contiguous())
+    assert abs(part.sum().item() - (diff.double() ** 2).mean().item()) < 1e-5 * (diff.double() ** 2).mean().item()
+    # tile order: m fastest (the 64x64 GEMM's fused epilogue)
+    t0 = (diff[:64, :64].double() ** 2).sum().item() * pscale
+    assert abs(part[0].item() - t0) < 1e-5 * t0
