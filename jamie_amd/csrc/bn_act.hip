@@ -56,10 +56,13 @@ __device__ __forceinline__ unsigned buf_u8(__amdgpu_buffer_rsrc_t r, unsigned of
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
 }
 
-// Keep decision of element (row, col): Philox counter = (col, row % 16, row / 64), lane = (row / 16) % 4, i.e.
-// the four keep bits of one call belong to rows r, r+16, r+32, r+48 of one column (a thread's own rows).
-__device__ __forceinline__ Philox4 drop_rand(const uint64_t* rng, int stream, int col, int rp, int g) {
-    return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)col << 24) | ((uint64_t)rp << 16) | (uint64_t)g);
+// Keep decision of element (row, col): Philox counter = (col / 4, row), lane = col % 4, i.e. the four keep bits of
+// one call belong to the 4 consecutive columns a thread of the float4 kernels owns in one row.
+__device__ __forceinline__ Philox4 drop_rand4(const uint64_t* rng, int stream, int col, int row) {
+    return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)(col >> 2) << 32) | (uint64_t)(uint32_t)row);
+}
+__device__ __forceinline__ bool drop_keep(const uint64_t* rng, int stream, int col, int row, uint32_t thr) {
+    return drop_rand4(rng, stream, col, row).v[col & 3] >= thr;
 }
 
 // bf16 outputs of a cached strip (thread (c, rp) holds rows rp + 16 j of column c in val[j]):
@@ -173,12 +176,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
                 mk[j] = buf_u8(m_rs, (row < B && cok) ? (unsigned)row * (unsigned)N + (unsigned)col : BN_OOB);
             }
         }
-        Philox4 r;
-        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
 #pragma unroll
         for (int j = 0; j < BN_MAXR; ++j) {
             const int row = rp + j * BN_RP;
-            if (drop && !P.mask && (j & 3) == 0) r = drop_rand(rng, P.rng_stream, col, rp, j >> 2);
             float y = 0.f;
             if (row < B && cok) {
                 const long long o = (long long)row * N + col;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
                 y = (v[j] - mean) * invstd * ga + be;
                 y = y > 0.f ? y : slope * y;
                 if (drop) {
-                    const bool keep = P.mask ? (mk[j] != 0) : (r.v[j & 3] >= thr);
+                    const bool keep = P.mask ? (mk[j] != 0) : drop_keep(rng, P.rng_stream, col, row, thr);
                     y = keep ? y * keep_scale : 0.f;
                 }
                 if (P.out) P.out[o] = y;
@@ -207,10 +207,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
             float y = (hv - mean) * invstd * ga + be;
             y = y > 0.f ? y : slope * y;
             if (drop) {
-                const int j = row / BN_RP;
                 bool keep;
                 if (P.mask) keep = P.mask[o] != 0;
-                else keep = drop_rand(rng, P.rng_stream, col, rp, j >> 2).v[j & 3] >= thr;
+                else keep = drop_keep(rng, P.rng_stream, col, row, thr);
                 y = keep ? y * keep_scale : 0.f;
             }
             if (P.out) P.out[o] = y;
@@ -259,8 +258,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
         xn = (P.h[o] - mean) * invstd;
         bool keep = true;
         if (drop) {
-            const int j = row / BN_RP;
-            keep = P.mask ? (P.mask[o] != 0) : (drop_rand(rng, P.rng_stream, col, rp, j >> 2).v[j & 3] >= thr);
+            keep = P.mask ? (P.mask[o] != 0) : drop_keep(rng, P.rng_stream, col, row, thr);
         }
         dy = to_dy(d, xn, keep);
     };
@@ -290,13 +288,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
                 mk[j] = buf_u8(m_rs, (row < B && cok) ? (unsigned)row * (unsigned)N + (unsigned)col : BN_OOB);
             }
         }
-        Philox4 r;
-        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
 #pragma unroll
         for (int j = 0; j < BN_MAXR; ++j) {
             const int row = rp + j * BN_RP;
-            if (drop && !P.mask && (j & 3) == 0) r = drop_rand(rng, P.rng_stream, col, rp, j >> 2);
-            const bool keep = drop ? (P.mask ? (mk[j] != 0) : (r.v[j & 3] >= thr)) : true;
+            const bool keep = drop ? (P.mask ? (mk[j] != 0) : drop_keep(rng, P.rng_stream, col, row, thr)) : true;
             const bool ok = cok && row < B;
             const float xn = ok ? (xnv[j] - mean) * invstd : 0.f;
             xnv[j] = xn;
@@ -358,6 +353,301 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// float4 variants (N % 4 == 0, B <= 512: every training shape of the bf16 / fp32 step).  The dword-per-lane kernels
+// above move 256 B per wave-instruction and ran at 1.7-2 TB/s (rocprofv3, config 2: 23 us for ~40 MB): the
+// address path handles a wave-instruction in >= 16 cycles whatever its width.  Here a thread owns 4 consecutive
+// columns x 8 rows (rows rp + 64 j, rp = 0..63): 16-byte loads / stores (1 KiB per wave-instruction = 16 rows x 64 B),
+// two slabs in flight at a time, column sums by xor-shuffles over the 16 row phases of a wave + a 4-wave LDS step.
+// ------------------------------------------------------------------------------------------------
+#define BN4_RP 64
+#define BN4_MAXR 8
+typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const bn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ unsigned buf_u32(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ float4 col_reduce4(float4 v, float (*sh)[BN_CW], int tid) {
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+        v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
+    }
+    const int lane = tid & 63, wid = tid >> 6, cq = tid & 3;
+    __syncthreads();
+    if (lane < 4) { sh[wid][4 * lane] = v.x; sh[wid][4 * lane + 1] = v.y; sh[wid][4 * lane + 2] = v.z; sh[wid][4 * lane + 3] = v.w; }
+    __syncthreads();
+    float4 t;
+    t.x = sh[0][4 * cq] + sh[1][4 * cq] + sh[2][4 * cq] + sh[3][4 * cq];
+    t.y = sh[0][4 * cq + 1] + sh[1][4 * cq + 1] + sh[2][4 * cq + 1] + sh[3][4 * cq + 1];
+    t.z = sh[0][4 * cq + 2] + sh[1][4 * cq + 2] + sh[2][4 * cq + 2] + sh[3][4 * cq + 2];
+    t.w = sh[0][4 * cq + 3] + sh[1][4 * cq + 3] + sh[2][4 * cq + 3] + sh[3][4 * cq + 3];
+    return t;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+// bf16 outputs of a strip held as val[j] = 4 columns of row rp + 64 j
+__device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[BN4_MAXR], unsigned short* out_bf, unsigned short* outT_bf,
+                                                 unsigned short* tl, int B, int N, int col0, int cq, int rp, bool cok) {
+    const int col = col0 + 4 * cq;
+    if (out_bf && cok) {
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) {
+            const int row = rp + j * BN4_RP;
+            if (row < B)
+                *reinterpret_cast<uint2*>(out_bf + (long long)row * N + col) =
+                    make_uint2(pack_bf16x2(val[j].x, val[j].y), pack_bf16x2(val[j].z, val[j].w));
+        }
+    }
+    if (!outT_bf) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        const int row = rp + j * BN4_RP;
+        tl[(4 * cq) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].x);
+        tl[(4 * cq + 1) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].y);
+        tl[(4 * cq + 2) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].z);
+        tl[(4 * cq + 3) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + 256 * i, cc = q >> 6, r8 = (q & 63) * 8;
+        if (col0 + cc < N && r8 < B) {        // B is a multiple of 8 in bf16 mode
+            const unsigned* sp = reinterpret_cast<const unsigned*>(tl + cc * BN_TS + r8);
+            *reinterpret_cast<uint4*>(outT_bf + (long long)(col0 + cc) * B + r8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
+                                                          float slope, const uint64_t* rng) {
+    __shared__ float sh[4][BN_CW];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * BN_TS];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
+    const BnFwdDev& P = g.p[pi];
+    const int tid = threadIdx.x, cq = tid & 3, rp = tid >> 2;
+    const int col0 = ((int)blockIdx.x - P.blk_begin) * BN_CW, col = col0 + 4 * cq;
+    const bool cok = col < P.N;                       // N % 4 == 0: a quad is wholly in or out
+    const int B = P.B, N = P.N, nslab = P.nslab;
+    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.h, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
+    unsigned roff[BN4_MAXR];
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        const int row = rp + j * BN4_RP;
+        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
+    }
+    float4 v[BN4_MAXR];
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslab; s += 2) {
+        float4 a[BN4_MAXR], b[BN4_MAXR];
+        const bool two = s + 1 < nslab;
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) a[j] = buf_f32x4(h_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) {
+            v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w;
+            v[j].x += b[j].x; v[j].y += b[j].y; v[j].z += b[j].z; v[j].w += b[j].w;
+        }
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
+    float4 mean = col_reduce4(sum, sh, tid);
+    const float fB = (float)B;
+    mean.x /= fB; mean.y /= fB; mean.z /= fB; mean.w /= fB;
+    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        if (rp + j * BN4_RP < B) {
+            const float dx = v[j].x - mean.x, dy = v[j].y - mean.y, dz = v[j].z - mean.z, dw = v[j].w - mean.w;
+            sq.x += dx * dx; sq.y += dy * dy; sq.z += dz * dz; sq.w += dw * dw;
+        }
+    }
+    float4 var = col_reduce4(sq, sh, tid);
+    var.x /= fB; var.y /= fB; var.z /= fB; var.w /= fB;
+    const float4 invstd = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
+    float ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ga[e] = P.gamma[col + e]; be[e] = P.beta[col + e]; }
+        if (rp == 0) {
+            const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, vv[4] = {var.x, var.y, var.z, var.w};
+            const float iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                P.smean[col + e] = mv[e];
+                P.sinvstd[col + e] = iv[e];
+                const float unb = B > 1 ? vv[e] * ((float)B / (float)(B - 1)) : vv[e];
+                P.rmean[col + e] = (1.f - momentum) * P.rmean[col + e] + momentum * mv[e];
+                P.rvar[col + e] = (1.f - momentum) * P.rvar[col + e] + momentum * unb;
+            }
+        }
+    }
+    const bool drop = p_drop > 0.f;
+    const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    const uint32_t thr = jamie_drop_threshold(p_drop);
+    unsigned mk[BN4_MAXR];
+    if (drop && P.mask) {
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+    }
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        const int row = rp + j * BN4_RP;
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < B && cok) {
+            const long long o = (long long)row * N + col;
+            if (nslab > 1) *reinterpret_cast<float4*>(P.h + o) = v[j];
+            const float hv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
+            Philox4 r;
+            r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
+            if (drop && !P.mask) r = drop_rand4(rng, P.rng_stream, col, row);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (hv[e] - mv[e]) * iv[e] * ga[e] + be[e];
+                t = t > 0.f ? t : slope * t;
+                if (drop) {
+                    const bool keep = P.mask ? (((mk[j] >> (8 * e)) & 0xFFu) != 0) : (r.v[e] >= thr);
+                    t = keep ? t * keep_scale : 0.f;
+                }
+                y[e] = t;
+            }
+            if (P.out) *reinterpret_cast<float4*>(P.out + o) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        v[j] = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    if (P.out_bf || P.outT_bf) strip_out_bf16x4(v, P.out_bf, P.outT_bf, tl, B, N, col0, cq, rp, cok);
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng) {
+    __shared__ float sh[4][BN_CW];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * BN_TS];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
+    const BnBwdDev& P = g.p[pi];
+    const int tid = threadIdx.x, cq = tid & 3, rp = tid >> 2;
+    const int col0 = ((int)blockIdx.x - P.blk_begin) * BN_CW, col = col0 + 4 * cq;
+    const bool cok = col < P.N;
+    const int B = P.B, N = P.N, nslab = P.nslab;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, invstd[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mean[e] = P.smean[col + e]; invstd[e] = P.sinvstd[col + e]; ga[e] = P.gamma[col + e]; be[e] = P.beta[col + e]; }
+    }
+    const bool drop = p_drop > 0.f;
+    const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    const uint32_t thr = jamie_drop_threshold(p_drop);
+    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.da, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)((unsigned)B * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
+    unsigned roff[BN4_MAXR];
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        const int row = rp + j * BN4_RP;
+        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
+    }
+    float4 dyv[BN4_MAXR], xnv[BN4_MAXR];
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) xnv[j] = buf_f32x4(h_rs, roff[j]);
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) dyv[j] = buf_f32x4(d_rs, roff[j]);
+    for (int s = 1; s < nslab; ++s) {
+        float4 a[BN4_MAXR];
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) a[j] = buf_f32x4(d_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) { dyv[j].x += a[j].x; dyv[j].y += a[j].y; dyv[j].z += a[j].z; dyv[j].w += a[j].w; }
+    }
+    unsigned mk[BN4_MAXR];
+    if (drop && P.mask) {
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        const int row = rp + j * BN4_RP;
+        const bool ok = cok && row < B;
+        Philox4 r;
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
+        if (ok && drop && !P.mask) r = drop_rand4(rng, P.rng_stream, col, row);
+        float d[4] = {dyv[j].x, dyv[j].y, dyv[j].z, dyv[j].w}, x[4] = {xnv[j].x, xnv[j].y, xnv[j].z, xnv[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xn = ok ? (x[e] - mean[e]) * invstd[e] : 0.f;
+            float dd = d[e];
+            if (drop) {
+                const bool keep = P.mask ? (((mk[j] >> (8 * e)) & 0xFFu) != 0) : (r.v[e] >= thr);
+                dd = keep ? dd * keep_scale : 0.f;
+            }
+            const float y = xn * ga[e] + be[e];
+            dd = ok ? (y > 0.f ? dd : dd * slope) : 0.f;
+            x[e] = xn; d[e] = dd;
+        }
+        xnv[j] = make_float4(x[0], x[1], x[2], x[3]);
+        dyv[j] = make_float4(d[0], d[1], d[2], d[3]);
+        s1.x += d[0]; s1.y += d[1]; s1.z += d[2]; s1.w += d[3];
+        s2.x += d[0] * x[0]; s2.y += d[1] * x[1]; s2.z += d[2] * x[2]; s2.w += d[3] * x[3];
+    }
+    const float4 dbeta = col_reduce4(s1, sh, tid);
+    const float4 dgamma = col_reduce4(s2, sh, tid);
+    const float invB = 1.f / (float)B;
+    const float k1[4] = {dbeta.x * invB, dbeta.y * invB, dbeta.z * invB, dbeta.w * invB};
+    const float k2[4] = {dgamma.x * invB, dgamma.y * invB, dgamma.z * invB, dgamma.w * invB};
+    float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < BN4_MAXR; ++j) {
+        const int row = rp + j * BN4_RP;
+        float dh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cok && row < B) {
+            const float d[4] = {dyv[j].x, dyv[j].y, dyv[j].z, dyv[j].w}, x[4] = {xnv[j].x, xnv[j].y, xnv[j].z, xnv[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dh[e] = ga[e] * invstd[e] * (d[e] - k1[e] - x[e] * k2[e]);
+            if (!P.skip_f32) *reinterpret_cast<float4*>(P.da + (long long)row * N + col) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+            s3.x += dh[0]; s3.y += dh[1]; s3.z += dh[2]; s3.w += dh[3];
+        }
+        dyv[j] = make_float4(dh[0], dh[1], dh[2], dh[3]);
+    }
+    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, cq, rp, cok);
+    const float4 dbias = col_reduce4(s3, sh, tid);
+    if (cok && rp == 0) {
+        const float dg[4] = {dgamma.x, dgamma.y, dgamma.z, dgamma.w}, db[4] = {dbeta.x, dbeta.y, dbeta.z, dbeta.w};
+        const float dl[4] = {dbias.x, dbias.y, dbias.z, dbias.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (P.accumulate) {
+                P.dgamma[col + e] += dg[e];
+                P.dbeta[col + e] += db[e];
+                if (P.dbias) P.dbias[col + e] += dl[e];
+            } else {
+                P.dgamma[col + e] = dg[e];
+                P.dbeta[col + e] = db[e];
+                if (P.dbias) P.dbias[col + e] = dl[e];
+            }
+        }
+    }
+}
+
 extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum,
                                 float eps, float slope, const uint64_t* rng, void* stream) {
     JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
@@ -366,7 +656,7 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     memset(&g, 0, sizeof(g));
     g.count = count;
     int blocks = 0, maxB = 0;
-    bool need_rng = false;
+    bool need_rng = false, wide = true;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_fwd_problem& s = pr[i];
         JAMIE_ARG(s.h && s.gamma && s.beta && s.running_mean && s.running_var && s.save_mean && s.save_invstd,
@@ -387,10 +677,15 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
         blocks += (s.N + BN_CW - 1) / BN_CW;
         if (s.B > maxB) maxB = s.B;
         if (!s.mask && p_drop > 0.f) need_rng = true;
+        if (s.N % 4 || s.slab_stride % 4 || (uintptr_t)s.h % 16 || (uintptr_t)s.out % 16 || (uintptr_t)s.mask % 4 ||
+            (uintptr_t)s.out_bf16 % 8)
+            wide = false;
     }
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
-    if (maxB <= BN_MAXR * BN_RP)
+    if (wide && maxB <= BN4_MAXR * BN4_RP)
+        hipLaunchKernelGGL(bn_act_fwd4_kernel, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
+    else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
@@ -405,7 +700,7 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
     memset(&g, 0, sizeof(g));
     g.count = count;
     int blocks = 0, maxB = 0;
-    bool need_rng = false;
+    bool need_rng = false, wide = true;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_bwd_problem& s = pr[i];
         JAMIE_ARG(s.da && s.h && s.gamma && s.beta && s.save_mean && s.save_invstd && s.dgamma && s.dbeta,
@@ -426,10 +721,15 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
         blocks += (s.N + BN_CW - 1) / BN_CW;
         if (s.B > maxB) maxB = s.B;
         if (!s.mask && p_drop > 0.f) need_rng = true;
+        if (s.N % 4 || s.slab_stride % 4 || (uintptr_t)s.da % 16 || (uintptr_t)s.h % 16 || (uintptr_t)s.mask % 4 ||
+            (uintptr_t)s.dh_bf16 % 8)
+            wide = false;
     }
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
-    if (maxB <= BN_MAXR * BN_RP)
+    if (wide && maxB <= BN4_MAXR * BN4_RP)
+        hipLaunchKernelGGL(bn_act_bwd4_kernel, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
+    else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
     else
         hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
