@@ -94,6 +94,8 @@ typedef struct {
     void* dstT;                 /* bf16 [C, R] (ldt) or NULL                                                    */
     int R, C, ld, ldd, ldt, nslab;
     long long slab_stride;
+    const void* src_bf16;       /* alternative source: bf16 [R, C] (ld), with src = NULL and nslab = 1 (a transposed  */
+                                /* copy of an existing bf16 matrix, e.g. the weights the Adam kernel wrote)            */
 } jamie_cast_problem;
 int jamie_cast_transpose(const jamie_cast_problem* problems /*host*/, int count /* <= 16 */, void* stream);
 

@@ -33,7 +33,7 @@ class GemmProblem(C.Structure):
 class CastProblem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('dstT', C.c_void_p),
                 ('R', C.c_int), ('C', C.c_int), ('ld', C.c_int), ('ldd', C.c_int), ('ldt', C.c_int),
-                ('nslab', C.c_int), ('slab_stride', C.c_longlong)]
+                ('nslab', C.c_int), ('slab_stride', C.c_longlong), ('src_bf16', C.c_void_p)]
 
 
 class MseProblem(C.Structure):
@@ -271,7 +271,10 @@ def cast_problem(src, dst=None, dstT=None, nslab=1, slab_stride=0):
     """fp32 [R, C] (contiguous 2-D view; slabs `slab_stride` elements apart) -> bf16 dst [R, C] / dstT [C, R]."""
     p = CastProblem()
     R, Cc = src.shape[-2], src.shape[-1]
-    p.src, p.dst, p.dstT = ptr(src), ptr(dst), ptr(dstT)
+    if src.dtype == torch.bfloat16:      # bf16 source: transposed (or plain) copy of an existing bf16 matrix
+        p.src_bf16, p.dst, p.dstT = ptr(src), ptr(dst), ptr(dstT)
+    else:
+        p.src, p.dst, p.dstT = ptr(src), ptr(dst), ptr(dstT)
     p.R, p.C, p.ld, p.ldd, p.ldt, p.nslab, p.slab_stride = R, Cc, Cc, Cc, R, nslab, slab_stride
     p._keep = (src, dst, dstT)
     return p

@@ -843,7 +843,7 @@ extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int*
 // the reads and the transposed writes move whole 128-byte lines.  Up to 16 matrices per launch (the weights).
 // ------------------------------------------------------------------------------------------------
 #define CT_MAX 16
-struct CastDev { const float* src; unsigned short* dst; unsigned short* dstT; long long slab_stride; int R, C, ld, ldd, ldt, nslab, blk_begin, tiles_c; };
+struct CastDev { const float* src; const unsigned short* src_bf; unsigned short* dst; unsigned short* dstT; long long slab_stride; int R, C, ld, ldd, ldt, nslab, blk_begin, tiles_c; };
 struct CastGroup { CastDev p[CT_MAX]; int count; };
 
 __global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
@@ -857,13 +857,25 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
     const int b = blockIdx.x - P.blk_begin;
     const int r0 = (b / P.tiles_c) * 64, c0 = (b % P.tiles_c) * 64;
     const int q = threadIdx.x & 15, rr0 = threadIdx.x >> 4;          // 16 column quads x 16 rows per pass
-    const bool vec = (P.ld % 4 == 0) && (((uintptr_t)P.src & 15) == 0) && (P.slab_stride % 4 == 0);
+    const bool vec = P.src && (P.ld % 4 == 0) && (((uintptr_t)P.src & 15) == 0) && (P.slab_stride % 4 == 0);
     const bool vecd = P.dst && (P.ldd % 4 == 0) && (((uintptr_t)P.dst & 7) == 0);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int rr = rr0 + 16 * pass, r = r0 + rr, c = c0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < P.R) {
+        if (r < P.R && P.src_bf) {       // bf16 source (the copy the Adam kernel wrote): half the read traffic
+            const unsigned short* sp = P.src_bf + (long long)r * P.ld + c;
+            if ((P.ld % 4 == 0) && (((uintptr_t)P.src_bf & 7) == 0) && c + 3 < P.C) {
+                const uint2 u = *reinterpret_cast<const uint2*>(sp);
+                v.x = __uint_as_float(u.x << 16); v.y = __uint_as_float(u.x & 0xFFFF0000u);
+                v.z = __uint_as_float(u.y << 16); v.w = __uint_as_float(u.y & 0xFFFF0000u);
+            } else {
+                if (c < P.C) v.x = __uint_as_float((unsigned)sp[0] << 16);
+                if (c + 1 < P.C) v.y = __uint_as_float((unsigned)sp[1] << 16);
+                if (c + 2 < P.C) v.z = __uint_as_float((unsigned)sp[2] << 16);
+                if (c + 3 < P.C) v.w = __uint_as_float((unsigned)sp[3] << 16);
+            }
+        } else if (r < P.R) {
             for (int s = 0; s < P.nslab; ++s) {
                 const float* sp = P.src + s * P.slab_stride + (long long)r * P.ld + c;
                 if (vec && c + 3 < P.C) {
@@ -923,11 +935,12 @@ extern "C" int jamie_cast_transpose(const jamie_cast_problem* pr, int count, voi
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
         const jamie_cast_problem& s = pr[i];
-        JAMIE_ARG(s.src && (s.dst || s.dstT) && s.R > 0 && s.C > 0 && s.ld >= s.C && s.nslab >= 1, "bad cast problem");
+        JAMIE_ARG((s.src || s.src_bf16) && (s.dst || s.dstT) && s.R > 0 && s.C > 0 && s.ld >= s.C && s.nslab >= 1, "bad cast problem");
+        JAMIE_ARG(!s.src_bf16 || (!s.src && s.nslab == 1), "src_bf16 excludes src / slabs");
         JAMIE_ARG(!s.dst || s.ldd >= s.C, "ldd < C");
         JAMIE_ARG(!s.dstT || s.ldt >= s.R, "ldt < R");
         CastDev& d = g.p[i];
-        d.src = s.src; d.dst = (unsigned short*)s.dst; d.dstT = (unsigned short*)s.dstT; d.slab_stride = s.slab_stride;
+        d.src = s.src; d.src_bf = (const unsigned short*)s.src_bf16; d.dst = (unsigned short*)s.dst; d.dstT = (unsigned short*)s.dstT; d.slab_stride = s.slab_stride;
         d.R = s.R; d.C = s.C; d.ld = s.ld; d.ldd = s.ldd; d.ldt = s.ldt; d.nslab = s.nslab;
         d.blk_begin = blocks; d.tiles_c = (s.C + 63) / 64;
         blocks += ((s.R + 63) / 64) * d.tiles_c;

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
     }
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* partials, int n_partials,
@@ -60,19 +61,28 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    for (long long i0 = (long long)blockIdx.x * (256 * U) + threadIdx.x; i0 < n4; i0 += (long long)gridDim.x * (256 * U)) {
         // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
-        float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const float4 gg = g4[i];
-        upd(pp.x, gg.x, mm.x, vv.x);
-        upd(pp.y, gg.y, mm.y, vv.y);
-        upd(pp.z, gg.z, mm.z, vv.z);
-        upd(pp.w, gg.w, mm.w, vv.w);
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
-        if (p_bf16) {   // bf16 copy of the updated master weights for the bf16-compute GEMMs (+2 B/parameter)
-            const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)pp.x), b1 = __builtin_bit_cast(unsigned short, (__bf16)pp.y);
-            const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)pp.z), b3 = __builtin_bit_cast(unsigned short, (__bf16)pp.w);
-            reinterpret_cast<uint2*>(p_bf16)[i] = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+        float4 pp[U], mm[U], vv[U], gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + u * 256;
+            if (i < n4) { pp[u] = p4[i]; mm[u] = m4[i]; vv[u] = v4[i]; gg[u] = g4[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + u * 256;
+            if (i >= n4) continue;
+            upd(pp[u].x, gg[u].x, mm[u].x, vv[u].x);
+            upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
+            upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z);
+            upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
+            p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
+            if (p_bf16) {   // bf16 copy of the updated master weights for the bf16-compute GEMMs (+2 B/parameter)
+                const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].x), b1 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].y);
+                const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].z), b3 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].w);
+                reinterpret_cast<uint2*>(p_bf16)[i] = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+            }
         }
     }
     if (blockIdx.x == 0) {
@@ -108,8 +118,12 @@ extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, lon
                   ((uintptr_t)v % 16) == 0, "buffers must be 16-byte aligned");
     JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
     JAMIE_ARG(p_bf16 == nullptr || ((uintptr_t)p_bf16 % 8) == 0, "p_bf16 must be 8-byte aligned");
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       partials, n_partials, hyper, state, (unsigned short*)p_bf16);
+    // one workgroup per CU, two float4 per thread and array in flight: fewer, longer streams keep more DRAM pages open
+    // (tools/bench_adam.py, 40.3 M parameters: 2048 workgroups x 1 float4 4.77 TB/s, 256 x 2 5.70-5.78 TB/s)
+    long long need = (n / 4 + 511) / 512;
+    const int grid = (int)(need < 1 ? 1 : (need > 256 ? 256 : need));
+    hipLaunchKernelGGL(clip_adam_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, partials,
+                       n_partials, hyper, state, (unsigned short*)p_bf16);
     return jamie_launch_status("jamie_clip_adam");
 }
 

@@ -262,7 +262,10 @@ class TrainEngine:
                 wt = self.wT.get(f'm{i}.{lin}')
                 if transposes_only and wt is None:
                     continue
-                probs.append(nv.cast_problem(W, None if transposes_only else self.wbf[f'm{i}.{lin}.W'], wt))
+                if transposes_only:      # after Adam: transpose the bf16 copy it wrote (half the bytes of the fp32 master)
+                    probs.append(nv.cast_problem(self.wbf[f'm{i}.{lin}.W'], None, wt))
+                else:
+                    probs.append(nv.cast_problem(W, self.wbf[f'm{i}.{lin}.W'], wt))
         nv.cast_transpose(probs)
 
     def _cast(self, key):

@@ -556,3 +556,15 @@ def test_mse_cast_matches_torch(nv, R, C, nslab):
     # tile order: m fastest (the 64x64 GEMM's fused epilogue)
     t0 = (diff[:64, :64].double() ** 2).sum().item() * pscale
     assert abs(part[0].item() - t0) < 1e-5 * t0
+
+
+@pytest.mark.parametrize('R,C', [(64, 64), (100, 72), (2000, 1000), (33, 201)])
+def test_cast_transpose_bf16_source(nv, R, C):
+    """bf16 -> bf16 transposed copy (the weight transposes after the Adam step read its bf16 output)."""
+    src = torch.randn(R, C, generator=torch.Generator().manual_seed(R * C)).to(torch.bfloat16).cuda()
+    dT = torch.empty(C, R, device='cuda', dtype=torch.bfloat16)
+    d = torch.empty(R, C, device='cuda', dtype=torch.bfloat16)
+    nv.cast_transpose([nv.cast_problem(src, d, dT)])
+    torch.cuda.synchronize()
+    assert torch.equal(d, src)
+    assert torch.equal(dT, src.t().contiguous())
