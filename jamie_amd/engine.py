@@ -22,6 +22,9 @@ H_KL, H_REC, H_ALIGN, H_F = 0, 1, 2, 3
 H_LR, H_B1, H_B2, H_EPS, H_MAXNORM, H_GSCALE = 8, 9, 10, 11, 12, 13
 
 
+SKINNY_KCHUNK = int(__import__("os").environ.get("JAMIE_SKINNY", "128"))
+
+
 def choose_splitk(M, N, K, bm=64, bn=64):
     """Split K so that a problem offers >= ~2 workgroups of 64x64 per CU (512 in all); each slice keeps at
     least 512 of K (256 for the skinny heads / latent products).  Slabs are summed by the consuming kernel.
@@ -30,7 +33,7 @@ def choose_splitk(M, N, K, bm=64, bn=64):
     if tiles >= 384:
         return 1
     s = max(1, math.ceil(512 / tiles))
-    return int(max(1, min(s, K // (512 if N > 64 else 256))))
+    return int(max(1, min(s, K // (512 if N > 64 else SKINNY_KCHUNK))))
 
 
 # ---- bf16 GEMM launch plans (tile configuration + per-problem split-K), from tools/bench_gemm_bf16.py ----
@@ -201,7 +204,8 @@ class TrainEngine:
         self.rsum = torch.empty(B, **f32); self.qsum = torch.empty(B, **f32)
         self.fc1 = torch.empty(B, L, **f32); self.fte = torch.empty(B, L, **f32)
         self.corr = torch.empty(B, B, **f32)
-        self.accumulate = False
+        self.accumulate = False          # True: gradients add to the buffer (batch_step=False, jamie.py:736-749)
+        self._dsig_tmp = torch.zeros(self.M, **f32)
         self._timing = None
         self._timing_every, self._timing_step = 1, 0
 
@@ -412,7 +416,7 @@ class TrainEngine:
         d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
         d.sigma, d.hyper, d.partials = nv.ptr(self.m.p['sigma']), nv.ptr(self.hyper), nv.ptr(self.lat_partials)
         d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
-        d.dsigma = nv.ptr(self.g['sigma'])
+        d.dsigma = nv.ptr(self._dsig_tmp if self.accumulate else self.g['sigma'])
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses, d.rng_stream = nv.ptr(self.losses), 100
         return d
@@ -435,7 +439,7 @@ class TrainEngine:
         d.rsum, d.qsum, d.fc1, d.fte = nv.ptr(self.rsum), nv.ptr(self.qsum), nv.ptr(self.fc1), nv.ptr(self.fte)
         d.partials = nv.ptr(self.lat_partials)
         d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
-        d.dsigma = nv.ptr(self.g['sigma'])
+        d.dsigma = nv.ptr(self._dsig_tmp if self.accumulate else self.g['sigma'])
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses = nv.ptr(self.losses)
         d.cosine, d.rng_stream = int(self.cosine), 100
@@ -566,6 +570,8 @@ class TrainEngine:
         self._bwd_gemms('de1', 'dec0', 'comb', 'dcomb', 'd_comb')
         self._region(allreduce, 'dec0')
         nv.latent_bwd(lat)                                                      # dml, dsigma, losses
+        if acc:                                                                 # batch_step=False: d(sigma) accumulates
+            self.g['sigma'].add_(self._dsig_tmp)
         self._cast('dml')
         nv.colsum_group([(self.ws[i]['dml'], self.g[f'm{i}.head.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')

@@ -248,13 +248,12 @@ class JAMIE:
         streak = 0
         if self.record_loss:
             self.loss_history = {}
-        if not self.batch_step:
-            raise NotImplementedError('batch_step=False (one optimiser step per epoch) is not accelerated yet')
         # fast path: device sampler, 'diag' sampling, no dense P/F blocks -> the step is a fixed launch sequence on
         # static buffers: record it once and replay it (one foreign call per launch, nothing rebuilt per step)
         plan = None
         use_plan = (self.sampler == 'device' and method == 'diag' and P_dense is None and F_dense is None
-                    and self.PF_Ratio == 1)
+                    and self.PF_Ratio == 1 and self.batch_step)
+        epoch_sum = torch.zeros((), device=dev)      # batch_step=False: epoch loss = mean of the batch losses (jamie.py:728)
         timer.log('Setup')
         for epoch in range(self.epoch_DNN):                                   # jamie.py:546
             eng.set_kl_anneal(kl_anneal(epoch, self.min_epochs, self.epoch_DNN))
@@ -309,10 +308,30 @@ class JAMIE:
                     else:
                         corr = (self.PF_Ratio * Pb).contiguous() if self.PF_Ratio != 1 else Pb
                 timer.log('Get subset samples')
-                eng.step(corr, Fblk, None, allreduce)
+                if self.batch_step:
+                    eng.step(corr, Fblk, None, allreduce)
+                else:
+                    # jamie.py:734-749: every batch back-propagates into the same gradient buffers, ONE clip + Adam
+                    # step per epoch; the gradient all-reduce rides on the last batch's backward
+                    last = batch_idx == len_dataloader - 1
+                    eng.accumulate = batch_idx > 0
+                    eng.forward_backward(corr, Fblk, None, allreduce if last else None)
+                    epoch_sum += eng.losses[4]
+                    if not last:
+                        eng.state[0] += 1          # the Philox step only advances with the optimiser: fresh noise per batch
+                    else:
+                        eng.state[0] -= len_dataloader - 1
+                    if last:
+                        if allreduce is not None:
+                            allreduce.finish() if hasattr(allreduce, 'finish') else allreduce(eng.grad)
+                        eng.accumulate = False
+                        eng.optimizer_step()
                 timer.log('Step')
             # ---- per-epoch bookkeeping (one device read per epoch; jamie.py:751-792) ----
             ls, total, best_batch_loss = eng.read_losses()
+            if not self.batch_step:                    # jamie.py:778-781: the early-stop criterion is the epoch loss
+                best_batch_loss = total = float(epoch_sum) / len_dataloader
+                epoch_sum.zero_()
             if self.record_loss:
                 for name, lo in zip(LOSS_NAMES, ls):
                     self.loss_history.setdefault(name, []).append(lo)

@@ -719,3 +719,64 @@ def test_three_modalities_facade_and_bf16(jam):
         assert len(emb) == 3 and all(e.shape == (N, 8) and np.isfinite(e).all() for e in emb)
         assert jm.loss_history['Rec'][-1] < jm.loss_history['Rec'][0]
         assert jm.modal_predict(data[2], 2).shape == (N, dims[0])          # modality 2 -> (2 + 1) % 3 = 0
+
+
+def test_batch_step_false_accumulates_like_reference(jam):
+    """batch_step=False (reference jamie.py:734-749): two batches back-propagate into the same gradient buffers,
+    then ONE clip + Adam step.  Engine (accumulate flag, incl. d sigma) against the oracle's summed gradients."""
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    B, dims, L, p = 128, (96, 72), 8, 0.6
+    torch.manual_seed(5)
+    model = edModelVar(dims, L, dropout=p)
+    torch.manual_seed(5)
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    eng = TrainEngine(model, B)
+    opt = orc.Adam(P.values(), 1e-3)
+    rng = np.random.default_rng(1)
+    total = None
+    for b in range(2):
+        X = [torch.from_numpy(rng.standard_normal((B, d)).astype(np.float32)) for d in dims]
+        torch.manual_seed(77 + b)
+        noise = orc.draw_noise(dims, L, B, p)
+        st = orc.train_step(P, Bf, opt, X, torch.eye(B), torch.zeros(B, B), noise, p, 0.5, do_step=False, return_grads=True)
+        total = st['grads'] if total is None else {k: total[k] + v for k, v in st['grads'].items()}
+        for i in range(2):
+            eng.ws[i]['x'].copy_(X[i])
+        eng.set_kl_anneal(0.5)
+        eng.accumulate = b > 0
+        eng.forward_backward(None, None, _noise_to_dev(noise, p))
+    eng.accumulate = False
+    for ref, (mine, sl) in model.layout.reference_names().items():
+        if orc.is_dead_bias(ref):
+            continue
+        got = eng.g[mine] if sl is None else eng.g[mine][sl]
+        want = total[ref].numpy()
+        scale = max(1e-6, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=2e-5 * scale + 1e-8, err_msg=ref)
+    glist = [total[k] for k in P]
+    with torch.no_grad():
+        orc.clip_grad_norm(glist)
+        opt.step(glist)
+    eng.optimizer_step()
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not orc.is_dead_bias(k):
+            assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=1e-4,
+                                rel_l2=2e-3, msg=k)
+
+
+def test_facade_batch_step_false_runs_one_step_per_epoch(jam):
+    """Facade: batch_step=False trains (loss falls), steps once per epoch and early-stops on the epoch loss."""
+    rng = np.random.default_rng(3)
+    Z = rng.standard_normal((300, 6))
+    data = [(Z @ rng.standard_normal((6, d)) + .1 * rng.standard_normal((300, d))).astype(np.float32) for d in (48, 40)]
+    jm = jam.JAMIE(output_dim=8, epoch_DNN=12, batch_size=64, pca_dim=None, use_f_tilde=False, batch_step=False,
+                   min_epochs=0, log_DNN=1000, record_loss=True)
+    emb = _quiet(lambda: jm.fit_transform(dataset=data))
+    assert emb[0].shape == (300, 8) and np.isfinite(emb[0]).all()
+    hist = jm.loss_history['Rec']
+    assert len(hist) == 12 and hist[-1] < hist[0]
+    assert int(jm.engine.state[1]) == 12            # one optimiser step per epoch (4 batches each)
