@@ -326,9 +326,12 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert np.isfinite(out['final_loss'])
 
 
-def test_data_parallel_ranks_stay_identical(tmp_path):
+@pytest.mark.parametrize('mode', ['f32_buckets', 'bf16_overlapped_plan'])
+def test_data_parallel_ranks_stay_identical(tmp_path, mode):
     """Two ranks (sharing cuda:0, gloo) training on different shards keep bit-identical parameters after
-    several steps: the all-reduced gradient and the 1/world average give every rank the same update."""
+    several steps: the all-reduced gradient and the 1/world average give every rank the same update.
+    `bf16_overlapped_plan`: bf16 compute, region-wise overlapped exchange with bf16 messages, recorded plan
+    (the configuration bench.py runs at N > 1)."""
     import os
     import subprocess
     import sys
@@ -345,16 +348,25 @@ dev = torch.device('cuda', local)
 torch.manual_seed(100 + rank)                     # different initial weights per rank ...
 model = edModelVar((96, 64), 8, device=dev)
 jd.broadcast_flat(model.flat)                     # ... until rank 0's are broadcast
-eng = TrainEngine(model, 64, seed=1 + rank, world_size=world)
-ar = jd.GradAllReduce(n_buckets=3)
+mode = {mode!r}
 g = torch.Generator(device=dev).manual_seed(50 + rank)
 data = [torch.randn(512, d, generator=g, device=dev) for d in (96, 64)]
 idx = [torch.zeros(64, dtype=torch.int32, device=dev) for _ in range(2)]
-for s in range(5):
-    nv.sample_indices(idx[0], 512, 0, False, eng.state, 200)
-    idx[1].copy_(idx[0])
-    eng.load_batch(data, idx)
-    eng.step(None, None, None, ar)
+if mode == 'f32_buckets':
+    eng = TrainEngine(model, 64, seed=1 + rank, world_size=world)
+    ar = jd.GradAllReduce(n_buckets=3)
+    for s in range(5):
+        nv.sample_indices(idx[0], 512, 0, False, eng.state, 200)
+        idx[1].copy_(idx[0])
+        eng.load_batch(data, idx)
+        eng.step(None, None, None, ar)
+else:
+    eng = TrainEngine(model, 64, seed=1 + rank, world_size=world, compute_dtype='bf16')
+    ar = jd.OverlappedGradAllReduce(min_bytes=16384, comm_dtype=torch.bfloat16)
+    plan = eng.make_plan(data, idx[0], 512, False, ar)
+    for s in range(4):
+        eng.run_plan(plan)
+    assert ar.comm is not None and ar.comm.dtype == torch.bfloat16 and not ar.works
 flat = model.flat.clone()
 others = [torch.zeros_like(flat) for _ in range(world)]
 torch.distributed.all_gather(others, flat)

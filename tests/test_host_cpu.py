@@ -159,6 +159,20 @@ for nb in (1, 3):
     jd.GradAllReduce(n_buckets=nb)(g)
     want = 3.0 + 2 * torch.arange(1003) * 0.001
     assert torch.allclose(g, want), nb
+# the overlapped exchange: regions arrive from the end of the buffer (backward order), merged into buckets;
+# fp32 messages are exact, bf16 messages (bf16 compute mode) agree to bf16 rounding and identically on both ranks
+for comm, tol in ((None, 0.0), (torch.bfloat16, 2e-2)):
+    ov = jd.OverlappedGradAllReduce(min_bytes=1024, comm_dtype=comm)
+    g = torch.full((1003,), float(rank + 1)) + torch.arange(1003) * 0.001
+    for lo, hi in ((900, 1003), (600, 900), (590, 600), (100, 590), (0, 100)):
+        ov.region_done(g, lo, hi)
+    ov.finish()
+    want = 3.0 + 2 * torch.arange(1003) * 0.001
+    assert torch.allclose(g, want, rtol=tol, atol=1e-6), comm
+    both = [torch.zeros(1003) for _ in range(world)]
+    dist.all_gather(both, g)
+    assert torch.equal(both[0], both[1]), comm
+    assert not ov.works and ov.pending is None
 # averaging happens inside the optimiser through grad_scale = 1/world: emulate the oracle update
 from oracle import jamie_oracle as orc
 p = [torch.ones(8)]
