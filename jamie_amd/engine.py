@@ -22,9 +22,6 @@ H_KL, H_REC, H_ALIGN, H_F = 0, 1, 2, 3
 H_LR, H_B1, H_B2, H_EPS, H_MAXNORM, H_GSCALE = 8, 9, 10, 11, 12, 13
 
 
-SKINNY_KCHUNK = int(__import__("os").environ.get("JAMIE_SKINNY", "128"))
-
-
 def choose_splitk(M, N, K, bm=64, bn=64):
     """Split K so that a problem offers >= ~2 workgroups of 64x64 per CU (512 in all); each slice keeps at
     least 512 of K (256 for the skinny heads / latent products).  Slabs are summed by the consuming kernel.
@@ -33,7 +30,7 @@ def choose_splitk(M, N, K, bm=64, bn=64):
     if tiles >= 384:
         return 1
     s = max(1, math.ceil(512 / tiles))
-    return int(max(1, min(s, K // (512 if N > 64 else SKINNY_KCHUNK))))
+    return int(max(1, min(s, K // (512 if N > 64 else 256))))
 
 
 # ---- bf16 GEMM launch plans (tile configuration + per-problem split-K), from tools/bench_gemm_bf16.py ----

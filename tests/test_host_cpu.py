@@ -125,6 +125,24 @@ def test_preclass_matches_oracle():
     assert g.mean.shape == () and np.isclose(g.transform(X.copy()).std(), 1)
 
 
+def test_bf16_gemm_plans():
+    """Deterministic tile / split-K rules of the bf16 GEMM launches (engine.plan_bf16_*): config 2 gets exactly one
+    workgroup per CU on the forward launches; small or ragged problems fall back to the library default."""
+    from jamie_amd.engine import plan_bf16_rows, plan_bf16_bwd, BF16_TILE, N_CU
+    import math
+    for shapes in ([(4000, 2000), (2000, 1000)], [(2000, 4000), (1000, 2000)]):
+        cfg, sk = plan_bf16_rows(512, shapes)
+        bm, bn = BF16_TILE[cfg]
+        assert sum(math.ceil(512 / bm) * math.ceil(N / bn) * s for (N, K), s in zip(shapes, sk)) == N_CU
+        assert all(K // s >= 256 for (N, K), s in zip(shapes, sk))
+    assert plan_bf16_rows(512, [(4000, 2000), (2000, 1000)])[0] != plan_bf16_rows(512, [(2000, 4000), (1000, 2000)])[0]
+    assert plan_bf16_rows(64, [(80, 40), (48, 24)])[0] == -1 and plan_bf16_bwd(64, [(80, 40)])[0] == -1
+    cfg, sk = plan_bf16_bwd(512, [(2000, 4000), (1000, 2000)])
+    assert cfg >= 0 and sk == [4, 2]
+    cfg, sk = plan_bf16_rows(512, [(10000, 5000), (4000, 2000)])          # config-5 dimensions: enough tiles already
+    assert sk == [1, 1]
+
+
 def test_shard_bounds_partition():
     from jamie_amd.distributed import shard_bounds
     for n, w in [(100000, 8), (10, 3), (7, 8), (1000001, 8)]:
