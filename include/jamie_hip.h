@@ -235,6 +235,12 @@ int jamie_sample_indices(int32_t* idx, int B, long long N, long long offset, int
                          const uint64_t* rng, int rng_stream, void* stream);
 /* corr[a,b] = (idx0[a] == idx1[b]) row-normalised (P = I_N block, jamie.py:586-589) */
 int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1, int B, float* corr, void* stream);
+/* blk[a,b] = P[idx0[a] + row_off, idx1[b] + col_off] for P in CSR form (int32 indptr / indices sorted within each
+ * row, fp32 values; `indices` / `vals` may be NULL when the matrix has no entries), row-normalised when `normalise`
+ * (zero rows keep divisor 1): P[idx0][:, idx1] of jamie.py:586-589 for sparse partial correspondence, no N x N array. */
+int jamie_csr_block(const int32_t* indptr, const int32_t* indices, const float* vals, const int32_t* idx0,
+                    const int32_t* idx1, int B0, int B1, int row_off, int col_off, int normalise, float* out /*[B0,B1]*/,
+                    void* stream);
 /* out[n] (+)= sum_m X[m,n]  (bias gradients of the non-BN Linear layers) */
 int jamie_colsum(const float* X, int M, int N, int ld, int nslab, long long slab_stride, float* out,
                  int accumulate, void* stream);

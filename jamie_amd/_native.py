@@ -126,6 +126,7 @@ EXPORTS = {
     'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
                                        C.c_int, C.c_void_p]),
     'jamie_corr_from_indices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_csr_block': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     'jamie_colsum_group': (C.c_int, [C.POINTER(ColsumProblem), C.c_int, C.c_void_p]),
     'jamie_colsum': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p,
                                C.c_int, C.c_void_p]),
@@ -355,6 +356,12 @@ def colsum_group(items, accumulate=False):
         probs.append(p)
     arr = (ColsumProblem * len(probs))(*probs)
     _call('jamie_colsum_group', arr, len(probs), _stream())
+
+
+def csr_block(indptr, indices, vals, idx0, idx1, out, row_off=0, col_off=0, normalise=True):
+    """out[a, b] = P[idx0[a] + row_off, idx1[b] + col_off] for a device CSR matrix (sorted column indices)."""
+    _call('jamie_csr_block', ptr(indptr), ptr(indices), ptr(vals), ptr(idx0), ptr(idx1), idx0.numel(), idx1.numel(),
+          int(row_off), int(col_off), int(normalise), ptr(out), _stream())
 
 
 def colsum(X, M, N, ld, out, nslab=1, slab_stride=0, accumulate=False):

@@ -157,6 +157,45 @@ extern "C" int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1,
     return jamie_launch_status("jamie_corr_from_indices");
 }
 
+// ---- blk[a,b] = P[idx0[a] + row_off, idx1[b] + col_off] of a CSR matrix, optionally row-normalised (a zero row keeps
+// divisor 1): the P block of jamie.py:586-589 for a sparse partial-correspondence matrix, without an N x N array.
+// One workgroup per output row; every thread binary-searches its columns in the row's sorted column indices.
+__global__ __launch_bounds__(256) void csr_block_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ vals, const int32_t* __restrict__ idx0,
+                                                        const int32_t* __restrict__ idx1, int B1, int row_off, int col_off,
+                                                        int normalise, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int a = blockIdx.x;
+    const int r = idx0[a] + row_off;
+    const int beg = indptr[r], end = indptr[r + 1];
+    float sum = 0.f;
+    for (int b = threadIdx.x; b < B1; b += 256) {
+        const int c = idx1[b] + col_off;
+        int lo = beg, hi = end;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (indices[mid] < c) lo = mid + 1; else hi = mid;
+        }
+        const float v = (lo < end && indices[lo] == c) ? vals[lo] : 0.f;
+        out[(long long)a * B1 + b] = v;
+        sum += v;
+    }
+    if (!normalise) return;
+    sum = block_sum(sum, red);
+    if (sum == 0.f) return;
+    for (int b = threadIdx.x; b < B1; b += 256) out[(long long)a * B1 + b] /= sum;   // own elements: no barrier needed
+}
+
+extern "C" int jamie_csr_block(const int32_t* indptr, const int32_t* indices, const float* vals, const int32_t* idx0,
+                               const int32_t* idx1, int B0, int B1, int row_off, int col_off, int normalise, float* out,
+                               void* stream) {
+    JAMIE_ARG(indptr && idx0 && idx1 && out && B0 > 0 && B1 > 0, "null pointer / empty");
+    JAMIE_ARG(row_off >= 0 && col_off >= 0, "negative offset");
+    hipLaunchKernelGGL(csr_block_kernel, dim3(B0), dim3(256), 0, (hipStream_t)stream, indptr, indices, vals, idx0, idx1,
+                       B1, row_off, col_off, normalise, out);
+    return jamie_launch_status("jamie_csr_block");
+}
+
 // ---- out[n] (+)= sum_m sum_slabs X[m,n]: 16 columns x 16 row phases per workgroup; up to 4 matrices per launch ----
 struct ColsumDev { const float* X; float* out; long long slab_stride; int M, N, ld, nslab, accumulate, blk_begin; };
 struct ColsumGroup { ColsumDev p[JAMIE_MAX_GROUP]; int count; };

@@ -12,6 +12,7 @@ import random
 import warnings
 
 import numpy as np
+import scipy.sparse as sp
 import torch
 
 from . import _native as nv
@@ -191,9 +192,30 @@ class JAMIE:
             rank, world, _ = jd.init_from_env()
             allreduce = jd.OverlappedGradAllReduce(comm_dtype=torch.bfloat16 if self.grad_comm_dtype == 'bf16' else None)
         # ---- P / F (never densified for the identity) ----
-        P_dense = None
+        P_dense = P_csr = None
         if self.P is None:
             method = 'diag' if self.row[0] == self.row[1] else 'zeros'      # jamie.py:423-428, 518-533
+        elif sp.issparse(self.P):
+            # sparse partial correspondence: CSR on the device, the B x B block of a batch is
+            # looked up by jamie_csr_block -- no N x N array at any point
+            Pc = sp.csr_matrix(self.P, dtype=np.float32)
+            Pc.sum_duplicates()
+            Pc.sort_indices()
+            if Pc.shape[0] == Pc.shape[1] and Pc.nnz == Pc.shape[0] and bool((Pc.diagonal() == 1).all()):
+                method = 'diag'
+            elif Pc.nnz and float(np.abs(Pc.data).sum()) != 0:
+                if world > 1:
+                    raise NotImplementedError('hybrid sampling (partial correspondence) is single-process')
+                method = 'hybrid'                                             # corrected sampler, see the dense branch
+                coo = Pc.tocoo()
+                keep = coo.data > 0
+                self.corr_samples = np.stack([coo.row[keep], coo.col[keep]], axis=1)
+                self.num_corr = len(self.corr_samples)
+                self.true_ratio = .8                                          # jamie.py:529
+                P_csr = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+                              (Pc.indptr.astype(np.int32), Pc.indices.astype(np.int32), Pc.data.astype(np.float32)))
+            else:
+                method = 'zeros'
         else:
             P_dense = torch.as_tensor(np.asarray(self.P), dtype=torch.float32, device=dev)
             if P_dense.shape[0] == P_dense.shape[1] and torch.abs(
@@ -245,7 +267,8 @@ class JAMIE:
         eng.accumulate = False
         self.engine = eng
         rep = min(self.col) < B and self.dataset_num == 2                    # jamie.py:553 (sic); M > 2: never
-        need_block = (method == 'diag' and rep) or method == 'zeros' or F_dense is not None or P_dense is not None
+        need_block = ((method == 'diag' and rep) or method == 'zeros' or F_dense is not None or P_dense is not None
+                      or P_csr is not None)
         if self.dataset_num > 2 and need_block:
             raise NotImplementedError('more than two modalities: min(features) must be >= batch_size (no duplicates)')
         idx_dev = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(self.dataset_num)]
@@ -257,7 +280,7 @@ class JAMIE:
         # static buffers: record it once and replay it (one foreign call per launch, nothing rebuilt per step)
         plan = None
         use_plan = (self.sampler == 'device' and method == 'diag' and P_dense is None and F_dense is None
-                    and self.PF_Ratio == 1 and self.batch_step)
+                    and P_csr is None and self.PF_Ratio == 1 and self.batch_step)
         epoch_sum = torch.zeros((), device=dev)      # batch_step=False: epoch loss = mean of the batch losses (jamie.py:728)
         timer.log('Setup')
         for epoch in range(self.epoch_DNN):                                   # jamie.py:546
@@ -300,7 +323,10 @@ class JAMIE:
                 corr = Fblk = None
                 if need_block:
                     i0, i1 = idx_dev[0].long(), idx_dev[1].long()
-                    if P_dense is not None:
+                    if P_csr is not None:
+                        nv.csr_block(*P_csr, idx_dev[0], idx_dev[1], eng.corr, bounds[0][0], bounds[1][0])
+                        Pb = eng.corr
+                    elif P_dense is not None:
                         Pb = _row_normalise(P_dense[i0 + bounds[0][0]][:, i1 + bounds[1][0]])
                     elif method == 'diag':
                         nv.corr_from_indices(idx_dev[0], idx_dev[1], eng.corr)

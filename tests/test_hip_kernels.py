@@ -568,3 +568,25 @@ def test_cast_transpose_bf16_source(nv, R, C):
     torch.cuda.synchronize()
     assert torch.equal(d, src)
     assert torch.equal(dT, src.t().contiguous())
+
+
+@pytest.mark.parametrize('N0,N1,B0,B1,dens', [(300, 260, 64, 64, 0.02), (1000, 1000, 128, 96, 0.004), (50, 40, 32, 48, 0.3)])
+def test_csr_block_matches_dense_p_block(nv, N0, N1, B0, B1, dens):
+    """jamie_csr_block == the oracle's p_block (reference jamie.py:586-589) on the dense matrix: duplicates in the index
+    lists, empty rows (divisor 1), row / column offsets of a shard."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(N0 + B0)
+    Pm = sp.random(N0, N1, density=dens, format='csr', random_state=7, dtype=np.float32)
+    Pm.sort_indices()
+    dense = torch.from_numpy(Pm.toarray())
+    off0, off1 = 5, 3
+    idx0 = torch.from_numpy(rng.integers(0, N0 - off0, B0).astype(np.int32))      # with replacement: duplicates
+    idx1 = torch.from_numpy(rng.integers(0, N1 - off1, B1).astype(np.int32))
+    want = orc.p_block(dense, idx0.long() + off0, idx1.long() + off1)
+    out = torch.empty(B0, B1, device='cuda')
+    args = [torch.from_numpy(a).cuda() for a in (Pm.indptr.astype(np.int32), Pm.indices.astype(np.int32), Pm.data)]
+    nv.csr_block(*args, idx0.cuda(), idx1.cuda(), out, off0, off1, True)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-6, atol=0)
+    raw = torch.empty(B0, B1, device='cuda')
+    nv.csr_block(*args, idx0.cuda(), idx1.cuda(), raw, off0, off1, False)
+    assert torch.equal(raw.cpu(), dense[idx0.long() + off0][:, idx1.long() + off1])

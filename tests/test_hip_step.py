@@ -792,3 +792,29 @@ def test_facade_batch_step_false_runs_one_step_per_epoch(jam):
     hist = jm.loss_history['Rec']
     assert len(hist) == 12 and hist[-1] < hist[0]
     assert int(jm.engine.state[1]) == 12            # one optimiser step per epoch (4 batches each)
+
+
+def test_facade_sparse_P_equals_dense_P(jam):
+    """Partial correspondence given as a scipy.sparse matrix (CSR lookup on the device, no N x N array) trains exactly
+    like the same P given densely: same sampler stream, same B x B blocks."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    N, dims = 320, (40, 32)
+    Z = rng.standard_normal((N, 4))
+    data = [Z @ rng.standard_normal((4, d)) + .05 * rng.standard_normal((N, d)) for d in dims]
+    known = rng.choice(N, N // 3, replace=False)
+    P = np.zeros((N, N), dtype=np.float32)
+    P[known, known] = 1
+    embs = []
+    for Pm in (P, sp.coo_matrix(P)):
+        np.random.seed(11)
+        jm = jam.JAMIE(output_dim=4, batch_size=64, epoch_DNN=6, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9,
+                       dropout=0.0)
+        embs.append(_quiet(lambda: jm.fit_transform(dataset=data, P=Pm)))
+        assert jm.sampling_method == 'hybrid' and jm.num_corr == N // 3
+    for a, b in zip(*embs):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5)
+    # a sparse identity is recognised as fully paired data ('diag' sampling, no block at all)
+    jm = jam.JAMIE(output_dim=4, batch_size=64, epoch_DNN=1, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9)
+    _quiet(lambda: jm.fit_transform(dataset=data, P=sp.identity(N, format='csr')))
+    assert jm.sampling_method == 'diag'
