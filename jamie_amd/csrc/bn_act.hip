@@ -15,6 +15,12 @@
 // pass explicit masks.
 #include "common.h"
 
+// diagnostic ablations of the float4 forward kernel (timing only): 1 = no global loads, 2 = no global stores,
+// 3 = neither (launch + reductions only)
+#ifndef JAMIE_BN_ABL
+#define JAMIE_BN_ABL 0
+#endif
+
 #define BN_CW 16
 #define BN_RP 16
 #define BN_MAXR 32
@@ -56,13 +62,20 @@ __device__ __forceinline__ unsigned buf_u8(__amdgpu_buffer_rsrc_t r, unsigned of
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
 }
 
-// Keep decision of element (row, col): Philox counter = (col / 4, row), lane = col % 4, i.e. the four keep bits of
-// one call belong to the 4 consecutive columns a thread of the float4 kernels owns in one row.
+// Keep decision of element (row, col): 16 random bits against a 16-bit threshold.  One Philox call serves the 4
+// consecutive columns of a quad (word e = col % 4) in the two rows r and r + 128 (low / high half of the word): counter =
+// (col / 4, row % 128 + 128 * (row / 256)), half = (row / 128) % 2 -- the 8 elements a thread of the float4 kernels owns
+// in rows rp + 256 q and rp + 256 q + 128.  Halves the Philox work (3.7 us per launch at one call per 4 elements).
 __device__ __forceinline__ Philox4 drop_rand4(const uint64_t* rng, int stream, int col, int row) {
-    return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)(col >> 2) << 32) | (uint64_t)(uint32_t)row);
+    const uint32_t rk = (uint32_t)(row & 127) | ((uint32_t)(row >> 8) << 7);
+    return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)(col >> 2) << 32) | (uint64_t)rk);
 }
-__device__ __forceinline__ bool drop_keep(const uint64_t* rng, int stream, int col, int row, uint32_t thr) {
-    return drop_rand4(rng, stream, col, row).v[col & 3] >= thr;
+__device__ __forceinline__ uint32_t drop_threshold16(float p) {
+    const float t = p * 65536.f;
+    return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+__device__ __forceinline__ bool drop_keep(const uint64_t* rng, int stream, int col, int row, uint32_t thr16) {
+    return ((drop_rand4(rng, stream, col, row).v[col & 3] >> (16 * ((row >> 7) & 1))) & 0xFFFFu) >= thr16;
 }
 
 // bf16 outputs of a cached strip (thread (c, rp) holds rows rp + 16 j of column c in val[j]):
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
     const float ga = cok ? P.gamma[col] : 0.f, be = cok ? P.beta[col] : 0.f;
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    const uint32_t thr = jamie_drop_threshold(p_drop);
+    const uint32_t thr = drop_threshold16(p_drop);
     if (CACHED) {
         unsigned mk[BN_MAXR];
         if (drop && P.mask) {
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
     const float ga = cok ? P.gamma[col] : 0.f, be = cok ? P.beta[col] : 0.f;
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    const uint32_t thr = jamie_drop_threshold(p_drop);
+    const uint32_t thr = drop_threshold16(p_drop);
     const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
     const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.da, 0, (int)((unsigned)(P.nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
@@ -358,11 +371,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
 // float4 variants (N % 4 == 0, B <= 512: every training shape of the bf16 / fp32 step).  The dword-per-lane kernels
 // above move 256 B per wave-instruction and ran at 1.7-2 TB/s (rocprofv3, config 2: 23 us for ~40 MB): the
 // address path handles a wave-instruction in >= 16 cycles whatever its width.  Here a thread owns 4 consecutive
-// columns x 8 rows (rows rp + 64 j, rp = 0..63): 16-byte loads / stores (1 KiB per wave-instruction = 16 rows x 64 B),
+// columns x 4 rows (rows rp + 128 j, rp = 0..127; 512 threads): 16-byte loads / stores (1 KiB per wave-instruction = 16 rows x 64 B),
 // two slabs in flight at a time, column sums by xor-shuffles over the 16 row phases of a wave + a 4-wave LDS step.
 // ------------------------------------------------------------------------------------------------
-#define BN4_RP 64
-#define BN4_MAXR 8
+#define BN4_RP 128
+#define BN4_MAXR 4
+#define BN4_NW 8          // waves per workgroup (512 threads)
 typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -381,12 +395,36 @@ __device__ __forceinline__ float4 col_reduce4(float4 v, float (*sh)[BN_CW], int 
     __syncthreads();
     if (lane < 4) { sh[wid][4 * lane] = v.x; sh[wid][4 * lane + 1] = v.y; sh[wid][4 * lane + 2] = v.z; sh[wid][4 * lane + 3] = v.w; }
     __syncthreads();
-    float4 t;
-    t.x = sh[0][4 * cq] + sh[1][4 * cq] + sh[2][4 * cq] + sh[3][4 * cq];
-    t.y = sh[0][4 * cq + 1] + sh[1][4 * cq + 1] + sh[2][4 * cq + 1] + sh[3][4 * cq + 1];
-    t.z = sh[0][4 * cq + 2] + sh[1][4 * cq + 2] + sh[2][4 * cq + 2] + sh[3][4 * cq + 2];
-    t.w = sh[0][4 * cq + 3] + sh[1][4 * cq + 3] + sh[2][4 * cq + 3] + sh[3][4 * cq + 3];
-    return t;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < BN4_NW; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += sh[w][4 * cq + e];
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+// two column sums at once (one pair of barriers): sh2 is [4][2 * BN_CW]
+__device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)[2 * BN_CW], int tid) {
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+        a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
+        b.x += __shfl_xor(b.x, m); b.y += __shfl_xor(b.y, m); b.z += __shfl_xor(b.z, m); b.w += __shfl_xor(b.w, m);
+    }
+    const int lane = tid & 63, wid = tid >> 6, cq = tid & 3;
+    __syncthreads();
+    if (lane < 4) {
+        float* d = sh2[wid] + 8 * lane;
+        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    }
+    __syncthreads();
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        t[e] = 0.f;
+#pragma unroll
+        for (int w = 0; w < BN4_NW; ++w) t[e] += sh2[w][8 * cq + e];
+    }
+    a = make_float4(t[0], t[1], t[2], t[3]);
+    b = make_float4(t[4], t[5], t[6], t[7]);
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
@@ -416,8 +454,8 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[BN4_MAXR], 
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = threadIdx.x + 256 * i, cc = q >> 6, r8 = (q & 63) * 8;
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 512 * i, cc = q >> 6, r8 = (q & 63) * 8;
         if (col0 + cc < N && r8 < B) {        // B is a multiple of 8 in bf16 mode
             const unsigned* sp = reinterpret_cast<const unsigned*>(tl + cc * BN_TS + r8);
             *reinterpret_cast<uint4*>(outT_bf + (long long)(col0 + cc) * B + r8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
@@ -425,9 +463,9 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[BN4_MAXR], 
     }
 }
 
-__global__ __launch_bounds__(256) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
+__global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                           float slope, const uint64_t* rng) {
-    __shared__ float sh[4][BN_CW];
+    __shared__ float sh[BN4_NW][BN_CW];
     __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * BN_TS];
     int pi = 0;
 #pragma unroll
@@ -448,16 +486,54 @@ __global__ __launch_bounds__(256) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
         const int row = rp + j * BN4_RP;
         roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
     }
+    // latency order: parameter loads and the first two slabs are issued first; the Philox keep words (pure VALU,
+    // ~100 instructions per call) are computed while those loads are in flight (they cost 3.7 us per launch when they
+    // sat behind the statistics: rocprofv3, tools/trace_bn.sh)
+    float ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, rm_old[4] = {0.f, 0.f, 0.f, 0.f}, rv_old[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ga[e] = P.gamma[col + e]; be[e] = P.beta[col + e]; }
+        if (rp == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rm_old[e] = P.rmean[col + e]; rv_old[e] = P.rvar[col + e]; }
+        }
+    }
+    const bool drop = p_drop > 0.f;
+    const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    const uint32_t thr = drop_threshold16(p_drop);
+    unsigned mk[BN4_MAXR];
+    if (drop && P.mask) {
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+    }
     float4 v[BN4_MAXR];
 #pragma unroll
     for (int j = 0; j < BN4_MAXR; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned keepbits = 0xFFFFFFFFu;              // bit 4 j + e: element (row j, column e) of this thread is kept
     for (int s = 0; s < nslab; s += 2) {
         float4 a[BN4_MAXR], b[BN4_MAXR];
         const bool two = s + 1 < nslab;
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) a[j] = buf_f32x4(h_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
+        for (int j = 0; j < BN4_MAXR; ++j) a[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
+        for (int j = 0; j < BN4_MAXR; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
+        if (s == 0 && drop) {                     // VALU work under the loads just issued
+            keepbits = 0u;
+#pragma unroll
+            for (int j = 0; j < BN4_MAXR; ++j) {
+                if (P.mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keepbits |= (((mk[j] >> (8 * e)) & 0xFFu) != 0 ? 1u : 0u) << (4 * j + e);
+                } else if ((j & 1) == 0) {        // rows rp + 128 j and rp + 128 (j + 1): low / high halves of one call
+                    const Philox4 r = drop_rand4(rng, P.rng_stream, col, rp + j * BN4_RP);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        keepbits |= ((r.v[e] & 0xFFFFu) >= thr ? 1u : 0u) << (4 * j + e);
+                        keepbits |= ((r.v[e] >> 16) >= thr ? 1u : 0u) << (4 * (j + 1) + e);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < BN4_MAXR; ++j) {
             v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w;
@@ -481,30 +557,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     float4 var = col_reduce4(sq, sh, tid);
     var.x /= fB; var.y /= fB; var.z /= fB; var.w /= fB;
     const float4 invstd = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
-    float ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
-    if (cok) {
+    if (cok && rp == 0) {
+        const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, vv[4] = {var.x, var.y, var.z, var.w};
+        const float iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ga[e] = P.gamma[col + e]; be[e] = P.beta[col + e]; }
-        if (rp == 0) {
-            const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, vv[4] = {var.x, var.y, var.z, var.w};
-            const float iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                P.smean[col + e] = mv[e];
-                P.sinvstd[col + e] = iv[e];
-                const float unb = B > 1 ? vv[e] * ((float)B / (float)(B - 1)) : vv[e];
-                P.rmean[col + e] = (1.f - momentum) * P.rmean[col + e] + momentum * mv[e];
-                P.rvar[col + e] = (1.f - momentum) * P.rvar[col + e] + momentum * unb;
-            }
+        for (int e = 0; e < 4; ++e) {
+            P.smean[col + e] = mv[e];
+            P.sinvstd[col + e] = iv[e];
+            const float unb = B > 1 ? vv[e] * ((float)B / (float)(B - 1)) : vv[e];
+            P.rmean[col + e] = (1.f - momentum) * rm_old[e] + momentum * mv[e];
+            P.rvar[col + e] = (1.f - momentum) * rv_old[e] + momentum * unb;
         }
-    }
-    const bool drop = p_drop > 0.f;
-    const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    const uint32_t thr = jamie_drop_threshold(p_drop);
-    unsigned mk[BN4_MAXR];
-    if (drop && P.mask) {
-#pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
     }
 #pragma unroll
     for (int j = 0; j < BN4_MAXR; ++j) {
@@ -515,28 +578,23 @@ __global__ __launch_bounds__(256) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
             if (nslab > 1) *reinterpret_cast<float4*>(P.h + o) = v[j];
             const float hv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
             const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
-            Philox4 r;
-            r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
-            if (drop && !P.mask) r = drop_rand4(rng, P.rng_stream, col, row);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = (hv[e] - mv[e]) * iv[e] * ga[e] + be[e];
                 t = t > 0.f ? t : slope * t;
-                if (drop) {
-                    const bool keep = P.mask ? (((mk[j] >> (8 * e)) & 0xFFu) != 0) : (r.v[e] >= thr);
-                    t = keep ? t * keep_scale : 0.f;
-                }
+                if (drop) t = ((keepbits >> (4 * j + e)) & 1u) ? t * keep_scale : 0.f;
                 y[e] = t;
             }
-            if (P.out) *reinterpret_cast<float4*>(P.out + o) = make_float4(y[0], y[1], y[2], y[3]);
+            if (P.out && (!(JAMIE_BN_ABL & 2) || y[0] == 123.456f)) *reinterpret_cast<float4*>(P.out + o) = make_float4(y[0], y[1], y[2], y[3]);
         }
         v[j] = make_float4(y[0], y[1], y[2], y[3]);
     }
-    if (P.out_bf || P.outT_bf) strip_out_bf16x4(v, P.out_bf, P.outT_bf, tl, B, N, col0, cq, rp, cok);
+    if ((P.out_bf || P.outT_bf) && (!(JAMIE_BN_ABL & 2) || v[0].x == 123.456f)) strip_out_bf16x4(v, P.out_bf, P.outT_bf, tl, B, N, col0, cq, rp, cok);
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng) {
-    __shared__ float sh[4][BN_CW];
+__global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng) {
+    __shared__ float sh[BN4_NW][BN_CW];
+    __shared__ float sh2[BN4_NW][2 * BN_CW];
     __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * BN_TS];
     int pi = 0;
 #pragma unroll
@@ -554,7 +612,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     }
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    const uint32_t thr = jamie_drop_threshold(p_drop);
+    const uint32_t thr = drop_threshold16(p_drop);
     const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
     const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.da, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
@@ -571,6 +629,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     for (int j = 0; j < BN4_MAXR; ++j) xnv[j] = buf_f32x4(h_rs, roff[j]);
 #pragma unroll
     for (int j = 0; j < BN4_MAXR; ++j) dyv[j] = buf_f32x4(d_rs, roff[j]);
+    unsigned mk[BN4_MAXR];
+    if (drop && P.mask) {
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+    }
+    unsigned keepbits = 0xFFFFFFFFu;              // Philox keep words under the loads in flight (see the forward kernel)
+    if (drop) {
+        keepbits = 0u;
+#pragma unroll
+        for (int j = 0; j < BN4_MAXR; ++j) {
+            if (P.mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) keepbits |= (((mk[j] >> (8 * e)) & 0xFFu) != 0 ? 1u : 0u) << (4 * j + e);
+            } else if ((j & 1) == 0) {
+                const Philox4 r = drop_rand4(rng, P.rng_stream, col, rp + j * BN4_RP);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    keepbits |= ((r.v[e] & 0xFFFFu) >= thr ? 1u : 0u) << (4 * j + e);
+                    keepbits |= ((r.v[e] >> 16) >= thr ? 1u : 0u) << (4 * (j + 1) + e);
+                }
+            }
+        }
+    }
     for (int s = 1; s < nslab; ++s) {
         float4 a[BN4_MAXR];
 #pragma unroll
@@ -578,28 +659,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
 #pragma unroll
         for (int j = 0; j < BN4_MAXR; ++j) { dyv[j].x += a[j].x; dyv[j].y += a[j].y; dyv[j].z += a[j].z; dyv[j].w += a[j].w; }
     }
-    unsigned mk[BN4_MAXR];
-    if (drop && P.mask) {
-#pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
-    }
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < BN4_MAXR; ++j) {
         const int row = rp + j * BN4_RP;
         const bool ok = cok && row < B;
-        Philox4 r;
-        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
-        if (ok && drop && !P.mask) r = drop_rand4(rng, P.rng_stream, col, row);
         float d[4] = {dyv[j].x, dyv[j].y, dyv[j].z, dyv[j].w}, x[4] = {xnv[j].x, xnv[j].y, xnv[j].z, xnv[j].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xn = ok ? (x[e] - mean[e]) * invstd[e] : 0.f;
             float dd = d[e];
-            if (drop) {
-                const bool keep = P.mask ? (((mk[j] >> (8 * e)) & 0xFFu) != 0) : (r.v[e] >= thr);
-                dd = keep ? dd * keep_scale : 0.f;
-            }
+            if (drop) dd = ((keepbits >> (4 * j + e)) & 1u) ? dd * keep_scale : 0.f;
             const float y = xn * ga[e] + be[e];
             dd = ok ? (y > 0.f ? dd : dd * slope) : 0.f;
             x[e] = xn; d[e] = dd;
@@ -609,8 +679,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
         s1.x += d[0]; s1.y += d[1]; s1.z += d[2]; s1.w += d[3];
         s2.x += d[0] * x[0]; s2.y += d[1] * x[1]; s2.z += d[2] * x[2]; s2.w += d[3] * x[3];
     }
-    const float4 dbeta = col_reduce4(s1, sh, tid);
-    const float4 dgamma = col_reduce4(s2, sh, tid);
+    col_reduce4x2(s1, s2, sh2, tid);
+    const float4 dbeta = s1, dgamma = s2;
     const float invB = 1.f / (float)B;
     const float k1[4] = {dbeta.x * invB, dbeta.y * invB, dbeta.z * invB, dbeta.w * invB};
     const float k2[4] = {dgamma.x * invB, dgamma.y * invB, dgamma.z * invB, dgamma.w * invB};
@@ -684,7 +754,7 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel, dim3(blocks), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
     else
@@ -728,7 +798,7 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
+        hipLaunchKernelGGL(bn_act_bwd4_kernel, dim3(blocks), dim3(512), 0, st, g, p_drop, slope, rng);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
     else
