@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libjamie_hip.so')
+# JAMIE_HIP_LIB: load a diagnostic build (tools/stamp_gemm_bf16.sh) instead of the in-tree product library
+LIB_PATH = os.environ.get('JAMIE_HIP_LIB') or os.path.join(_HERE, 'libjamie_hip.so')
 
 MAX_GROUP = 4
 NT, NN, TN = 0, 1, 2
@@ -190,15 +191,22 @@ def record_callable(fn):
 
 
 def replay(plan):
+    global _stream_override
     st = _stream()
     lib_err = None
-    for fn, args in plan:
-        if args is None:
-            fn()
-        else:
-            rc = fn(*args[:-1], st)          # the stream is the last argument of every launch entry point
-            if rc:
-                lib_err = rc
+    try:
+        for fn, args in plan:
+            if fn is _SET_STREAM:                # later entries launch on another HIP stream (None = torch's current)
+                _stream_override = args
+                st = _stream()
+            elif args is None:
+                fn()
+            else:
+                rc = fn(*args[:-1], st)          # the stream is the last argument of every launch entry point
+                if rc:
+                    lib_err = rc
+    finally:
+        _stream_override = None
     if lib_err:
         _check(lib_err)
 
@@ -210,8 +218,26 @@ def _call(name, *args):
     _check(fn(*args))
 
 
+# launches go to torch's current HIP stream unless `set_stream` names another one (the optimiser stream of the
+# pipelined step, engine.TrainEngine.enable_pipeline); stream switches are plan entries too
+_SET_STREAM = object()
+_stream_override = None
+
+
+def set_stream(stream):
+    """Launch the following ops on `stream` (a torch.cuda.Stream; None = back to torch's current stream)."""
+    global _stream_override
+    _stream_override = stream
+    if _rec is not None:
+        _rec.append((_SET_STREAM, stream))
+
+
+def current_stream():
+    return _stream_override if _stream_override is not None else torch.cuda.current_stream()
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(current_stream().cuda_stream)
 
 
 def ptr(t):

@@ -38,6 +38,22 @@ struct GemmBGroup { GemmBDev p[JAMIE_MAX_GROUP]; int count; };
 
 #define JB_OOB 0xFFFFFFF0u
 
+// Diagnostic build only (-DJAMIE_GEMMB_STAMP, tools/stamp_gemm_bf16.sh): thread 0 of every workgroup of the large-tile
+// kernel writes s_memrealtime (100 MHz) at entry / tile 0 published / k-loop done / stores issued into a buffer of its
+// own that nothing else reads.  No stamp exists in the product build.
+#ifdef JAMIE_GEMMB_STAMP
+#define JB_NSTAMP 8
+__device__ unsigned long long jamie_dbg_stamps[8192 * JB_NSTAMP];
+#define JB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) jamie_dbg_stamps[blockIdx.x * JB_NSTAMP + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define JB_STAMPV(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) jamie_dbg_stamps[blockIdx.x * JB_NSTAMP + (k)] = (unsigned long long)(v); } while (0)
+extern "C" int jamie_debug_stamps(unsigned long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(jamie_dbg_stamps), sizeof(unsigned long long) * JB_NSTAMP * n_blocks);
+}
+#else
+#define JB_STAMP(k) do {} while (0)
+#define JB_STAMPV(k, v) do {} while (0)
+#endif
+
 // D = register prefetch depth: the global loads of tiles kt+1 .. kt+D are in flight while tile kt is multiplied.  With
 // a 64x64x64 tile a k-step is only 128 MFMA cycles per wave, far less than one HBM round trip, so D = 1 pays one
 // memory latency per k-step; D = 3 divides that by three (counted vmcnt waits come from the compiler: the loads are
@@ -473,6 +489,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * T_SZ];
     float* red = reinterpret_cast<float*>(smem);
 
+    JB_STAMP(0);
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     int slot = bid >> 3;
@@ -502,6 +519,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     const int kend = min(P.K, kbeg + P.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
+    JB_STAMPV(4, pi * 1000 + nk);
+    JB_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));   // XCC_ID, HW_ID cu/se bits
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
@@ -587,6 +606,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     wait_tile(0, min(NB, nk) - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    JB_STAMP(1);
     read_frags(smem, 0, 0);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -624,53 +644,76 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
         cur = nxt;
     }
     __syncthreads();
+    JB_STAMP(2);
 
     // ---- epilogue: transposed C/D map -> m = lane & 31, n = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) ----
+    // Stored straight from that map a wave-instruction writes 32 rows x 32 bytes: 32 partial lines per instruction, and
+    // the stores of a tile took 6.5-9 us (in-kernel stamps, tools/stamp_gemm_bf16.py) during which the workgroup keeps
+    // its LDS and wave slots.  So every wave first turns its 32-row strips through a private LDS scratch (the k-loop's
+    // buffers are free now) and then writes whole row segments: TN * 128 contiguous bytes per row, 64 / (TN * 8) rows
+    // per instruction.
     float* Cout = P.C + (long long)ks * P.slab_stride;
     const bool add_bias = (P.bias != nullptr) && ks == 0;
     float local = 0.f;
+    // scratch row stride in floats: 16 B pad (conflict-free b128 writes) wherever the LDS of the k-loop has room for it
+    constexpr int SROW = TN * 32 + ((NB * T_SZ >= NW * 32 * (TN * 32 + 4) * 4) ? 4 : 0);
+    constexpr int CPR = TN * 8, RPI = 64 / CPR;       // 16-byte chunks per row segment, rows per wave-instruction
+    static_assert(NB * T_SZ >= NW * 32 * SROW * 4 && 64 % CPR == 0, "epilogue scratch");
+    float* scr = reinterpret_cast<float*>(smem) + wid * (32 * SROW);
+    const int cch = lane % CPR, rsub = lane / CPR;
+    const int nc = n0 + wn0 + cch * 4;                // first of this lane's 4 output columns
+    const bool v4 = P.vec && nc + 3 < P.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add_bias) {
+        if (v4) b4 = *reinterpret_cast<const float4*>(P.bias + nc);
+        else {
+            if (nc < P.N) b4.x = P.bias[nc];
+            if (nc + 1 < P.N) b4.y = P.bias[nc + 1];
+            if (nc + 2 < P.N) b4.z = P.bias[nc + 2];
+            if (nc + 3 < P.N) b4.w = P.bias[nc + 3];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm0 + i * 32 + r;
-        if (m >= P.M) continue;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n4 = n0 + wn0 + j * 32 + 8 * q + 4 * h;
-                if (n4 >= P.N) continue;
-                float* cp = Cout + (long long)m * P.ldc + n4;
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (P.vec && n4 + 3 < P.N) {
-                    if (add_bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + n4);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(scr + r * SROW + j * 32 + 8 * q + 4 * h) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+#pragma unroll
+        for (int rr = 0; rr < 32 / RPI; ++rr) {
+            const int row = rr * RPI + rsub;
+            const float4 a4 = *reinterpret_cast<const float4*>(scr + row * SROW + cch * 4);
+            const int m = m0 + wm0 + i * 32 + row;
+            if (m >= P.M || nc >= P.N) continue;
+            float* cp = Cout + (long long)m * P.ldc + nc;
+            float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
+            if (v4) {
+                if (P.epi == JAMIE_EPI_STORE) {
+                    if (P.accumulate) {
+                        const float4 o = *reinterpret_cast<const float4*>(cp);
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                     }
+                } else {  // JAMIE_EPI_MSE
+                    const float4 x = *reinterpret_cast<const float4*>(P.aux0 + (long long)m * P.aux_ld + nc);
+                    v[0] -= x.x; v[1] -= x.y; v[2] -= x.z; v[3] -= x.w;
+                    local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
+                }
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (nc + e >= P.N) continue;
+                    float w = v[e];
                     if (P.epi == JAMIE_EPI_STORE) {
-                        if (P.accumulate) {
-                            const float4 o = *reinterpret_cast<const float4*>(cp);
-                            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-                        }
-                    } else {  // JAMIE_EPI_MSE
-                        const float4 x = *reinterpret_cast<const float4*>(P.aux0 + (long long)m * P.aux_ld + n4);
-                        v[0] -= x.x; v[1] -= x.y; v[2] -= x.z; v[3] -= x.w;
-                        local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-                        v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
-                    }
-                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n4 + e >= P.N) continue;
-                        float w = v[e] + (add_bias ? P.bias[n4 + e] : 0.f);
-                        if (P.epi == JAMIE_EPI_STORE) {
-                            if (P.accumulate) w += cp[e];
-                            cp[e] = w;
-                        } else {
-                            const float d = w - P.aux0[(long long)m * P.aux_ld + n4 + e];
-                            local += d * d;
-                            cp[e] = d * P.scale;
-                        }
+                        if (P.accumulate) w += cp[e];
+                        cp[e] = w;
+                    } else {
+                        const float d = w - P.aux0[(long long)m * P.aux_ld + nc + e];
+                        local += d * d;
+                        cp[e] = d * P.scale;
                     }
                 }
             }
@@ -680,6 +723,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
     }
+#ifdef JAMIE_GEMMB_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    JB_STAMP(3);
+#endif
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int D>

@@ -205,6 +205,47 @@ class TrainEngine:
         self._dsig_tmp = torch.zeros(self.M, **f32)
         self._timing = None
         self._timing_every, self._timing_step = 1, 0
+        self.pipeline = False            # enable_pipeline(): optimiser on its own stream, overlapped with the next forward
+
+    # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
+    # Adam is HBM-bound (28 B/parameter) and the forward GEMMs are bound by the L2 -> LDS fabric and the matrix pipe, so
+    # the two share the chip well.  The flat buffers are layer-major, so the update is issued as four contiguous
+    # launches in FORWARD order (enc0 | enc1+head+dec0 | dec1 | dec2, about a quarter of the parameters each); the
+    # forward pass of the next step waits, layer by layer, for the event of the group it is about to read.  Every
+    # element sees exactly the update of the one-launch form (bit-identical, tests/test_hip_step.py).
+    PIPE_GROUPS = (('enc0',), ('enc1', 'head', 'dec0'), ('dec1',), ('dec2',))
+    PIPE_WAIT = {'enc0': 0, 'enc1': 1, 'dec1': 2, 'dec2': 3}
+
+    def enable_pipeline(self, priority=0):
+        """Run clip + Adam (and the bf16 weight transposes) on a side stream; `flush()` before anything other than
+        the next training step reads the parameters."""
+        self.pipeline = True
+        self.opt_stream = torch.cuda.Stream(device=self.dev, priority=priority)
+        self._ev_grads = torch.cuda.Event()
+        self._ev_params = [torch.cuda.Event() for _ in self.PIPE_GROUPS]
+        self._opt_pending = False
+
+    def _both(self, fn):
+        """Run `fn` now and, while a plan is being recorded, make it a plan entry as well."""
+        nv.record_callable(fn)
+        fn()
+
+    def _wait_params(self, lin):
+        g = self.PIPE_WAIT.get(lin) if self.pipeline else None
+        if g is None:
+            return
+        ev = self._ev_params[g]
+
+        def fn():
+            if self._opt_pending:
+                nv.current_stream().wait_event(ev)
+        self._both(fn)
+
+    def flush(self):
+        """Make torch's current stream wait for the optimiser stream (parameters, Adam moments, bf16 copies)."""
+        if self.pipeline and self._opt_pending:
+            for ev in self._ev_params:
+                torch.cuda.current_stream().wait_event(ev)
 
     # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
     def set_kl_anneal(self, anneal):
@@ -228,7 +269,7 @@ class TrainEngine:
             if self._timing is None or label not in self._timing or self._timing_step % self._timing_every:
                 return
             e = torch.cuda.Event(enable_timing=True)
-            e.record()
+            e.record(nv.current_stream())
             lst = self._timing[label]
             if which == 0:
                 lst.append([e, None])
@@ -253,12 +294,12 @@ class TrainEngine:
         return float(t.mean())
 
     # ---- bf16 compute mode: bf16 / bf16-transposed copies of GEMM operands ----
-    def refresh_weights_bf16(self, transposes_only=False):
+    def refresh_weights_bf16(self, transposes_only=False, lins=('enc0', 'enc1', 'head', 'dec0', 'dec1', 'dec2')):
         """bf16 copy of every weight matrix (written by the Adam kernel itself during training) and the
         K-contiguous transposed copies the dX products read."""
         probs = []
         for i, d in enumerate(self.dims):
-            for lin in ('enc0', 'enc1', 'head', 'dec0', 'dec1', 'dec2'):
+            for lin in lins:
                 W = self.m.p[f'm{i}.{lin}.W']
                 wt = self.wT.get(f'm{i}.{lin}')
                 if transposes_only and wt is None:
@@ -267,7 +308,8 @@ class TrainEngine:
                     probs.append(nv.cast_problem(self.wbf[f'm{i}.{lin}.W'], None, wt))
                 else:
                     probs.append(nv.cast_problem(W, self.wbf[f'm{i}.{lin}.W'], wt))
-        nv.cast_transpose(probs)
+        if probs:
+            nv.cast_transpose(probs)
 
     def _cast(self, key):
         """fp32 activation / gradient `key` ([B, n] or slab 0 of [S, B, n]) -> bf16 [B, n] and bf16 [n, B]."""
@@ -335,6 +377,7 @@ class TrainEngine:
                                          bias=P[f'm{i}.{lin}.b'] if with_bias else None,
                                          splitk=w['sk'][sk_key], slab_stride=self.B * nout))
         cfg = self.gcfg.get(sk_key, -1)
+        self._wait_params(lin)
         self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') else lin,
                      (lambda: nv.gemm_bf16(probs, cfg)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
 
@@ -381,18 +424,20 @@ class TrainEngine:
             self._dw_gemm(dy_key, a_key, lin)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
+        # the dX tiles run 2-3x as long as the dW tiles (K = features / slices vs K = batch): they go first in the
+        # grid so that the short dW tiles fill in behind them (in-kernel stamps: the launch ends 4-5 us earlier)
         probs = []
+        for i, d in enumerate(self.dims):
+            w = self.ws[i]
+            nout, nin = self.g[f'm{i}.{lin}.W'].shape
+            probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
+                                         nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         for i, d in enumerate(self.dims):
             w = self.ws[i]
             dW = self.g[f'm{i}.{lin}.W']
             nout, nin = dW.shape
             probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
                                          accumulate=self.accumulate))
-        for i, d in enumerate(self.dims):
-            w = self.ws[i]
-            nout, nin = self.g[f'm{i}.{lin}.W'].shape
-            probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
-                                         nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
@@ -548,6 +593,7 @@ class TrainEngine:
                                          aux_ld=d, partial=self.rec_partials[off:off + self.rec_tiles[i]],
                                          scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
             off += self.rec_tiles[i]
+        self._wait_params('dec2')
         self._launch('enc_gemm', (lambda: nv.gemm_bf16(probs)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
         self._cast('dxhat')
         return lat
@@ -586,11 +632,32 @@ class TrainEngine:
     def optimizer_step(self):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step)."""
         nv.grad_sqnorm(self.grad, self.norm_partials, self.state)
-        self._launch('adam', lambda: nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq,
-                                                   self.norm_partials, self.hyper, self.state,
-                                                   self.wbf_flat if self.bf16 else None))
-        if self.bf16:
-            self.refresh_weights_bf16(transposes_only=True)
+        if not self.pipeline:
+            self._launch('adam', lambda: nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq,
+                                                       self.norm_partials, self.hyper, self.state,
+                                                       self.wbf_flat if self.bf16 else None))
+            if self.bf16:
+                self.refresh_weights_bf16(transposes_only=True)
+            return
+        # pipelined: the optimiser stream takes over once the gradient norm is known; it hands the parameter groups
+        # back one by one (events) while the main stream already runs the next step's sampler, gather and forward
+        opt = self.opt_stream
+        self._both(lambda: (self._ev_grads.record(nv.current_stream()), opt.wait_event(self._ev_grads)))
+        nv.set_stream(opt)
+        try:
+            regions = self.m.layout.regions
+            for g, names in enumerate(self.PIPE_GROUPS):
+                lo, hi = regions[names[0]][0], regions[names[-1]][1]
+                self._launch('adam', lambda: nv.clip_adam(self.m.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi],
+                                                           self.exp_avg_sq[lo:hi], self.norm_partials, self.hyper,
+                                                           self.state, self.wbf_flat[lo:hi] if self.bf16 else None))
+                if self.bf16:
+                    self.refresh_weights_bf16(transposes_only=True, lins=names)
+                ev = self._ev_params[g]
+                self._both(lambda ev=ev: ev.record(opt))
+        finally:
+            nv.set_stream(None)
+        self._opt_pending = True
 
     def step(self, corr=None, Fblk=None, noise=None, allreduce=None):
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an

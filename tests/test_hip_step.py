@@ -479,6 +479,48 @@ def test_plan_replay_equals_eager_steps(jam, mode):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('use_plan', [False, True])
+def test_pipelined_optimizer_is_bit_identical(jam, mode, use_plan):
+    """clip + Adam on the optimiser stream, group by group under the next step's forward pass
+    (TrainEngine.enable_pipeline), produces exactly the parameters, moments and bf16 copies of the one-launch form."""
+    from jamie_amd import _native as nv
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    dims, L, B, N = (264, 136), 8, 128, 2048
+    g = torch.Generator().manual_seed(0)
+    data = [torch.randn(N, d, generator=g).cuda() for d in dims]
+    out = []
+    for pipe in (False, True):
+        torch.manual_seed(9)
+        model = edModelVar(dims, L)
+        eng = TrainEngine(model, B, compute_dtype=mode, seed=21)
+        if pipe:
+            eng.enable_pipeline()
+        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+        if use_plan:
+            plan = eng.make_plan(data, idx, N)
+            for _ in range(7):
+                eng.run_plan(plan)
+        else:
+            for _ in range(8):
+                nv.sample_indices(idx, N, 0, False, eng.state, 200)
+                eng.load_batch(data, [idx, idx])
+                eng.step()
+        eng.flush()
+        ls = eng.read_losses()
+        out.append((model.flat.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(),
+                    eng.wbf_flat.clone() if mode == 'bf16' else None,
+                    {k: v.clone() for k, v in eng.wT.items()} if mode == 'bf16' else {}, ls))
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[5] == b[5]
+    if mode == 'bf16':
+        assert torch.equal(a[3], b[3])
+        for k in a[4]:
+            assert torch.equal(a[4][k], b[4][k]), k
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
 def test_facade_device_sampler_plan_path(jam, mode):
     """sampler='device' + identity P takes the recorded-plan fast path; bf16 compute through the facade."""
     import io

@@ -1,0 +1,59 @@
+"""GPU diagnostic: timeline of the large-tile bf16 GEMM from in-kernel s_memrealtime stamps (diagnostic build,
+tools/stamp_gemm_bf16.sh).  Per workgroup: entry, tile 0 published, k-loop done, stores retired."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from jamie_amd import _native as nv
+nv.require_gpu()
+lib = nv.load()
+B, d = 512, (2000, 1000)
+NBUF = int(os.environ.get('NBUF', '6'))
+def T(*s): return torch.randn(*s, device='cuda').to(torch.bfloat16)
+def run(name, shapes, cfg, sks, iters=13):
+    sets = []
+    for b in range(NBUF):
+        probs = []
+        for (M, N, K), s1 in zip(shapes, sks):
+            probs.append(nv.gemm_problem(T(M, K), T(N, K), torch.empty(s1, M, N, device='cuda'), M, N, K, K, K, N, splitk=s1, slab_stride=M * N))
+        sets.append(probs)
+    for i in range(iters): nv.gemm_bf16(sets[i % NBUF], cfg)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); nv.gemm_bf16(sets[iters % NBUF], cfg); e1.record(); torch.cuda.synchronize()
+    nb = 8192
+    buf = (C.c_ulonglong * (8 * nb))()
+    lib.jamie_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+    assert lib.jamie_debug_stamps(buf, nb) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
+    a = a[a[:, 3] > 0]
+    # keep the blocks of the last launch only (stamps of earlier, larger launches would be stale)
+    a = a[a[:, 0] > a[:, 0].max() - 30000]          # the last launch only (300 us window)
+    t0 = a[:, 0].min()
+    us = lambda x: x / 100.0
+    st, pro, loop, epi, end = us(a[:, 0] - t0), us(a[:, 1] - a[:, 0]), us(a[:, 2] - a[:, 1]), us(a[:, 3] - a[:, 2]), us(a[:, 3] - t0)
+    print(f'== {name} cfg {cfg} sk {sks}: {len(a)} workgroups, event {e0.elapsed_time(e1)*1e3:.1f} us, last end {end.max():.1f} us')
+    q = lambda v: f'min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}'
+    print('  start    ', q(st)); print('  prologue ', q(pro)); print('  k-loop   ', q(loop)); print('  epilogue ', q(epi)); print('  end      ', q(end))
+    for pi in sorted(set(a[:, 4] // 1000)):
+        m = a[:, 4] // 1000 == pi
+        nk = a[m, 4] % 1000
+        print(f'  problem {pi}: {m.sum()} wgs, nk {nk.min()}..{nk.max()}, loop med {np.median(loop[m]):.2f} us = {np.median(loop[m]) / np.median(nk) * 1e3:.0f} ns/k-step, epi med {np.median(epi[m]):.2f}, start med {np.median(st[m]):.2f}, end max {end[m].max():.2f}')
+    cu = a[:, 5]
+    cnt = np.unique(cu, return_counts=True)[1]
+    print(f'  distinct CUs {len(cnt)}, workgroups per CU min {cnt.min()} max {cnt.max()}')
+    busy = {}
+    for c, e in zip(cu, end): busy[c] = max(busy.get(c, 0), e)
+    bv = np.array(list(busy.values()))
+    print(f'  per-CU last end: min {bv.min():.1f} med {np.median(bv):.1f} max {bv.max():.1f}')
+cases = {
+ 'fwd_d2d': ([(B, 2 * x, x) for x in d], 23, (3, 2)),
+ 'fwd_2dd': ([(B, x, 2 * x) for x in d], 24, (3, 2)),
+ 'bwd_dec1': ([(2 * x, x, B) for x in d] + [(B, x, 2 * x) for x in d], 25, (1, 1, 4, 2)),
+ 'bwd_enc1': ([(x, 2 * x, B) for x in d] + [(B, 2 * x, x) for x in d], 25, (1, 1, 2, 1)),
+ 'dw_only': ([(2 * x, x, B) for x in d], 25, (1, 1)),
+ 'bwd_dec1_r': ([(B, x, 2 * x) for x in d] + [(2 * x, x, B) for x in d], 25, (4, 2, 1, 1)),      # dX problems first
+ 'bwd_enc1_r': ([(B, 2 * x, x) for x in d] + [(x, 2 * x, B) for x in d], 25, (2, 1, 1, 1)),
+}
+for k in os.environ.get('CASES', 'fwd_d2d,fwd_2dd,bwd_dec1,bwd_dec1_r,bwd_enc1,bwd_enc1_r').split(','):
+    shapes, cfg, sks = cases[k]
+    run(k, shapes, int(os.environ.get('CFG', cfg)), sks)
