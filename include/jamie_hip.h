@@ -248,6 +248,40 @@ typedef struct { const float* X; float* out; int M, N, ld, nslab; long long slab
 /* the same for up to JAMIE_MAX_GROUP matrices in one launch (the modalities) */
 int jamie_colsum_group(const jamie_colsum_problem* problems /*host*/, int count, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Correspondence stage: JAMIE.Prime_Dual (jamie/jamie.py:314-414, MultiOmics branch), SURVEY.md §8(f) rank 3.
+ * The seven dense products per iteration of the reference become four jamie_gemm_f32 launches issued by the
+ * host (T1 = F^T (F Ky), G1 = (F Ky) T1, F Ky and G2 = Kx (F Ky) for the new F); the element-wise rest of one
+ * iteration is the two entry points below.  All matrices are contiguous row-major fp32 on the device.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    float* F;            /* [m,n] correspondence matrix, updated in place (jamie.py:339, 384) */
+    const float* G1;     /* [m,n] (F Ky)(F^T F Ky) for the current F (jamie.py:358-359) */
+    const float* G2;     /* [m,n] Kx F Ky for the current F (jamie.py:360) */
+    float* m1;           /* [m,n] first / second moment (jamie.py:350-351, 376-377) */
+    float* m2;
+    float* Mu;           /* [m]  dual variable (jamie.py:343, 393) */
+    float* Lambda;       /* [n]  dual variable (jamie.py:342, 394) */
+    float* S;            /* [n]  slack (jamie.py:344, 386-390) */
+    float* rowsum;       /* [m]  F 1   of the current F, replaced by that of the new F */
+    float* colsum;       /* [n]  F^T 1 of the current F, replaced by that of the new F */
+    const float* alpha;  /* [1]  scaling factor a (jamie.py:335, 397-402) */
+    float* rowpart;      /* workspace, jamie_pd_workspace() elements */
+    float* colpart;
+    int m, n;
+    float rho, epsilon;  /* UnionCom attributes (jamie.py:365, 384) */
+} jamie_pd_state;
+/* sizes (in floats) of the two partial-sum workspaces for an [m,n] problem */
+int jamie_pd_workspace(int m, int n, long long* rowpart_elems, long long* colpart_elems);
+/* One iteration's element-wise work (jamie.py:357-394 minus the products): gradient from G1, G2 and the rank-one
+ * terms, moments with bias correction for `iteration` (1-based), projected step, F <- (1-eps) F + eps relu(F - step),
+ * then row / column sums of the new F and the S, Mu, Lambda updates.  Deterministic (no atomics). */
+int jamie_pd_step(const jamie_pd_state* state /*host*/, int iteration, void* stream);
+/* alpha[0] = sum(G2 o F) * inv_trkk = tr(Kx (F Ky) F^T) / tr(Kx Kx) for G2 = Kx F Ky (jamie.py:397-402);
+ * `partials`: n_partials <= 4096 floats of workspace */
+int jamie_pd_alpha(const float* G2, const float* F, long long count, float* partials, int n_partials, float inv_trkk,
+                   float* alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

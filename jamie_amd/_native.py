@@ -99,6 +99,13 @@ class LatentM(C.Structure):
                 ('rng_stream', C.c_int)]
 
 
+class PdState(C.Structure):
+    _fields_ = [('F', C.c_void_p), ('G1', C.c_void_p), ('G2', C.c_void_p), ('m1', C.c_void_p), ('m2', C.c_void_p),
+                ('Mu', C.c_void_p), ('Lambda', C.c_void_p), ('S', C.c_void_p), ('rowsum', C.c_void_p),
+                ('colsum', C.c_void_p), ('alpha', C.c_void_p), ('rowpart', C.c_void_p), ('colpart', C.c_void_p),
+                ('m', C.c_int), ('n', C.c_int), ('rho', C.c_float), ('epsilon', C.c_float)]
+
+
 EXPORTS = {
     'jamie_last_error': (C.c_char_p, []),
     'jamie_version': (C.c_int, []),
@@ -131,6 +138,10 @@ EXPORTS = {
     'jamie_colsum_group': (C.c_int, [C.POINTER(ColsumProblem), C.c_int, C.c_void_p]),
     'jamie_colsum': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p,
                                C.c_int, C.c_void_p]),
+    'jamie_pd_workspace': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'jamie_pd_step': (C.c_int, [C.POINTER(PdState), C.c_int, C.c_void_p]),
+    'jamie_pd_alpha': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                 C.c_void_p]),
 }
 
 _lib = None
@@ -392,3 +403,18 @@ def csr_block(indptr, indices, vals, idx0, idx1, out, row_off=0, col_off=0, norm
 
 def colsum(X, M, N, ld, out, nslab=1, slab_stride=0, accumulate=False):
     _call('jamie_colsum', ptr(X), M, N, ld, nslab, slab_stride, ptr(out), int(accumulate), _stream())
+
+
+def pd_workspace(m, n):
+    a, b = C.c_longlong(), C.c_longlong()
+    _check(load().jamie_pd_workspace(m, n, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def pd_step(state, iteration):
+    _call('jamie_pd_step', C.pointer(state), int(iteration), _stream())
+
+
+def pd_alpha(G2, F, partials, inv_trkk, alpha):
+    _call('jamie_pd_alpha', ptr(G2), ptr(F), F.numel(), ptr(partials), partials.numel(), float(inv_trkk), ptr(alpha),
+          _stream())

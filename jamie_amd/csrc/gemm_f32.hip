@@ -25,6 +25,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// diagnostic build only (tools/stamp_gemm_bf16.sh): in-kernel s_memrealtime stamps, see gemm_bf16.hip
+#ifdef JAMIE_GEMMB_STAMP
+__device__ unsigned long long jamie_dbg_stamps_f32[8192 * 8];
+#define JF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) jamie_dbg_stamps_f32[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define JF_STAMPV(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) jamie_dbg_stamps_f32[blockIdx.x * 8 + (k)] = (unsigned long long)(v); } while (0)
+extern "C" int jamie_debug_stamps_f32(unsigned long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(jamie_dbg_stamps_f32), sizeof(unsigned long long) * 8 * n_blocks);
+}
+#else
+#define JF_STAMP(k) do {} while (0)
+#define JF_STAMPV(k, v) do {} while (0)
+#endif
+
 struct GemmDev {
     const float* A; const float* B; float* C; const float* bias;
     const float* aux0; const float* aux1; const float* aux2; const float* aux3;
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     // modalities have different K, so mixing them unevenly left whole XCDs with only long or only short
     // tiles), and a weight panel is fetched from HBM into one L2 only.  Remainders are dealt round-robin
     // (rotation o_p) so the chunk sizes add up to exactly the number of blocks each XCD receives.
+    JF_STAMP(0);
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     int slot = bid >> 3;
@@ -130,6 +144,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     const int kbeg = ks * P.kchunk;
     const int kend = min(P.K, kbeg + P.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
+    JF_STAMPV(4, pi * 1000 + nk);
+    JF_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
@@ -269,6 +285,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
         store_tile(0, kbeg);
     }
     __syncthreads();
+    JF_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
@@ -325,6 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
         __syncthreads();
     }
 
+    JF_STAMP(2);
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
     float* Cout = P.C + (long long)ks * P.slab_stride;
     const bool add_bias = (P.bias != nullptr) && ks == 0;
@@ -366,6 +384,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
     }
+#ifdef JAMIE_GEMMB_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    JF_STAMP(3);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,10 +122,6 @@ class JAMIE:
         assert self.model_pca in ('pca', 'umap')
         if self.project_mode == 'tsne':
             raise NotImplementedError("project_mode='tsne' is outside the accelerated path (SURVEY.md §8)")
-        if self.use_f_tilde and self.match_result is None:
-            raise NotImplementedError(
-                'Stages A/B (compute_distances + Prime_Dual, reference jamie.py:224-414, 839-890) are outside '
-                'the accelerated path: pass use_f_tilde=False, or a precomputed match_result=[F].')
         time = time_logger(sync=torch.cuda.synchronize)
         init_random_seed(self.manual_seed)                         # jamie.py:142
         self.dataset = dataset
@@ -138,7 +134,14 @@ class JAMIE:
         self.dataset_num = len(self.dataset)
         self.row = [np.shape(d)[0] for d in self.dataset]
         self.col = [np.shape(d)[1] for d in self.dataset]
+        # stage A (host, as in the reference) and stage B (Prime_Dual on the GPU): jamie.py:162-177
+        if self.match_result is None and self.use_f_tilde:
+            if self.dataset_num != 2:
+                raise NotImplementedError('use_f_tilde=True follows the reference: two modalities')
+            self.compute_distances(save_dist=True)
         time.log('Distance')
+        if self.match_result is None and self.use_f_tilde:
+            self.match_result = self.match()
         time.log('Correspondence')
         integrated = self.project_jamie()
         time.log('Mapping')
@@ -147,6 +150,42 @@ class JAMIE:
         time.aggregate()
         print()
         return integrated
+
+    # ---- stages A / B (reference jamie.py:224-249, 314-414, 839-890) ----
+    def compute_distances(self, save_dist=True):
+        """Cell x cell distance matrix of every modality (host numpy / scipy / sklearn, as in the reference)."""
+        from .utilities import distance_matrix
+        if save_dist:
+            self.dist = []
+        print('Shape of Raw data')
+        for i in range(self.dataset_num):
+            print('Dataset {}:'.format(i), np.shape(self.dataset[i]))
+        self.distance_function = lambda df: distance_matrix(df, self.distance_mode, self.kmax)   # noqa: E731
+        if save_dist:
+            self.dist = [self.distance_function(d) for d in self.dataset]
+
+    def Prime_Dual(self, dist, dx=None, dy=None, verbose=True):
+        """reference jamie.py:314-414, on the MI355X (jamie_amd/correspondence.py); returns F as numpy float32."""
+        from .correspondence import prime_dual
+        if self.integration_type != 'MultiOmics':
+            raise NotImplementedError("Prime_Dual: integration_type 'MultiOmics' (the only one fit_transform accepts)")
+        return prime_dual(dist, dx, dy, epoch_pd=self.epoch_pd, rho=self.rho, epsilon=self.epsilon, delay=self.delay,
+                          log_pd=self.log_pd, verbose=verbose, device=self.device)
+
+    def match(self):
+        """reference jamie.py:224-249."""
+        print('Device:', self.device)
+        cor_pairs = []
+        for i in range(self.dataset_num):
+            for j in range(i + 1, self.dataset_num):
+                print('-' * 33)
+                print(f'Find correspondence between Dataset {i + 1} and Dataset {j + 1}')
+                if self.corr_method != 'unioncom':
+                    raise NotImplementedError("corr_method='jamie' is a work in progress in the reference "
+                                              '(jamie.py:241-246) and is not built')
+                cor_pairs.append(self.Prime_Dual([self.dist[i], self.dist[j]], dx=self.col[i], dy=self.col[j]))
+        print('Finished Matching!')
+        return cor_pairs
 
     def fit(self, dataset=None, P=None):
         """north_star spelling: train, return self."""
@@ -237,7 +276,9 @@ class JAMIE:
         self.sampling_method = method
         F_dense = None
         if self.use_f_tilde:
-            F_dense = torch.as_tensor(np.asarray(self.match_result[0]), dtype=torch.float32, device=dev)
+            mr = self.match_result[0]
+            F_dense = (mr.to(dev, torch.float32) if torch.is_tensor(mr)
+                       else torch.as_tensor(np.asarray(mr), dtype=torch.float32, device=dev))
         timer = time_logger(sync=torch.cuda.synchronize)
         # ---- preprocessing (host, numpy/sklearn like the reference) ----
         pre = self._build_preprocessing()

@@ -72,3 +72,58 @@ class time_logger:
             running_total += v.mean()
             print(f'{k}: {v.mean()}')
         print(f'Total: {running_total}')
+
+
+def geodesic_distances(X, kmax):
+    """`unioncom.utils.geodesic_distances` (unioncom 0.4.0, absent from /root/reference and from this image), restated
+    from its published algorithm -- PARITY UNPINNED: k-nearest-neighbour graph (k from 5, +2 until the graph is
+    connected or k exceeds max(kmax, 1 % of the cells)), all-pairs shortest paths, unreachable pairs set to twice the
+    largest finite distance.  Host side (scipy / sklearn), like every distance mode of the reference
+    (jamie.py:839-890)."""
+    import scipy.sparse.csgraph as csgraph
+    from sklearn.neighbors import NearestNeighbors
+    X = np.asarray(X)
+    kmin = 5
+
+    def graph(k):
+        nbrs = NearestNeighbors(n_neighbors=min(k, len(X)), metric='euclidean').fit(X)
+        return nbrs.kneighbors_graph(X, mode='distance')
+    knn = graph(kmin)
+    while csgraph.connected_components(knn, directed=False)[0] != 1:
+        if kmin > np.max((kmax, 0.01 * len(X))):
+            break
+        kmin += 2
+        knn = graph(kmin)
+    dist = csgraph.shortest_path(knn, method='D', directed=False)
+    finite = dist[np.isfinite(dist)]
+    dist_max = finite.max() if finite.size else 0.0
+    dist[~np.isfinite(dist)] = 2 * dist_max
+    return dist
+
+
+def distance_matrix(X, mode, kmax=40):
+    """One modality's cell x cell distance matrix, reference jamie.py:839-890 (`compute_distances`)."""
+    from scipy import stats
+    from sklearn.metrics import pairwise_distances
+    if mode == 'geodesic':                                                      # jamie.py:851-856
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return np.array(geodesic_distances(X, kmax))
+    if mode == 'spearman':                                                      # jamie.py:857-869
+        if X.shape[0] == 1:
+            return np.array([0])
+        d, _ = stats.spearmanr(X, axis=1)
+        if np.isnan(d).any():
+            raise Exception('Data is not well conditioned for spearman method '
+                            '(scipy.stats.spearmanr returned ``np.nan``)')
+        if len(np.shape(d)) == 0:
+            d = np.array([[1, d], [d, 1]])
+        return (1 - np.array(d)) / 2
+    if mode == 'pearson':                                                       # jamie.py:870-879
+        if X.shape[0] == 1:
+            return np.array([0])
+        d = np.corrcoef(X.toarray() if hasattr(X, 'toarray') else np.asarray(X))
+        if len(np.shape(d)) == 0:
+            d = np.array([[1, d], [d, 1]])
+        return (1 - np.array(d)) / 2
+    return pairwise_distances(X, metric=mode)                                   # jamie.py:880-882

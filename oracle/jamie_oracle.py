@@ -514,3 +514,72 @@ class OracleJAMIE:
             x = torch.tensor(self.pre[modality].transform(np.asarray(data))).float().to(self.dtype)
             dec = impute(self.P_, self.Bf, x, modality, to)
         return np.array(self.pre[to].inverse_transform(dec.numpy()))
+
+
+# --------------------------------------------------------------------------------------------
+# correspondence stage: Prime_Dual and the distance matrices that feed it
+# --------------------------------------------------------------------------------------------
+def prime_dual(Kx, Ky, dx, dy, epoch_pd=2000, rho=10, epsilon=1e-3, delay=0, dtype=torch.float32, history=None):
+    """jamie.py:314-414 (`integration_type == 'MultiOmics'`), all seven products per iteration as the reference
+    writes them.  Kx [m,m], Ky [n,n] distance matrices (numpy); returns F [m,n] float32 numpy.
+    `history` (list) receives the scaling factor `a` of every iteration."""
+    Kx, Ky = np.asarray(Kx), np.asarray(Ky)
+    if Kx.shape == (1, 1) and Ky.shape == (1, 1):                              # jamie.py:326-328
+        return np.ones((1, 1), np.float32)
+    N = int(np.maximum(Kx.shape[0], Ky.shape[0]))                              # jamie.py:330-334
+    Kx = torch.from_numpy(Kx / N).float().to(dtype)
+    Ky = torch.from_numpy(Ky / N).float().to(dtype)
+    a = np.sqrt(dy / dx)                                                       # jamie.py:335
+    m, n = Kx.shape[0], Ky.shape[0]
+    Fm = torch.zeros(m, n, dtype=dtype)                                        # jamie.py:339-345
+    Im, In, Inn = torch.ones(m, 1, dtype=dtype), torch.ones(n, 1, dtype=dtype), torch.ones(n, n, dtype=dtype)
+    Lambda, Mu, S = torch.zeros(n, 1, dtype=dtype), torch.zeros(m, 1, dtype=dtype), torch.zeros(n, 1, dtype=dtype)
+    pho1, pho2, delta = 0.9, 0.999, 10e-8                                      # jamie.py:347-349
+    m1, m2 = torch.zeros(m, n, dtype=dtype), torch.zeros(m, n, dtype=dtype)
+    i = 0
+    while i < epoch_pd:
+        FKy = Fm @ Ky                                                          # jamie.py:357-373
+        grad = (4 * FKy @ (Fm.t() @ FKy) - 4 * a * (Kx @ FKy) + Mu @ In.t() + Im @ Lambda.t()
+                + rho * (Fm @ Inn + Im @ (Im.t() @ Fm + (S - 2 * In).t())))
+        i += 1
+        m1 = pho1 * m1 + (1 - pho1) * grad                                     # jamie.py:375-381
+        m2 = pho2 * m2 + (1 - pho2) * grad * grad
+        step = (m1 / (1 - np.power(pho1, i))) / (torch.sqrt(m2 / (1 - np.power(pho2, i))) + delta)
+        F_tmp = Fm - step
+        F_tmp[F_tmp < 0] = 0
+        Fm = (1 - epsilon) * Fm + epsilon * F_tmp                              # jamie.py:384
+        grad_s = Lambda + rho * (Fm.t() @ Im - In + S)                         # jamie.py:387-390
+        s_tmp = S - grad_s
+        s_tmp[s_tmp < 0] = 0
+        S = (1 - epsilon) * S + epsilon * s_tmp
+        Mu = Mu + epsilon * (Fm @ In - Im)                                     # jamie.py:393-394
+        Lambda = Lambda + epsilon * (Fm.t() @ Im - In + S)
+        if i >= delay:                                                         # jamie.py:397-402
+            a = torch.trace(Kx @ ((Fm @ Ky) @ Fm.t())) / torch.trace(Kx @ Kx)
+        if history is not None:
+            history.append(float(a))
+    return Fm.float().numpy()
+
+
+def distance_matrix(X, mode):
+    """jamie.py:839-890 for the modes whose arithmetic is in the reference file or in scipy / sklearn
+    ('geodesic' is unioncom's, absent from /root/reference)."""
+    from scipy import stats
+    from sklearn.metrics import pairwise_distances
+    if mode == 'spearman':                                                     # jamie.py:857-869
+        if X.shape[0] == 1:
+            return np.array([0])
+        d, _ = stats.spearmanr(X, axis=1)
+        if np.isnan(d).any():
+            raise Exception('Data is not well conditioned for spearman method (scipy.stats.spearmanr returned ``np.nan``)')
+        if len(np.shape(d)) == 0:
+            d = np.array([[1, d], [d, 1]])
+        return (1 - np.array(d)) / 2
+    if mode == 'pearson':                                                      # jamie.py:870-879 (dense input)
+        if X.shape[0] == 1:
+            return np.array([0])
+        d = np.corrcoef(np.asarray(X))
+        if len(np.shape(d)) == 0:
+            d = np.array([[1, d], [d, 1]])
+        return (1 - np.array(d)) / 2
+    return pairwise_distances(X, metric=mode)                                  # jamie.py:880-882

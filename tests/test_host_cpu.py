@@ -40,13 +40,13 @@ def test_ctypes_struct_sizes_match_header(lib, tmp_path):
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include "jamie_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
                    'sizeof(jamie_gemm_problem),sizeof(jamie_bnact_fwd_problem),sizeof(jamie_bnact_bwd_problem),'
-                   'sizeof(jamie_latent));return 0;}\n')
+                   'sizeof(jamie_latent));printf("%zu\\n",sizeof(jamie_pd_state));return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     import ctypes
     assert sizes == [ctypes.sizeof(lib.GemmProblem), ctypes.sizeof(lib.BnFwdProblem),
-                     ctypes.sizeof(lib.BnBwdProblem), ctypes.sizeof(lib.Latent)]
+                     ctypes.sizeof(lib.BnBwdProblem), ctypes.sizeof(lib.Latent), ctypes.sizeof(lib.PdState)]
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -216,3 +216,32 @@ def test_gradient_exchange_world2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count('OK') == 2
+
+
+# ---- correspondence stage: host pieces ----
+@pytest.mark.parametrize('mode', ['euclidean', 'cosine', 'spearman', 'pearson'])
+def test_distance_matrix_matches_oracle(mode):
+    from jamie_amd.utilities import distance_matrix
+    from oracle import jamie_oracle as orc
+    X = np.random.default_rng(3).standard_normal((40, 12))
+    np.testing.assert_array_equal(distance_matrix(X, mode), orc.distance_matrix(X, mode))
+
+
+def test_geodesic_distances_properties():
+    """unioncom's geodesic distances are restated (parity unpinned): check what the algorithm guarantees."""
+    from jamie_amd.utilities import geodesic_distances
+    rng = np.random.default_rng(0)
+    X = np.concatenate([rng.standard_normal((30, 3)), rng.standard_normal((30, 3)) + 50.0])   # two far clusters
+    D = geodesic_distances(X, kmax=7)
+    assert D.shape == (60, 60) and np.isfinite(D).all()
+    np.testing.assert_allclose(D, D.T)
+    assert (np.diag(D) == 0).all() and (D[~np.eye(60, dtype=bool)] > 0).all()
+    from sklearn.metrics import pairwise_distances
+    E = pairwise_distances(X)
+    assert (D[:30, :30] >= E[:30, :30] - 1e-9).all()  # a path is never shorter than the straight line
+    within = max(D[:30, :30].max(), D[30:, 30:].max())
+    np.testing.assert_allclose(D[:30, 30:], 2 * within)   # disconnected clusters: twice the largest finite distance
+
+
+def test_pd_workspace_sizes(lib):
+    assert lib.pd_workspace(100, 700) == (100 * 3, 4 * 700)

@@ -175,3 +175,20 @@ def test_m_modality_generalisation_reduces_to_reference_for_two():
     lb = orc.losses(X, *b, None, 0.3)
     for u, v in zip(la, lb):
         assert torch.allclose(u, v, rtol=1e-6, atol=1e-8)
+
+
+# ---- correspondence stage: the oracle's Prime_Dual against the reference's own outputs (tools/make_goldens_pd.py) ----
+@pytest.mark.parametrize('name', ['pd1_delay0', 'pd2_delay', 'pd3_pipeline'])
+def test_prime_dual_oracle_vs_reference_golden(name):
+    import ast
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
+    m = ast.literal_eval(str(g['meta']))
+    if 'Kx' in g:
+        Kx, Ky = g['Kx'], g['Ky']
+    else:                                              # stage A + B wiring: euclidean distances, then Prime_Dual
+        Kx, Ky = orc.distance_matrix(g['X'], 'euclidean'), orc.distance_matrix(g['Y'], 'euclidean')
+        np.testing.assert_allclose(Kx, g['dist0'], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Ky, g['dist1'], rtol=0, atol=1e-12)
+    F = orc.prime_dual(Kx, Ky, m['dx'], m['dy'], m['epoch_pd'], m['rho'], m['epsilon'], m['delay'])
+    np.testing.assert_allclose(F, g['F'], rtol=1e-6, atol=1e-9)

@@ -1,0 +1,36 @@
+"""GPU microbenchmark: fp32 grouped GEMM launches of config 2 with PER-PROBLEM split-K (equal-sized work units)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from jamie_amd import _native as nv
+nv.require_gpu()
+B, d = 512, (2000, 1000)
+NBUF = int(os.environ.get('NBUF', '4'))
+def T(*s): return torch.randn(*s, device='cuda')
+def run(layout, shapes, sks, cfg=-1, iters=20):
+    sets = []
+    for b in range(NBUF):
+        probs = []
+        for (M, N, K), sk in zip(shapes, sks):
+            if layout == nv.NT: A, Bm = T(M, K), T(N, K); lda, ldb = K, K
+            elif layout == nv.NN: A, Bm = T(M, K), T(K, N); lda, ldb = K, N
+            else: A, Bm = T(K, M), T(K, N); lda, ldb = M, N
+            probs.append(nv.gemm_problem(A, Bm, torch.empty(sk, M, N, device='cuda'), M, N, K, lda, ldb, N, splitk=sk, slab_stride=M * N))
+        sets.append(probs)
+    fl = sum(2.0 * M * N * K for (M, N, K) in shapes)
+    for i in range(4): nv.gemm(sets[i % NBUF], layout, cfg)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters): nv.gemm(sets[i % NBUF], layout, cfg)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms * 1e3, fl / ms / 1e9
+cases = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], [(1, 1), (2, 1), (4, 2), (3, 2)]),
+         ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], [(2, 3), (4, 2), (2, 1), (8, 4)]),
+         ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], [(2, 3), (4, 2), (2, 1)]),
+         ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], [(1, 1), (2, 1), (4, 2)])]
+for name, layout, shapes, skl in cases:
+    for sks in skl:
+        us, tf = run(layout, shapes, sks)
+        print(f'{name:12s} sk {sks}: {us:8.1f} us {tf:7.1f} TFLOP/s', flush=True)

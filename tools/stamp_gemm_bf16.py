@@ -10,20 +10,24 @@ B, d = 512, (2000, 1000)
 NBUF = int(os.environ.get('NBUF', '6'))
 def T(*s): return torch.randn(*s, device='cuda').to(torch.bfloat16)
 def run(name, shapes, cfg, sks, iters=13):
+    f32 = name.startswith('f32')
     sets = []
     for b in range(NBUF):
         probs = []
         for (M, N, K), s1 in zip(shapes, sks):
-            probs.append(nv.gemm_problem(T(M, K), T(N, K), torch.empty(s1, M, N, device='cuda'), M, N, K, K, K, N, splitk=s1, slab_stride=M * N))
+            A, Bm = (torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda')) if f32 else (T(M, K), T(N, K))
+            probs.append(nv.gemm_problem(A, Bm, torch.empty(s1, M, N, device='cuda'), M, N, K, K, K, N, splitk=s1, slab_stride=M * N))
         sets.append(probs)
-    for i in range(iters): nv.gemm_bf16(sets[i % NBUF], cfg)
+    launch = (lambda p: nv.gemm(p, nv.NT, cfg)) if f32 else (lambda p: nv.gemm_bf16(p, cfg))
+    for i in range(iters): launch(sets[i % NBUF])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); nv.gemm_bf16(sets[iters % NBUF], cfg); e1.record(); torch.cuda.synchronize()
+    e0.record(); launch(sets[iters % NBUF]); e1.record(); torch.cuda.synchronize()
     nb = 8192
     buf = (C.c_ulonglong * (8 * nb))()
-    lib.jamie_debug_stamps.argtypes = [C.c_void_p, C.c_int]
-    assert lib.jamie_debug_stamps(buf, nb) == 0
+    fn = lib.jamie_debug_stamps_f32 if f32 else lib.jamie_debug_stamps
+    fn.argtypes = [C.c_void_p, C.c_int]
+    assert fn(buf, nb) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
     a = a[a[:, 3] > 0]
     # keep the blocks of the last launch only (stamps of earlier, larger launches would be stale)
@@ -50,6 +54,8 @@ cases = {
  'fwd_2dd': ([(B, x, 2 * x) for x in d], 24, (3, 2)),
  'bwd_dec1': ([(2 * x, x, B) for x in d] + [(B, x, 2 * x) for x in d], 25, (1, 1, 4, 2)),
  'bwd_enc1': ([(x, 2 * x, B) for x in d] + [(B, 2 * x, x) for x in d], 25, (1, 1, 2, 1)),
+ 'f32_fwd_d2d': ([(B, 2 * x, x) for x in d], -1, (1, 1)),
+ 'f32_fwd_2dd': ([(B, x, 2 * x) for x in d], -1, (2, 3)),
  'dw_only': ([(2 * x, x, B) for x in d], 25, (1, 1)),
  'bwd_dec1_r': ([(B, x, 2 * x) for x in d] + [(2 * x, x, B) for x in d], 25, (4, 2, 1, 1)),      # dX problems first
  'bwd_enc1_r': ([(B, 2 * x, x) for x in d] + [(x, 2 * x, B) for x in d], 25, (2, 1, 1, 1)),
