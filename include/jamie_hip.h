@@ -282,6 +282,18 @@ int jamie_pd_step(const jamie_pd_state* state /*host*/, int iteration, void* str
 int jamie_pd_alpha(const float* G2, const float* F, long long count, float* partials, int n_partials, float inv_trkk,
                    float* alpha, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-side preprocessing: `preclass(sample, axis=0)` of the reference (utilities.py:654-678; built at
+ * jamie.py:462-465, applied at jamie.py:508), SURVEY.md §8(f) rank 4.  X is [N, d] row-major fp32 (is_f64 = 0) or
+ * fp64 (is_f64 = 1) on the device.
+ * ------------------------------------------------------------------------------------------------ */
+/* mean[d], sd[d] (fp64; population standard deviation, numpy's two-pass order); `partials`: n_row_blocks * d doubles */
+int jamie_col_stats(const void* X, int is_f64, long long N, int d, long long ld, double* partials, int n_row_blocks,
+                    double* mean, double* sd, void* stream);
+/* out[N,d] fp32 = (X - mean) / sd computed in fp64, NaN -> 0 (utilities.py:663-669) */
+int jamie_standardise(const void* X, int is_f64, long long N, int d, long long ld, const double* mean, const double* sd,
+                      float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

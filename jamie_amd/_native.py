@@ -138,6 +138,10 @@ EXPORTS = {
     'jamie_colsum_group': (C.c_int, [C.POINTER(ColsumProblem), C.c_int, C.c_void_p]),
     'jamie_colsum': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p,
                                C.c_int, C.c_void_p]),
+    'jamie_col_stats': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    'jamie_standardise': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     'jamie_pd_workspace': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'jamie_pd_step': (C.c_int, [C.POINTER(PdState), C.c_int, C.c_void_p]),
     'jamie_pd_alpha': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
@@ -418,3 +422,19 @@ def pd_step(state, iteration):
 def pd_alpha(G2, F, partials, inv_trkk, alpha):
     _call('jamie_pd_alpha', ptr(G2), ptr(F), F.numel(), ptr(partials), partials.numel(), float(inv_trkk), ptr(alpha),
           _stream())
+
+
+def standardise_columns(X):
+    """Device `preclass(axis=0)`: X [N, d] fp32 / fp64 on the GPU -> (fp32 standardised [N, d], mean [d] f64, std [d] f64)."""
+    if X.dtype not in (torch.float32, torch.float64) or X.dim() != 2 or not X.is_contiguous():
+        raise JamieHipError('standardise_columns needs a contiguous 2-D fp32 / fp64 GPU tensor')
+    N, d = X.shape
+    R = int(max(1, min(256, (N + 2047) // 2048)))
+    part = torch.empty(R * d, dtype=torch.float64, device=X.device)
+    mean = torch.empty(d, dtype=torch.float64, device=X.device)
+    sd = torch.empty(d, dtype=torch.float64, device=X.device)
+    out = torch.empty(N, d, dtype=torch.float32, device=X.device)
+    f64 = int(X.dtype == torch.float64)
+    _call('jamie_col_stats', ptr(X), f64, N, d, d, ptr(part), R, ptr(mean), ptr(sd), _stream())
+    _call('jamie_standardise', ptr(X), f64, N, d, d, ptr(mean), ptr(sd), ptr(out), _stream())
+    return out, mean, sd

@@ -247,3 +247,82 @@ extern "C" int jamie_colsum(const float* X, int M, int N, int ld, int nslab, lon
     p.X = X; p.out = out; p.M = M; p.N = N; p.ld = ld; p.nslab = nslab; p.slab_stride = slab_stride; p.accumulate = accumulate;
     return jamie_colsum_group(&p, 1, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Device-side `preclass(axis=0)` (reference utilities.py:654-678, built at jamie.py:462-465): per-feature mean and
+// population standard deviation of a [N, d] matrix, then (x - mean) / std with NaN -> 0, fp32 out.  The reference
+// does this in fp64 numpy on the host; here the cells are uploaded once in their own dtype (fp32 or fp64), the
+// statistics are accumulated in fp64 in numpy's two-pass order (mean, then mean of squared deviations) and the
+// standardised fp32 matrix is written straight into the buffer the training loop gathers from.
+// Deterministic: per-(row block, column) partial sums, added in a fixed order.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void col_moment_kernel(const T* __restrict__ X, long long N, int d, long long ld,
+                                                         const double* __restrict__ mean, double* partials) {
+    __shared__ double sh[4][64];
+    const int c = threadIdx.x & 63, rp = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const long long rows_per = (N + gridDim.y - 1) / gridDim.y;
+    const long long r0 = (long long)blockIdx.y * rows_per, r1 = min(N, r0 + rows_per);
+    double acc = 0.0;
+    if (col < d) {
+        const double mu = mean ? mean[col] : 0.0;
+        if (mean) {
+            for (long long r = r0 + rp; r < r1; r += 4) { const double v = (double)X[r * ld + col] - mu; acc += v * v; }
+        } else {
+            for (long long r = r0 + rp; r < r1; r += 4) acc += (double)X[r * ld + col];
+        }
+    }
+    sh[rp][c] = acc;
+    __syncthreads();
+    if (rp == 0 && col < d) partials[(long long)blockIdx.y * d + col] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+}
+
+__global__ __launch_bounds__(256) void col_moment_finish_kernel(const double* partials, int R, int d, double inv_n,
+                                                                int take_sqrt, double* out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= d) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += partials[(long long)r * d + col];
+    s *= inv_n;
+    out[col] = take_sqrt ? sqrt(s) : s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void standardise_kernel(const T* __restrict__ X, long long N, int d, long long ld,
+                                                          const double* __restrict__ mean, const double* __restrict__ sd,
+                                                          float* __restrict__ out) {
+    const long long total = N * d;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d;
+        const int c = (int)(i - r * d);
+        const double v = ((double)X[r * ld + c] - mean[c]) / sd[c];          // utilities.py:663-668
+        out[i] = (v != v) ? 0.f : (float)v;                                   // out[np.isnan(out)] = 0
+    }
+}
+
+extern "C" int jamie_col_stats(const void* X, int is_f64, long long N, int d, long long ld, double* partials,
+                               int n_row_blocks, double* mean, double* sd, void* stream) {
+    JAMIE_ARG(X && partials && mean && sd && N > 0 && d > 0 && ld >= d, "null pointer / empty");
+    JAMIE_ARG(n_row_blocks >= 1 && n_row_blocks <= 1024, "1 <= n_row_blocks <= 1024");
+    const dim3 grid((d + 63) / 64, n_row_blocks), fin((d + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* mu = pass ? mean : nullptr;
+        if (is_f64) hipLaunchKernelGGL(col_moment_kernel<double>, grid, dim3(256), 0, st, (const double*)X, N, d, ld, mu, partials);
+        else hipLaunchKernelGGL(col_moment_kernel<float>, grid, dim3(256), 0, st, (const float*)X, N, d, ld, mu, partials);
+        hipLaunchKernelGGL(col_moment_finish_kernel, fin, dim3(256), 0, st, partials, n_row_blocks, d, 1.0 / (double)N, pass,
+                           pass ? sd : mean);
+    }
+    return jamie_launch_status("jamie_col_stats");
+}
+
+extern "C" int jamie_standardise(const void* X, int is_f64, long long N, int d, long long ld, const double* mean,
+                                 const double* sd, float* out, void* stream) {
+    JAMIE_ARG(X && mean && sd && out && N > 0 && d > 0 && ld >= d, "null pointer / empty");
+    long long b = (N * d + 255) / 256;
+    const int grid = (int)(b > 8192 ? 8192 : b);
+    if (is_f64) hipLaunchKernelGGL(standardise_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double*)X, N, d, ld, mean, sd, out);
+    else hipLaunchKernelGGL(standardise_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)X, N, d, ld, mean, sd, out);
+    return jamie_launch_status("jamie_standardise");
+}

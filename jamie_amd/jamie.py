@@ -65,7 +65,8 @@ class JAMIE:
                  dropout=None, pca_dim=2 * [512], batch_step=True, use_f_tilde=True, use_early_stop=True,
                  min_epochs=2500, min_increment=1e-8, max_steps_without_increment=500, debug=False,
                  log_debug=100, record_loss=True, enable_memory_logging=False, device='cuda',
-                 sampler='numpy', distributed=False, compute_dtype='f32', grad_comm_dtype='auto', **kwargs):
+                 sampler='numpy', distributed=False, compute_dtype='f32', grad_comm_dtype='auto',
+                 preprocess='host', checkpoint_path=None, checkpoint_every=0, **kwargs):
         self.match_result = match_result
         self.PF_Ratio = PF_Ratio
         self.corr_method = corr_method
@@ -93,6 +94,14 @@ class JAMIE:
         self.sampler = sampler
         self.distributed = distributed
         self.compute_dtype = compute_dtype
+        if preprocess not in ('host', 'device'):
+            raise ValueError("preprocess must be 'host' (numpy fp64, the reference's arithmetic) or 'device'")
+        self.preprocess = preprocess
+        # training checkpoints (the reference only pickles the finished model, jamie.py:967-972):
+        # every `checkpoint_every` epochs the full training state goes to `checkpoint_path`;
+        # fit_transform(..., resume_from=path) continues from it and ends bit-identical to an uninterrupted run
+        self.checkpoint_path, self.checkpoint_every = checkpoint_path, int(checkpoint_every or 0)
+        self._resume_from = None
         if grad_comm_dtype not in ('auto', 'f32', 'bf16'):
             raise ValueError("grad_comm_dtype must be 'auto', 'f32' or 'bf16'")
         self.grad_comm_dtype = compute_dtype if grad_comm_dtype == 'auto' else grad_comm_dtype
@@ -110,9 +119,10 @@ class JAMIE:
         self.loss_history = {}
 
     # ------------------------------------------------------------------------------------------
-    def fit_transform(self, dataset=None, P=None):
-        """reference jamie.py:113-222."""
+    def fit_transform(self, dataset=None, P=None, resume_from=None):
+        """reference jamie.py:113-222.  `resume_from`: a checkpoint written by this class (`checkpoint_path`)."""
         self.P = P
+        self._resume_from = resume_from
         if self.integration_type not in ['MultiOmics']:
             raise Exception('integration_type error! Enter MultiOmics.')
         if self.distance_mode not in _DISTANCE_MODES:
@@ -187,9 +197,9 @@ class JAMIE:
         print('Finished Matching!')
         return cor_pairs
 
-    def fit(self, dataset=None, P=None):
+    def fit(self, dataset=None, P=None, resume_from=None):
         """north_star spelling: train, return self."""
-        self._last_embedding = self.fit_transform(dataset, P)
+        self._last_embedding = self.fit_transform(dataset, P, resume_from=resume_from)
         return self
 
     # ------------------------------------------------------------------------------------------
@@ -281,8 +291,23 @@ class JAMIE:
                        else torch.as_tensor(np.asarray(mr), dtype=torch.float32, device=dev))
         timer = time_logger(sync=torch.cuda.synchronize)
         # ---- preprocessing (host, numpy/sklearn like the reference) ----
-        pre = self._build_preprocessing()
-        self.dataset = [p.transform(np.asarray(x)) for p, x in zip(pre, self.dataset)]
+        dev_pre = self.preprocess == 'device' and (self.pca_dim is None or all(dm is None for dm in self.pca_dim))
+        if dev_pre:
+            # per-feature standardisation on the GPU (jamie_col_stats / jamie_standardise: fp64 statistics in numpy's
+            # two-pass order, fp32 cells written straight into the resident training matrices); the host keeps the
+            # `preclass` objects (mean / std) for transform / inverse_transform of new data
+            pre, data_dev = [], []
+            for x in self.dataset:
+                xa = np.ascontiguousarray(np.asarray(x))
+                if xa.dtype not in (np.float32, np.float64):
+                    xa = xa.astype(np.float64)
+                out, mean, sd = nv.standardise_columns(torch.from_numpy(xa).to(dev))
+                pre.append(preclass.from_stats(mean.cpu().numpy(), sd.cpu().numpy(), axis=0))
+                data_dev.append(out)
+            self.dataset = [d.cpu().numpy() for d in data_dev]                # the reference keeps the transformed cells
+        else:
+            pre = self._build_preprocessing()
+            self.dataset = [p.transform(np.asarray(x)) for p, x in zip(pre, self.dataset)]
         self.col = [x.shape[1] for x in self.dataset]
         # ---- model / engine ----
         self.model = self.model_class(self.col, self.output_dim, preprocessing=[p.transform for p in pre],
@@ -291,10 +316,10 @@ class JAMIE:
         if world > 1:
             jd.broadcast_flat(self.model.flat)
         self.model.train()
-        data_all = [torch.from_numpy(np.ascontiguousarray(x)).float() for x in self.dataset]
+        data_all = data_dev if dev_pre else [torch.from_numpy(np.ascontiguousarray(x)).float() for x in self.dataset]
         # row shards for data parallelism ('diag' keeps the same rows of both modalities on one rank)
         bounds = [jd.shard_bounds(r, rank, world) for r in self.row]
-        data = [d[lo:hi].to(dev) for d, (lo, hi) in zip(data_all, bounds)]
+        data = [d[lo:hi].to(dev).contiguous() for d, (lo, hi) in zip(data_all, bounds)]
         rows = [hi - lo for lo, hi in bounds]
         len_dataloader = int(np.max(rows) / self.batch_size)                 # jamie.py:511-514
         if len_dataloader == 0:
@@ -323,8 +348,12 @@ class JAMIE:
         use_plan = (self.sampler == 'device' and method == 'diag' and P_dense is None and F_dense is None
                     and P_csr is None and self.PF_Ratio == 1 and self.batch_step)
         epoch_sum = torch.zeros((), device=dev)      # batch_step=False: epoch loss = mean of the batch losses (jamie.py:728)
+        start_epoch = 0
+        if self._resume_from is not None:
+            start_epoch, best_running_loss, streak = self._load_checkpoint(self._resume_from, eng)
+            self._resume_from = None
         timer.log('Setup')
-        for epoch in range(self.epoch_DNN):                                   # jamie.py:546
+        for epoch in range(start_epoch, self.epoch_DNN):                      # jamie.py:546
             eng.set_kl_anneal(kl_anneal(epoch, self.min_epochs, self.epoch_DNN))
             eng.reset_best()
             for batch_idx in range(len_dataloader):
@@ -419,6 +448,8 @@ class JAMIE:
                     streak += 1
                 if streak >= self.max_steps_without_increment and self.use_early_stop:
                     break
+            if self.checkpoint_every and self.checkpoint_path and (epoch + 1) % self.checkpoint_every == 0 and rank == 0:
+                self.save_checkpoint(self.checkpoint_path, epoch + 1, best_running_loss, streak)
         self.model.eval()
         out = [self.model.embed(data_all[i], i).cpu().numpy() for i in range(self.dataset_num)]   # jamie.py:794-799
         timer.log('Output')
@@ -466,6 +497,44 @@ class JAMIE:
         torch.save({'format': 'jamie_amd.v1', 'input_dim': m.input_dim, 'output_dim': m.output_dim,
                     'dropout': m.dropout, 'state_dict': {k: v.cpu() for k, v in m.state_dict().items()},
                     'preprocessing': m.preprocessing, 'preprocessing_inverse': m.preprocessing_inverse}, f)
+
+    def save_checkpoint(self, f, next_epoch, best_running_loss=np.inf, streak=0):
+        """Full training state after `next_epoch` epochs: parameters, BatchNorm statistics, both Adam moments, the
+        device step / RNG counters, the host sampler's RNG, the early-stop bookkeeping and the loss history."""
+        eng, m = self.engine, self.model
+        eng.flush()
+        torch.save({'format': 'jamie_amd.ckpt.v1', 'epoch': int(next_epoch), 'input_dim': list(m.input_dim),
+                    'output_dim': m.output_dim, 'dropout': m.dropout, 'batch_size': eng.B,
+                    'compute_dtype': eng.compute_dtype,
+                    'state_dict': {k: v.cpu() for k, v in m.state_dict().items()},
+                    'flat': m.flat.cpu(), 'exp_avg': eng.exp_avg.cpu(), 'exp_avg_sq': eng.exp_avg_sq.cpu(),
+                    'engine_state': eng.state.cpu(), 'num_batches_tracked': int(m.num_batches_tracked),
+                    'best_running_loss': float(best_running_loss), 'streak': int(streak),
+                    'loss_history': {k: list(v) for k, v in self.loss_history.items()},
+                    'np_random': np.random.get_state(), 'py_random': random.getstate()}, f)
+
+    def _load_checkpoint(self, f, eng):
+        ck = torch.load(f, weights_only=False)
+        m = self.model
+        if ck.get('format') != 'jamie_amd.ckpt.v1':
+            raise ValueError(f'{f}: not a jamie_amd training checkpoint')
+        if list(ck['input_dim']) != list(m.input_dim) or ck['output_dim'] != m.output_dim or ck['batch_size'] != eng.B \
+                or ck['compute_dtype'] != eng.compute_dtype:
+            raise ValueError(f'{f}: checkpoint of a different configuration (features {ck["input_dim"]}, latent '
+                             f'{ck["output_dim"]}, batch {ck["batch_size"]}, {ck["compute_dtype"]})')
+        m.load_state_dict(ck['state_dict'])
+        m.flat.copy_(ck['flat'])                       # incl. alignment padding: bit-identical continuation
+        m.num_batches_tracked = ck['num_batches_tracked']
+        eng.exp_avg.copy_(ck['exp_avg'])
+        eng.exp_avg_sq.copy_(ck['exp_avg_sq'])
+        eng.state[1:].copy_(ck['engine_state'][1:])    # step counters; the Philox seed stays this rank's own
+        if eng.bf16:
+            eng.refresh_weights_bf16()
+        if self.record_loss:
+            self.loss_history = {k: list(v) for k, v in ck['loss_history'].items()}
+        np.random.set_state(ck['np_random'])
+        random.setstate(ck['py_random'])
+        return ck['epoch'], ck['best_running_loss'], ck['streak']
 
     def load_model(self, f):
         """reference jamie.py:970-972."""

@@ -19,6 +19,14 @@ class preclass:
         self.mean = np.asarray(sample.mean(axis))
         self.std = np.asarray(sample.std(axis))
 
+    @classmethod
+    def from_stats(cls, mean, std, axis=0):
+        """The same object from statistics computed elsewhere (the device path, `_native.standardise_columns`)."""
+        self = cls.__new__(cls)
+        self.pca, self.axis = None, axis
+        self.mean, self.std = np.asarray(mean), np.asarray(std)
+        return self
+
     def transform(self, X):
         out = X
         if self.pca is not None:

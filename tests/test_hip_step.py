@@ -616,8 +616,7 @@ def test_facade_dense_F_pf_ratio_loss_weights_and_replacement(jam):
     jm3 = jam.JAMIE(output_dim=4, batch_size=32, epoch_DNN=1, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9)
     _quiet(lambda: jm3.fit_transform(dataset=data, P=P))
     assert jm3.sampling_method == 'hybrid'
-    with pytest.raises(NotImplementedError):
-        jam.JAMIE(output_dim=4).fit_transform(dataset=data)          # use_f_tilde=True without match_result
+    # use_f_tilde=True without match_result runs stages A / B itself: tests/test_hip_correspondence.py
 
 
 def test_facade_unequal_rows_zeros_sampler_and_small_n(jam):
@@ -860,3 +859,84 @@ def test_facade_sparse_P_equals_dense_P(jam):
     jm = jam.JAMIE(output_dim=4, batch_size=64, epoch_DNN=1, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9)
     _quiet(lambda: jm.fit_transform(dataset=data, P=sp.identity(N, format='csr')))
     assert jm.sampling_method == 'diag'
+
+
+# ---- device-side preprocessing and training checkpoints ----
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_device_standardisation_matches_numpy(jam, dtype):
+    """jamie_col_stats / jamie_standardise against `preclass(axis=0)` (utilities.py:654-678): fp64 statistics in
+    numpy's two-pass order; a constant feature (0/0 -> NaN -> 0) and a NaN cell behave as in the reference."""
+    from jamie_amd import _native as nv
+    from jamie_amd.utilities import preclass
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((5000, 203)) * rng.uniform(0.1, 30, 203) + rng.uniform(-5, 5, 203)).astype(dtype)
+    X[:, 7] = 3.25                                    # zero variance
+    # the device computes in fp64 whatever the input type (a fp32 input is standardised more accurately than numpy's
+    # fp32 arithmetic does it): the reference value is the fp64 one
+    X64 = X.astype(np.float64)
+    pc = preclass(X64, axis=0)
+    want = pc.transform(X64.copy()).astype(np.float32)
+    out, mean, sd = nv.standardise_columns(torch.from_numpy(X).cuda())
+    np.testing.assert_allclose(mean.cpu().numpy(), X64.mean(0), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sd.cpu().numpy(), X64.std(0), rtol=1e-10, atol=1e-12)
+    got = out.cpu().numpy()
+    assert (got[:, 7] == 0).all()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+    Xn = X.copy()
+    Xn[11, 3] = np.nan                                 # a NaN cell poisons its feature's statistics: all NaN -> 0
+    out2, _, _ = nv.standardise_columns(torch.from_numpy(Xn).cuda())
+    assert (out2[:, 3] == 0).all() and torch.isfinite(out2).all()
+
+
+def test_facade_device_preprocessing_equals_host(jam):
+    import io
+    import contextlib
+    rng = np.random.default_rng(8)
+    N, dims = 700, (72, 40)
+    Z = rng.standard_normal((N, 5))
+    data = [3.0 * (Z @ rng.standard_normal((5, d))) + rng.standard_normal((N, d)) + 2.0 for d in dims]
+    embs, pres = [], []
+    for mode in ('host', 'device'):
+        with contextlib.redirect_stdout(io.StringIO()):
+            jm = jam.JAMIE(output_dim=8, batch_size=64, epoch_DNN=6, min_epochs=3, pca_dim=None, use_f_tilde=False,
+                           log_DNN=10 ** 9, sampler='device', preprocess=mode)
+            embs.append(jm.fit_transform(dataset=[d.copy() for d in data]))
+        pres.append(jm)
+    for a, b in zip(*embs):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+    x_new = data[0][:50]
+    np.testing.assert_allclose(pres[0].transform_one(x_new, 0), pres[1].transform_one(x_new, 0), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(pres[0].modal_predict(x_new, 0), pres[1].modal_predict(x_new, 0), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('sampler,mode', [('device', 'f32'), ('device', 'bf16'), ('numpy', 'f32')])
+def test_checkpoint_resume_is_bit_identical(jam, tmp_path, sampler, mode):
+    """8 epochs straight == 5 epochs + checkpoint + resume for 3 more: weights, BN statistics, loss history."""
+    import io
+    import contextlib
+    rng = np.random.default_rng(4)
+    N, dims = 640, (72, 40)
+    Z = rng.standard_normal((N, 5))
+    data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
+    kw = dict(output_dim=8, batch_size=64, min_epochs=3, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9,
+              sampler=sampler, compute_dtype=mode)
+    ck = str(tmp_path / 'train.ckpt')
+    with contextlib.redirect_stdout(io.StringIO()):
+        np.random.seed(7)        # the reference's numpy sampler draws from numpy's global stream (never seeded by it)
+        full = jam.JAMIE(epoch_DNN=8, **kw)
+        e_full = full.fit_transform(dataset=data)
+        np.random.seed(7)
+        part = jam.JAMIE(epoch_DNN=5, checkpoint_path=ck, checkpoint_every=5, **kw)
+        part.fit_transform(dataset=data)
+        res = jam.JAMIE(epoch_DNN=8, **kw)
+        e_res = res.fit_transform(dataset=data, resume_from=ck)
+    assert torch.equal(full.model.flat, res.model.flat)
+    sa, sb = full.model.state_dict(), res.model.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert full.loss_history == res.loss_history and len(res.loss_history['Rec']) == 8
+    for a, b in zip(e_full, e_res):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        with contextlib.redirect_stdout(io.StringIO()):
+            jam.JAMIE(epoch_DNN=8, **{**kw, 'output_dim': 4}).fit_transform(dataset=data, resume_from=ck)
