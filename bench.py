@@ -122,8 +122,11 @@ def main():
     ap.add_argument('--grad-comm', default='auto', choices=['auto', 'f32', 'bf16'],
                     help='dtype of the gradient all-reduce messages (auto: the compute dtype)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-pipeline', action='store_true',
-                    help='clip + Adam on the main stream (default: on a second stream, under the next forward pass)')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='clip + Adam on a second stream under the next forward pass (+2-3 %; default: main stream, so '
+                         'that the roofline kernel is timed alone)')
+    ap.add_argument('--side-transposes', action='store_true',
+                    help='bf16: transposed weight copies on a side stream under the next forward pass')
     ap.add_argument('--opt-priority', type=int, default=0, help='HIP stream priority of the optimiser stream')
     ap.add_argument('--cpu-budget', type=float, default=15.0)
     args = ap.parse_args()
@@ -158,8 +161,10 @@ def main():
     # 3-modality generalisation always samples without replacement (duplicates would need a non-identity corr)
     rep = min(dims) < B and len(dims) == 2
     eng.set_kl_anneal(0.5)
-    if not args.no_pipeline:
+    if args.pipeline:
         eng.enable_pipeline(args.opt_priority)
+    if args.side_transposes:
+        eng.enable_side_transposes()
     eng.enable_kernel_timing('enc_gemm', 'adam')
     # the step is a fixed launch sequence on static buffers: record it once, replay it (one foreign call per launch)
     plan = eng.make_plan(data, idx, hi - lo, rep, allreduce)

@@ -206,6 +206,7 @@ class TrainEngine:
         self._timing = None
         self._timing_every, self._timing_step = 1, 0
         self.pipeline = False            # enable_pipeline(): optimiser on its own stream, overlapped with the next forward
+        self.side_transposes, self._wT_pending = False, False
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
     # Adam is HBM-bound (28 B/parameter) and the forward GEMMs are bound by the L2 -> LDS fabric and the matrix pipe, so
@@ -215,6 +216,23 @@ class TrainEngine:
     # element sees exactly the update of the one-launch form (bit-identical, tests/test_hip_step.py).
     PIPE_GROUPS = (('enc0',), ('enc1', 'head', 'dec0'), ('dec1',), ('dec2',))
     PIPE_WAIT = {'enc0': 0, 'enc1': 1, 'dec1': 2, 'dec2': 3}
+
+    def enable_side_transposes(self):
+        """bf16 mode: make the transposed weight copies on a side stream, overlapped with the next forward pass."""
+        if not self.bf16:
+            return
+        self.side_transposes = True
+        self.side_stream = torch.cuda.Stream(device=self.dev)
+        self._ev_adam, self._ev_wT = torch.cuda.Event(), torch.cuda.Event()
+
+    def _wait_wT(self):
+        if not self.side_transposes:
+            return
+
+        def fn():
+            if self._wT_pending:
+                nv.current_stream().wait_event(self._ev_wT)
+        self._both(fn)
 
     def enable_pipeline(self, priority=0):
         """Run clip + Adam (and the bf16 weight transposes) on a side stream; `flush()` before anything other than
@@ -246,6 +264,8 @@ class TrainEngine:
         if self.pipeline and self._opt_pending:
             for ev in self._ev_params:
                 torch.cuda.current_stream().wait_event(ev)
+        if self.side_transposes and self._wT_pending:
+            torch.cuda.current_stream().wait_event(self._ev_wT)
 
     # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
     def set_kl_anneal(self, anneal):
@@ -601,6 +621,7 @@ class TrainEngine:
     def _backward(self, lat, noise, allreduce):
         B, L = self.B, self.L
         acc = self.accumulate
+        self._wait_wT()
         nv.colsum_group([(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
         self._region(allreduce, 'dec2')
@@ -636,7 +657,19 @@ class TrainEngine:
             self._launch('adam', lambda: nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq,
                                                        self.norm_partials, self.hyper, self.state,
                                                        self.wbf_flat if self.bf16 else None))
-            if self.bf16:
+            if self.bf16 and self.side_transposes:
+                # the K-contiguous W^T copies are only read by the NEXT backward pass: they are made on a side stream
+                # under the next forward pass (36 us of HBM-bound copying off the critical path)
+                side = self.side_stream
+                self._both(lambda: (self._ev_adam.record(nv.current_stream()), side.wait_event(self._ev_adam)))
+                nv.set_stream(side)
+                try:
+                    self.refresh_weights_bf16(transposes_only=True)
+                    self._both(lambda: self._ev_wT.record(side))
+                finally:
+                    nv.set_stream(None)
+                self._wT_pending = True
+            elif self.bf16:
                 self.refresh_weights_bf16(transposes_only=True)
             return
         # pipelined: the optimiser stream takes over once the gradient norm is known; it hands the parameter groups

@@ -478,9 +478,9 @@ def test_plan_replay_equals_eager_steps(jam, mode):
     assert torch.equal(flats[0], flats[1])
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode,variant', [('f32', 'pipeline'), ('bf16', 'pipeline'), ('bf16', 'side')])
 @pytest.mark.parametrize('use_plan', [False, True])
-def test_pipelined_optimizer_is_bit_identical(jam, mode, use_plan):
+def test_pipelined_optimizer_is_bit_identical(jam, mode, use_plan, variant):
     """clip + Adam on the optimiser stream, group by group under the next step's forward pass
     (TrainEngine.enable_pipeline), produces exactly the parameters, moments and bf16 copies of the one-launch form."""
     from jamie_amd import _native as nv
@@ -494,8 +494,10 @@ def test_pipelined_optimizer_is_bit_identical(jam, mode, use_plan):
         torch.manual_seed(9)
         model = edModelVar(dims, L)
         eng = TrainEngine(model, B, compute_dtype=mode, seed=21)
-        if pipe:
+        if pipe and variant == 'pipeline':
             eng.enable_pipeline()
+        elif pipe:                      # only the transposed bf16 weight copies move to a side stream
+            eng.enable_side_transposes()
         idx = torch.zeros(B, dtype=torch.int32, device='cuda')
         if use_plan:
             plan = eng.make_plan(data, idx, N)

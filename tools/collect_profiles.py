@@ -30,6 +30,16 @@ tr[cfg] = {'kernel': KERNEL, 'hbm_bytes_per_launch': hbm, 'fetch_size_kib_raw': 
            'launches_averaged': [n1, n2], 'correction': 'FETCH_SIZE x2 (gfx950), KiB -> bytes', 'source': name}
 json.dump(tr, open(tr_path, 'w'), indent=1)
 bench['roofline']['traffic'] = hbm
+# the same command under rocprofv3 (--kernel-trace --stats): its own event timing next to the profiler's average, so the
+# two clocks can be compared on the SAME run (profiled runs are slower than the un-profiled bench, MI355X_MICROARCH.md DVFS 2)
+try:
+    prof = json.loads(open(os.path.join(src, 'stats.json')).read().strip().splitlines()[-1])
+    kk = [r for r in rows if KERNEL in r['Name']]
+    bench['profiled_run'] = {'value': prof['value'], 'ms_per_step': prof['ms_per_step'],
+                             'kernel_event_timing_ms': prof['kernel_event_timing_ms'],
+                             'rocprofv3_avg_us': float(kk[0]['AverageNs']) / 1e3 if kk else None, 'kernel': KERNEL}
+except Exception as e:      # noqa: BLE001
+    bench['profiled_run'] = {'error': str(e)}
 json.dump(bench, open(os.path.join(dst, name + '_bench.json'), 'w'), indent=1)
 k = [r for r in rows if KERNEL in r['Name']]
 print('bench ms/step', bench['ms_per_step'], 'cells/s', bench['value'])
