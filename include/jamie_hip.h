@@ -68,6 +68,9 @@ typedef struct {
     int epi; int accumulate;
     float scale; float slope; float eps;
     float pscale;               /* EPI_MSE: partial[block] = pscale * sum d^2 (e.g. w_rec / (B*d)) */
+    int b_tr;                   /* jamie_gemm_bf16 only: B is stored [K, N] row-major (N contiguous, ldb >= N) -- the dX
+                                 * product dy W reads the weights W [out, in] as they are (model.py Linear backward), no
+                                 * transposed copy; large-tile configurations with 128 columns (23, 24, 25) */
 } jamie_gemm_problem;
 
 /* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */

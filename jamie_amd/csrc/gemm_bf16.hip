@@ -13,6 +13,7 @@
 // are padded to BK*2 + 16 bytes (16 * odd): conflict-free ds_read_b128.  Staging, double buffering, fragment
 // prefetch, grouped launch, XCD mapping, split-K slabs and epilogues are those of gemm_f32.hip.
 #include "common.h"
+#include <type_traits>
 
 // diagnostic ablations (timing only, wrong results): 1 = no global loads in the k-loop, 2 = no MFMAs,
 // 3 = no LDS writes, 4 = no fragment reads (LDS read traffic removed)
@@ -23,6 +24,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmBDev {
     const unsigned short* A; const unsigned short* B; float* C; const float* bias;
@@ -31,6 +33,7 @@ struct GemmBDev {
     int M, N, K, lda, ldb, ldc, aux_ld;
     int splitk, kchunk, tiles_m, tiles_n, n_tiles;
     int epi, accumulate, vec;
+    int b_tr;            // B is [K, N] row-major (N contiguous): staged as [k][n] rows, fragments by ds_read_b64_tr_b16
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -532,10 +535,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
         const int row = 8 * (wid + NW * i) + lrow;
         a_src[i] = P.A + (long long)min(m0 + row, P.M - 1) * P.lda + ((pch ^ ((row >> 1) & 7)) * 8);
     }
+    // B operand as stored: [N, K] with K contiguous (forward, dW) or, b_tr, [K, N] with N contiguous (dX = dy W reads
+    // the weights W [out, in] as they are: no transposed copy).  The b_tr tile is [64 k][BN n] with 256-byte rows, one
+    // 1-KiB DMA piece = 4 k-rows, 16-byte chunks XOR-swizzled by ((k & 3) << 2) | ((k >> 2) & 3): the image on which
+    // both DMA fills and the 32x32x16 transposed reads are conflict-free (cdna_hip_programming.md T10 (b)).
+    const bool b_tr = P.b_tr != 0;
+    const long long b_kstep = b_tr ? (long long)P.ldb : 1;
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int row = 8 * (wid + NW * i) + lrow;
-        b_src[i] = P.B + (long long)min(n0 + row, P.N - 1) * P.ldb + ((pch ^ ((row >> 1) & 7)) * 8);
+        if (b_tr) {
+            const int piece = wid + NW * i, krow = 4 * piece + (lane >> 4);
+            const int lc = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+            b_src[i] = P.B + (long long)krow * P.ldb + min(n0 + lc * 8, P.N - 8);
+        } else {
+            const int row = 8 * (wid + NW * i) + lrow;
+            b_src[i] = P.B + (long long)min(n0 + row, P.N - 1) * P.ldb + ((pch ^ ((row >> 1) & 7)) * 8);
+        }
     }
     typedef const void __attribute__((address_space(1)))* gptr_t;
     typedef void __attribute__((address_space(3)))* lptr_t;
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                 __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
         } else {   // partial k-tile: masked loads through registers into the same swizzled image
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
@@ -561,11 +576,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
             }
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
-                const int f = tid + j * NT, row = f >> 3, c = f & 7;
-                const int gn = min(n0 + row, P.N - 1);
+                const int f = tid + j * NT;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.B + (long long)gn * P.ldb + k0 + c * 8);
-                *reinterpret_cast<uint4*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+                if (b_tr) {      // [k][n] rows; k rows beyond the slice are zero (finite: the A tile is zero there too)
+                    const int krow = f / (BN / 8), lc = f % (BN / 8);
+                    if (k0 + krow < kend)
+                        v = *reinterpret_cast<const uint4*>(P.B + (long long)(k0 + krow) * P.ldb + min(n0 + lc * 8, P.N - 8));
+                    *reinterpret_cast<uint4*>(Bs + krow * (BN * 2) + ((lc ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)) = v;
+                } else {
+                    const int row = f >> 3, c = f & 7;
+                    const int gn = min(n0 + row, P.N - 1);
+                    if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.B + (long long)gn * P.ldb + k0 + c * 8);
+                    *reinterpret_cast<uint4*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+                }
             }
         }
     };
@@ -588,15 +611,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
 
     const int swz = (r >> 1) & 7;
     bf16x8 af[2][TM], bf[2][TN];
-    auto read_frags = [&](const unsigned char* As, int fb, int s) {
+    // transposed read of the [k][n] image: in a 16-lane group lane 4q+p supplies row q, columns 4p..4p+3 of a 4 x 16
+    // block and lane i receives column i of the 4 rows; lane (n = lane & 31, kh = lane >> 5) of the MFMA operand needs
+    // k = 16 s + 8 kh + 0..7 of column n: two reads (k-rows +0..3, +4..7).  Row 16 s + 8 kh + 4 t + q has row & 3 = q
+    // and (row >> 2) & 3 = (2 kh + t) & 3 in the swizzle.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tc0 = wn0 + 16 * ((lane >> 4) & 1);
+    typedef s16x4 __attribute__((address_space(3)))* trp_t;
+    auto read_frags = [&](const unsigned char* As, int fb, int s, auto tr) {
         const unsigned char* Bs = As + A_SZ;
         const int off = ((2 * s + h) ^ swz) << 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
             af[fb][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * 128 + off);
+        if constexpr (decltype(tr)::value) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            bf[fb][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * 128 + off);
+            for (int j = 0; j < TN; ++j) {
+                // the next 32 columns are 4 chunks on: XOR with 4 flips bit 2 of the chunk index, which the swizzle
+                // term ((q << 2) | ...) may also flip, so the offset is recomputed per j from the chunk index
+                const int ch = ((tc0 + 32 * j) >> 3) + (tp >> 1);
+                const unsigned char* base = Bs + s * (16 * BN * 2) + 8 * (tp & 1);
+                const int o0 = (8 * h + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h) & 3))) << 4);
+                const int o1 = (8 * h + 4 + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o1));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[fb][j] = __builtin_bit_cast(bf16x8, both);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[fb][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + r) * 128 + off);
+        }
     };
 
     // prologue: every buffer in flight, then tile 0 published and its first fragments read
@@ -607,7 +653,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     JB_STAMP(1);
-    read_frags(smem, 0, 0);
+    auto k_loop = [&](auto tr) {
+    read_frags(smem, 0, 0, tr);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char* As = smem + cur * T_SZ;
@@ -621,7 +668,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s & 1][0], af[s & 1][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < BK / 16) {
-                read_frags(As, (s + 1) & 1, s + 1);
+                read_frags(As, (s + 1) & 1, s + 1, tr);
             } else if (kt + 1 < nk) {
                 // tile kt+1 becomes visible and buffer `cur` free (every wave holds its last fragments of tile kt in
                 // registers: lgkmcnt(0)); tile kt+NB goes into it and the first fragments of tile kt+1 are fetched
@@ -631,7 +678,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (kt + NB < nk) stage(cur, kt + NB);
-                read_frags(smem + nxt * T_SZ, 0, 0);
+                read_frags(smem + nxt * T_SZ, 0, 0, tr);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -643,6 +690,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
         }
         cur = nxt;
     }
+    };
+    if (b_tr) k_loop(std::true_type{}); else k_loop(std::false_type{});
     __syncthreads();
     JB_STAMP(2);
 
@@ -752,6 +801,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
+        if (s.b_tr) return jamie_fail(-1, "%s: b_tr needs a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         d.a_bytes = (unsigned)(((long long)(s.M - 1) * s.lda + s.K) * 2);
         d.b_bytes = (unsigned)(((long long)(s.N - 1) * s.ldb + s.K) * 2);
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
@@ -787,6 +837,10 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
+        d.b_tr = s.b_tr;
+        if (s.b_tr && !(V2 && BN == 128))
+            return jamie_fail(-1, "%s: b_tr (B stored [K, N]) needs a large-tile configuration with 128 columns (23, 24, 25) [%lld %lld]",
+                              "jamie_gemm_bf16", BM, BN);
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
     if (tiles == 0) return 0;
@@ -828,11 +882,13 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         const jamie_gemm_problem& s = pr[i];
         JAMIE_ARG(s.A && s.B && s.C, "null operand");
         JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
-        JAMIE_ARG(s.ldc >= s.N && s.lda >= s.K && s.ldb >= s.K, "leading dimensions");
+        JAMIE_ARG(s.ldc >= s.N && s.lda >= s.K && s.ldb >= (s.b_tr ? s.N : s.K), "leading dimensions");
         if (s.K < min_k) min_k = s.K;
         JAMIE_ARG(s.K % 8 == 0 && s.lda % 8 == 0 && s.ldb % 8 == 0, "bf16 operands need K, lda, ldb multiples of 8");
+        JAMIE_ARG(!s.b_tr || (s.N % 8 == 0 && s.N >= 8 && s.epi == JAMIE_EPI_STORE), "b_tr: N must be a multiple of 8, plain store epilogue");
         JAMIE_ARG(((uintptr_t)s.A % 16) == 0 && ((uintptr_t)s.B % 16) == 0, "bf16 operands must be 16-byte aligned");
-        JAMIE_ARG(((long long)(s.M - 1) * s.lda + s.K) * 2 < 0xFFFFFFF0LL && ((long long)(s.N - 1) * s.ldb + s.K) * 2 < 0xFFFFFFF0LL,
+        JAMIE_ARG(((long long)(s.M - 1) * s.lda + s.K) * 2 < 0xFFFFFFF0LL &&
+                      (s.b_tr ? ((long long)(s.K - 1) * s.ldb + s.N) : ((long long)(s.N - 1) * s.ldb + s.K)) * 2 < 0xFFFFFFF0LL,
                   "operands must stay below 4 GiB");
         JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.epi == JAMIE_EPI_MSE, "bf16 GEMM epilogues: STORE, MSE");
         JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.splitk <= 1, "fused epilogues need splitk == 1");

@@ -77,7 +77,7 @@ def kl_anneal(epoch, min_epochs, epoch_DNN):
 
 class TrainEngine:
     def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
-                 world_size=1, compute_dtype='f32'):
+                 world_size=1, compute_dtype='f32', dx_from_weights=True):
         """compute_dtype 'f32': exact-fp32 MFMA GEMMs (the parity configuration).  'bf16': bf16 MFMA GEMMs with
         fp32 accumulation, fp32 master weights / optimiser / BatchNorm / losses (BASELINE config 2); needs every
         feature count, the latent size and the batch size to be multiples of 8."""
@@ -188,9 +188,13 @@ class TrainEngine:
             # bf16 copies of the weights: same flat layout, plus K-contiguous transposes for the dX products
             self.wbf_flat = torch.zeros(model.layout.total, device=self.dev, dtype=torch.bfloat16)
             self.wbf = model.layout.views(self.wbf_flat)
+            # dX = dy W: the large-tile kernel reads W [out, in] as stored (b_tr: [k][n] LDS image, transposed fragment
+            # reads), so only the layers whose backward launch does not take that kernel keep a transposed copy
             self.wT = {}
             for i, d in enumerate(self.dims):
-                for lin in ('enc1', 'head', 'dec0', 'dec1', 'dec2'):
+                for lin, key in (('enc1', 'd_a1'), ('head', 'd_a2'), ('dec0', 'd_comb'), ('dec1', 'd_e1'), ('dec2', 'd_e2')):
+                    if dx_from_weights and self.gcfg.get(key, -1) in BF16_TILE:
+                        continue
                     nout, nin = model.p[f'm{i}.{lin}.W'].shape
                     self.wT[f'm{i}.{lin}'] = torch.empty(nin, nout, device=self.dev, dtype=torch.bfloat16)
             self.refresh_weights_bf16()
@@ -408,7 +412,10 @@ class TrainEngine:
             w, P = self.ws[i], self.m.p
             dy, W, out = w[dy_key], P[f'm{i}.{lin}.W'], w[out_key]
             nout, nin = W.shape
-            if self.bf16:     # dx = dy W  ==  dy (W^T)^T with the K-contiguous transposed copy
+            if self.bf16 and f'm{i}.{lin}' not in self.wT:      # dx = dy W on W [out, in] as stored (b_tr)
+                probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wbf[f'm{i}.{lin}.W'], out, self.B, nin, nout,
+                                             nout, nin, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin, b_tr=True))
+            elif self.bf16:   # dx = dy W  ==  dy (W^T)^T with the K-contiguous transposed copy (skinny layers)
                 probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], out, self.B, nin, nout,
                                              nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
             else:
@@ -450,8 +457,12 @@ class TrainEngine:
         for i, d in enumerate(self.dims):
             w = self.ws[i]
             nout, nin = self.g[f'm{i}.{lin}.W'].shape
-            probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
-                                         nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+            if f'm{i}.{lin}' not in self.wT:                    # W [out, in] as stored (b_tr): no transposed copy
+                probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wbf[f'm{i}.{lin}.W'], w[out_key], self.B, nin, nout,
+                                             nout, nin, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin, b_tr=True))
+            else:
+                probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
+                                             nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         for i, d in enumerate(self.dims):
             w = self.ws[i]
             dW = self.g[f'm{i}.{lin}.W']

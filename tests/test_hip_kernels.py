@@ -498,6 +498,43 @@ def test_gemm_bf16(nv, M, N, K, cfg):
     close(out, ref, rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)     # exact bf16 products, fp32 accumulation
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (512, 256, 128), (130, 264, 200), (512, 1000, 2000), (40, 136, 24),
+                                   (256, 72, 520)])
+@pytest.mark.parametrize('cfg', [23, 24, 25])
+def test_gemm_bf16_b_stored_k_by_n(nv, M, N, K, cfg):
+    """b_tr: C = A [M,K] x B [K,N] with B row-major as stored (the dX product dy W on the weights W [out, in] themselves;
+    [k][n] LDS image + ds_read_b64_tr_b16): ragged M / N, partial k-tiles, split-K, grouped with a K-contiguous problem."""
+    g = torch.Generator().manual_seed(M + N + K + cfg)
+    a, w = _bf16(torch.randn(M, K, generator=g)), _bf16(torch.randn(K, N, generator=g))
+    out = torch.full((M, N), float('nan'), device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(a), dev(w), out, M, N, K, K, N, N, b_tr=True)], cfg)
+    ref = a.double() @ w.double()
+    close(out, ref, rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)
+    # exactly representable values: bit-exact against fp32 torch (catches any swizzle / lane-map slip at every position)
+    ai = _bf16(torch.randint(-4, 5, (M, K), generator=g).float())
+    wi = _bf16((torch.arange(K * N, dtype=torch.float32).reshape(K, N) % 13) - 6)
+    out2 = torch.zeros(M, N, device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(ai), dev(wi), out2, M, N, K, K, N, N, b_tr=True)], cfg)
+    assert torch.equal(out2.cpu(), ai.float() @ wi.float())
+    if K >= 128:
+        sk = 2
+        slabs = torch.full((sk, M, N), float('nan'), device='cuda')
+        a2, w2 = _bf16(torch.randn(72, 136, generator=g)), _bf16(torch.randn(200, 136, generator=g))
+        o2 = torch.zeros(72, 200, device='cuda')
+        nv.gemm_bf16([nv.gemm_problem(dev(a), dev(w), slabs, M, N, K, K, N, N, splitk=sk, slab_stride=M * N, b_tr=True),
+                      nv.gemm_problem(dev(a2), dev(w2), o2, 72, 200, 136, 136, 136, 200)], cfg)
+        close(slabs.sum(0), ref, rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)
+        close(o2, a2.double() @ w2.double().t(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_bf16_b_tr_needs_a_128_column_large_tile(nv):
+    a, w = dev(_bf16(torch.randn(64, 64))), dev(_bf16(torch.randn(64, 64)))
+    out = torch.zeros(64, 64, device='cuda')
+    for cfg in (1, 7, 26, 27):
+        with pytest.raises(nv.JamieHipError):
+            nv.gemm_bf16([nv.gemm_problem(a, w, out, 64, 64, 64, 64, 64, 64, b_tr=True)], cfg)
+
+
 def test_gemm_bf16_identity_asymmetric(nv):
     n = 96
     B = _bf16(torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)       # exactly representable
