@@ -99,6 +99,9 @@ typedef struct {
     long long slab_stride;
     const void* src_bf16;       /* alternative source: bf16 [R, C] (ld), with src = NULL and nslab = 1 (a transposed  */
                                 /* copy of an existing bf16 matrix, e.g. the weights the Adam kernel wrote)            */
+    const int32_t* rows;        /* optional row gather: output row r reads source row rows[r] (x = data[idx],          */
+                                /* jamie.py:583: the batch is gathered, cast and transposed in ONE launch)            */
+    float* dst32; int ld32;     /* optional fp32 copy [R, C] of the gathered / slab-summed rows                        */
 } jamie_cast_problem;
 int jamie_cast_transpose(const jamie_cast_problem* problems /*host*/, int count /* <= 16 */, void* stream);
 

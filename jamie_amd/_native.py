@@ -34,7 +34,8 @@ class GemmProblem(C.Structure):
 class CastProblem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('dstT', C.c_void_p),
                 ('R', C.c_int), ('C', C.c_int), ('ld', C.c_int), ('ldd', C.c_int), ('ldt', C.c_int),
-                ('nslab', C.c_int), ('slab_stride', C.c_longlong), ('src_bf16', C.c_void_p)]
+                ('nslab', C.c_int), ('slab_stride', C.c_longlong), ('src_bf16', C.c_void_p),
+                ('rows', C.c_void_p), ('dst32', C.c_void_p), ('ld32', C.c_int)]
 
 
 class MseProblem(C.Structure):
@@ -310,16 +311,21 @@ def gemm_bf16_tile(max_m, max_n, cfg=-1):
     return bm.value, bn.value
 
 
-def cast_problem(src, dst=None, dstT=None, nslab=1, slab_stride=0):
-    """fp32 [R, C] (contiguous 2-D view; slabs `slab_stride` elements apart) -> bf16 dst [R, C] / dstT [C, R]."""
+def cast_problem(src, dst=None, dstT=None, nslab=1, slab_stride=0, rows=None, dst32=None):
+    """fp32 [R, C] (contiguous 2-D view; slabs `slab_stride` elements apart) -> bf16 dst [R, C] / dstT [C, R].
+    `rows` (int32 [R'] device tensor): output row r reads source row rows[r]; `dst32`: fp32 copy of the output rows."""
     p = CastProblem()
     R, Cc = src.shape[-2], src.shape[-1]
+    if rows is not None:
+        p.rows, R = ptr(rows), rows.numel()
+    if dst32 is not None:
+        p.dst32, p.ld32 = ptr(dst32), Cc
     if src.dtype == torch.bfloat16:      # bf16 source: transposed (or plain) copy of an existing bf16 matrix
         p.src_bf16, p.dst, p.dstT = ptr(src), ptr(dst), ptr(dstT)
     else:
         p.src, p.dst, p.dstT = ptr(src), ptr(dst), ptr(dstT)
     p.R, p.C, p.ld, p.ldd, p.ldt, p.nslab, p.slab_stride = R, Cc, Cc, Cc, R, nslab, slab_stride
-    p._keep = (src, dst, dstT)
+    p._keep = (src, dst, dstT, rows, dst32)
     return p
 
 

@@ -947,7 +947,7 @@ extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int*
 // the reads and the transposed writes move whole 128-byte lines.  Up to 16 matrices per launch (the weights).
 // ------------------------------------------------------------------------------------------------
 #define CT_MAX 16
-struct CastDev { const float* src; const unsigned short* src_bf; unsigned short* dst; unsigned short* dstT; long long slab_stride; int R, C, ld, ldd, ldt, nslab, blk_begin, tiles_c; };
+struct CastDev { const float* src; const unsigned short* src_bf; unsigned short* dst; unsigned short* dstT; const int32_t* rows; float* dst32; long long slab_stride; int R, C, ld, ldd, ldt, ld32, nslab, blk_begin, tiles_c; };
 struct CastGroup { CastDev p[CT_MAX]; int count; };
 
 __global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
@@ -980,8 +980,9 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
                 if (c + 3 < P.C) v.w = __uint_as_float((unsigned)sp[3] << 16);
             }
         } else if (r < P.R) {
+            const long long gr = P.rows ? (long long)P.rows[r] : (long long)r;      // row gather: x = data[idx] (jamie.py:583)
             for (int s = 0; s < P.nslab; ++s) {
-                const float* sp = P.src + s * P.slab_stride + (long long)r * P.ld + c;
+                const float* sp = P.src + s * P.slab_stride + gr * P.ld + c;
                 if (vec && c + 3 < P.C) {
                     const float4 u = *reinterpret_cast<const float4*>(sp);
                     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
@@ -994,6 +995,17 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
             }
         }
         tile[rr][4 * q] = v.x; tile[rr][4 * q + 1] = v.y; tile[rr][4 * q + 2] = v.z; tile[rr][4 * q + 3] = v.w;
+        if (P.dst32 && r < P.R) {        // fp32 copy of the (gathered, slab-summed) rows
+            float* dp = P.dst32 + (long long)r * P.ld32 + c;
+            if ((P.ld32 % 4 == 0) && (((uintptr_t)P.dst32 & 15) == 0) && c + 3 < P.C) {
+                *reinterpret_cast<float4*>(dp) = v;
+            } else {
+                if (c < P.C) dp[0] = v.x;
+                if (c + 1 < P.C) dp[1] = v.y;
+                if (c + 2 < P.C) dp[2] = v.z;
+                if (c + 3 < P.C) dp[3] = v.w;
+            }
+        }
         if (P.dst && r < P.R) {
             const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)v.x), b1 = __builtin_bit_cast(unsigned short, (__bf16)v.y);
             const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)v.z), b3 = __builtin_bit_cast(unsigned short, (__bf16)v.w);
@@ -1039,13 +1051,16 @@ extern "C" int jamie_cast_transpose(const jamie_cast_problem* pr, int count, voi
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
         const jamie_cast_problem& s = pr[i];
-        JAMIE_ARG((s.src || s.src_bf16) && (s.dst || s.dstT) && s.R > 0 && s.C > 0 && s.ld >= s.C && s.nslab >= 1, "bad cast problem");
+        JAMIE_ARG((s.src || s.src_bf16) && (s.dst || s.dstT || s.dst32) && s.R > 0 && s.C > 0 && s.ld >= s.C && s.nslab >= 1, "bad cast problem");
+        JAMIE_ARG(!s.rows || s.src, "row gather needs an fp32 source");
+        JAMIE_ARG(!s.dst32 || s.ld32 >= s.C, "ld32 < C");
         JAMIE_ARG(!s.src_bf16 || (!s.src && s.nslab == 1), "src_bf16 excludes src / slabs");
         JAMIE_ARG(!s.dst || s.ldd >= s.C, "ldd < C");
         JAMIE_ARG(!s.dstT || s.ldt >= s.R, "ldt < R");
         CastDev& d = g.p[i];
         d.src = s.src; d.src_bf = (const unsigned short*)s.src_bf16; d.dst = (unsigned short*)s.dst; d.dstT = (unsigned short*)s.dstT; d.slab_stride = s.slab_stride;
         d.R = s.R; d.C = s.C; d.ld = s.ld; d.ldd = s.ldd; d.ldt = s.ldt; d.nslab = s.nslab;
+        d.rows = s.rows; d.dst32 = s.dst32; d.ld32 = s.ld32;
         d.blk_begin = blocks; d.tiles_c = (s.C + 63) / 64;
         blocks += ((s.R + 63) / 64) * d.tiles_c;
     }

@@ -526,9 +526,12 @@ class TrainEngine:
     # ---- the step ----
     def load_batch(self, data, idx):
         """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors."""
+        if self.bf16:      # gather + bf16 copy + transposed bf16 copy of the batch in one launch
+            nv.cast_transpose([nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'], rows=idx[i],
+                                               dst32=self.ws[i]['x']) for i in range(self.M)])
+            return
         for i in range(self.M):
             nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
-        self._cast('x')
 
     def _region(self, ar, name):
         """Tell an overlapping all-reduce that the gradients of parameter region `name` have been launched."""

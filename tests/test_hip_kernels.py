@@ -435,6 +435,13 @@ def test_colsum(nv):
     close(out, X.double().sum((0, 1)), 1e-5, 1e-4)           # 390 fp32 terms per column
     nv.colsum(Xd, 130, 50, 50, out, nslab=3, slab_stride=130 * 50, accumulate=True)
     close(out, 2 * X.double().sum((0, 1)), 1e-5, 2e-4)
+    # the 16-byte path (rows of whole float4s), grouped launch, row counts around the 8-deep unrolled loop
+    g = torch.Generator().manual_seed(9)
+    mats = [torch.randn(512, 2000, generator=g), torch.randn(135, 72, generator=g), torch.randn(17, 264, generator=g)]
+    outs = [torch.full((m.shape[1],), float('nan'), device='cuda') for m in mats]
+    nv.colsum_group([(dev(m), o) for m, o in zip(mats, outs)])
+    for m, o in zip(mats, outs):
+        close(o, m.double().sum(0), 1e-5, 2e-4)
 
 
 def test_sampler_without_replacement(nv):
@@ -483,6 +490,20 @@ def test_cast_transpose(nv, R, C, nslab):
     ref = src.sum(0).to(torch.bfloat16)
     assert torch.equal(dst.cpu(), ref)
     assert torch.equal(dstT.cpu(), ref.t())
+
+
+def test_cast_transpose_with_row_gather(nv):
+    """x = data[idx] (jamie.py:583) fused with the bf16 / transposed copies: fp32 rows, bf16 [B, d], bf16 [d, B]."""
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn(1000, 200, generator=g)
+    idx = torch.randint(0, 1000, (130,), generator=g).to(torch.int32)
+    x32 = torch.zeros(130, 200, device='cuda')
+    xb = torch.zeros(130, 200, dtype=torch.bfloat16, device='cuda')
+    xt = torch.zeros(200, 130, dtype=torch.bfloat16, device='cuda')
+    nv.cast_transpose([nv.cast_problem(dev(data), xb, xt, rows=dev(idx), dst32=x32)])
+    ref = data[idx.long()]
+    assert torch.equal(x32.cpu(), ref)
+    assert torch.equal(xb.cpu(), ref.to(torch.bfloat16)) and torch.equal(xt.cpu(), ref.to(torch.bfloat16).t())
 
 
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (512, 256, 128), (128, 72, 200), (40, 136, 24), (512, 64, 1000),
