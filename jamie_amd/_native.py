@@ -128,6 +128,9 @@ EXPORTS = {
     'jamie_latent_m_bwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p]),
     'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
     'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_grad_sqnorm_ranges': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
+    'jamie_sqnorm_range_blocks': (C.c_int, [C.c_void_p, C.c_int]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'jamie_gather_rows': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -445,3 +448,18 @@ def standardise_columns(X):
     _call('jamie_col_stats', ptr(X), f64, N, d, d, ptr(part), R, ptr(mean), ptr(sd), _stream())
     _call('jamie_standardise', ptr(X), f64, N, d, d, ptr(mean), ptr(sd), ptr(out), _stream())
     return out, mean, sd
+
+
+class SqRanges:
+    """Host description of the gradient ranges jamie_grad_sqnorm_ranges covers (kept alive for recorded plans)."""
+
+    def __init__(self, ranges):
+        self.count = len(ranges)
+        self.off = (C.c_longlong * self.count)(*[int(a) for a, _ in ranges])
+        self.len = (C.c_longlong * self.count)(*[int(b) for _, b in ranges])
+        self.blocks = load().jamie_sqnorm_range_blocks(self.len, self.count)
+
+
+def grad_sqnorm_ranges(g, ranges, partials, state):
+    _call('jamie_grad_sqnorm_ranges', ptr(g), ranges.off, ranges.len, ranges.count, ptr(partials), partials.numel(),
+          ptr(state), _stream())

@@ -744,6 +744,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                         const float4 o = *reinterpret_cast<const float4*>(cp);
                         v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                     }
+                    local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];   // -> partial[t]: ||dW||^2 for the clip
                 } else {  // JAMIE_EPI_MSE
                     const float4 x = *reinterpret_cast<const float4*>(P.aux0 + (long long)m * P.aux_ld + nc);
                     v[0] -= x.x; v[1] -= x.y; v[2] -= x.z; v[3] -= x.w;
@@ -759,6 +760,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                     if (P.epi == JAMIE_EPI_STORE) {
                         if (P.accumulate) w += cp[e];
                         cp[e] = w;
+                        local += w * w;
                     } else {
                         const float d = w - P.aux0[(long long)m * P.aux_ld + nc + e];
                         local += d * d;
@@ -768,7 +770,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
             }
         }
     }
-    if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
+    // per-tile partial: the MSE term (EPI_MSE) or, for a plain store, the sum of squares of the stored values -- the
+    // dW launches hand the gradient-norm kernel its partial sums (clip_grad_norm_, jamie.py:739) without a second pass
+    if (P.partial != nullptr) {           // (block_sum's own barrier comes before it touches `red`, which the scratch overlaps)
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
     }
@@ -802,6 +806,8 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
         if (s.b_tr) return jamie_fail(-1, "%s: b_tr needs a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
+        if (s.partial && s.epi == JAMIE_EPI_STORE)
+            return jamie_fail(-1, "%s: sum-of-squares partials of a plain store need a large-tile configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         d.a_bytes = (unsigned)(((long long)(s.M - 1) * s.lda + s.K) * 2);
         d.b_bytes = (unsigned)(((long long)(s.N - 1) * s.ldb + s.K) * 2);
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
@@ -838,6 +844,9 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
         d.b_tr = s.b_tr;
+        if (s.partial && s.epi == JAMIE_EPI_STORE && (!V2 || d.splitk != 1))
+            return jamie_fail(-1, "%s: sum-of-squares partials of a plain store need a large-tile configuration and splitk == 1 [%lld %lld]",
+                              "jamie_gemm_bf16", BM, BN);
         if (s.b_tr && !(V2 && BN == 128))
             return jamie_fail(-1, "%s: b_tr (B stored [K, N]) needs a large-tile configuration with 128 columns (23, 24, 25) [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);

@@ -94,6 +94,58 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     }
 }
 
+// Sum of squares over a list of ranges of the gradient buffer (the parameters whose producers do not emit partial sums
+// themselves: biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices), one chunk of <= 16384
+// elements per workgroup; also advances the step counter, as jamie_grad_sqnorm does.
+#define JAMIE_SQ_CHUNK 16384
+struct SqRanges { long long off[128]; int len[128]; };
+__global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, SqRanges r, float* partials,
+                                                                 uint64_t* state) {
+    __shared__ float red[4];
+    const float* p = g + r.off[blockIdx.x];
+    const int n = r.len[blockIdx.x], n4 = n >> 2;
+    float acc = 0.f;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += p[i] * p[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) acc += p[i] * p[i];
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t;
+        if (blockIdx.x == 0 && state) state[1] += 1;
+    }
+}
+
+extern "C" int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets, const long long* lengths, int count,
+                                        float* partials, int n_partials, uint64_t* state, void* stream) {
+    JAMIE_ARG(g && offsets && lengths && partials && count >= 1, "null pointer / empty");
+    SqRanges r;
+    int nb = 0;
+    for (int i = 0; i < count; ++i) {
+        JAMIE_ARG(offsets[i] >= 0 && lengths[i] >= 0, "negative range");
+        for (long long o = 0; o < lengths[i]; o += JAMIE_SQ_CHUNK) {
+            JAMIE_ARG(nb < 128, "more than 128 chunks of 16384 elements");
+            r.off[nb] = offsets[i] + o;
+            r.len[nb] = (int)(lengths[i] - o < JAMIE_SQ_CHUNK ? lengths[i] - o : JAMIE_SQ_CHUNK);
+            ++nb;
+        }
+    }
+    JAMIE_ARG(nb >= 1 && n_partials == nb, "n_partials must equal jamie_sqnorm_range_blocks()");
+    hipLaunchKernelGGL(grad_sqnorm_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, r, partials, state);
+    return jamie_launch_status("jamie_grad_sqnorm_ranges");
+}
+
+extern "C" int jamie_sqnorm_range_blocks(const long long* lengths, int count) {
+    int nb = 0;
+    for (int i = 0; i < count; ++i) nb += (int)((lengths[i] + JAMIE_SQ_CHUNK - 1) / JAMIE_SQ_CHUNK);
+    return nb;
+}
+
 static int grid_for(long long n) {
     long long b = (n / 4 + 255) / 256;
     if (b < 1) b = 1;

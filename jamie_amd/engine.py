@@ -198,6 +198,34 @@ class TrainEngine:
                     nout, nin = model.p[f'm{i}.{lin}.W'].shape
                     self.wT[f'm{i}.{lin}'] = torch.empty(nin, nout, device=self.dev, dtype=torch.bfloat16)
             self.refresh_weights_bf16()
+        # ---- gradient norm without a second pass over the weight gradients (single GPU, bf16 large-tile dW launches):
+        # every dW tile's epilogue writes its sum of squares into `norm_partials`; a small kernel adds the ranges the
+        # GEMMs do not produce (biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices)
+        self.fused_norm, self._fuse_now, self._norm_ready = False, False, False
+        big = {'dec2': 'd_e2', 'dec1': 'd_e1', 'enc1': 'd_a1', 'enc0': 'dw'}
+        if self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values()):
+            bm_d, bn_d = BF16_TILE[self.gcfg['dw']]
+            self.dw_partial, off, covered = {}, 0, []
+            for lin in big:
+                for i in range(self.M):
+                    o, shp = model.layout.entries[f'm{i}.{lin}.W']
+                    t = math.ceil(shp[0] / bm_d) * math.ceil(shp[1] / bn_d)
+                    self.dw_partial[f'm{i}.{lin}'] = (off, t)
+                    off += t
+                    covered.append((o, o + shp[0] * shp[1]))
+            covered.sort()
+            rest, pos = [], 0
+            for lo, hi in covered:
+                if lo > pos:
+                    rest.append((pos, lo - pos))
+                pos = hi
+            if n > pos:
+                rest.append((pos, n - pos))
+            self.sq_ranges = nv.SqRanges(rest)
+            if off + self.sq_ranges.blocks <= nv.load().jamie_max_partials() and self.sq_ranges.blocks <= 128:
+                self.fused_norm = True
+                self.n_dw_partials = off
+                self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm), **f32)
         bm_t, bn_t = (nv.gemm_bf16_tile(B, max(self.dims)) if self.bf16 else
                       nv.gemm_tile(nv.NT, B, max(self.dims), 2 * max(self.dims)))   # tile of the grouped launch
         self.rec_tiles = [math.ceil(B / bm_t) * math.ceil(d / bn_t) for d in self.dims]
@@ -435,7 +463,7 @@ class TrainEngine:
             nout, nin = dW.shape
             if self.bf16:     # dW = dy^T a  ==  (dy^T) (a^T)^T, both [features, B] copies are K(=batch)-contiguous
                 probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B,
-                                             nin, accumulate=self.accumulate))
+                                             nin, accumulate=self.accumulate, partial=self._dw_partial(i, lin)))
             else:
                 probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
         if self.bf16:
@@ -443,6 +471,13 @@ class TrainEngine:
             nv.gemm_bf16(probs, self.gcfg['dw'] if big else -1)
         else:
             nv.gemm(probs, nv.TN)
+
+    def _dw_partial(self, i, lin):
+        """Slice of `norm_partials` the dW launch of m{i}.{lin} fills (None: the separate norm kernel reads the gradient)."""
+        if not self._fuse_now or f'm{i}.{lin}' not in self.dw_partial:
+            return None
+        off, t = self.dw_partial[f'm{i}.{lin}']
+        return self.norm_partials[off:off + t]
 
     def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key):
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
@@ -468,7 +503,7 @@ class TrainEngine:
             dW = self.g[f'm{i}.{lin}.W']
             nout, nin = dW.shape
             probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
-                                         accumulate=self.accumulate))
+                                         accumulate=self.accumulate, partial=self._dw_partial(i, lin)))
         nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
@@ -636,6 +671,7 @@ class TrainEngine:
         B, L = self.B, self.L
         acc = self.accumulate
         self._wait_wT()
+        self._fuse_now = self.fused_norm and allreduce is None      # a reduced gradient needs its norm taken afterwards
         nv.colsum_group([(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
         self._region(allreduce, 'dec2')
@@ -662,14 +698,22 @@ class TrainEngine:
         self._cast('da1')
         self._dw_gemm('da1', 'x', 'enc0')
         self._region(allreduce, 'enc0')
+        self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
 
     def optimizer_step(self):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step)."""
-        nv.grad_sqnorm(self.grad, self.norm_partials, self.state)
+        if self._norm_ready:         # the dW launches of this backward pass wrote their tiles' sums of squares
+            n_live = self.n_dw_partials + self.sq_ranges.blocks
+            norm = self.norm_partials[:n_live]
+            nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state)
+        else:                        # (also: reduced gradient, external backward) one pass over the whole buffer
+            norm = self.norm_partials[:self.n_norm]
+            nv.grad_sqnorm(self.grad, norm, self.state)
+        self._norm_ready = False
         if not self.pipeline:
             self._launch('adam', lambda: nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq,
-                                                       self.norm_partials, self.hyper, self.state,
+                                                       norm, self.hyper, self.state,
                                                        self.wbf_flat if self.bf16 else None))
             if self.bf16 and self.side_transposes:
                 # the K-contiguous W^T copies are only read by the NEXT backward pass: they are made on a side stream
@@ -696,7 +740,7 @@ class TrainEngine:
             for g, names in enumerate(self.PIPE_GROUPS):
                 lo, hi = regions[names[0]][0], regions[names[-1]][1]
                 self._launch('adam', lambda: nv.clip_adam(self.m.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi],
-                                                           self.exp_avg_sq[lo:hi], self.norm_partials, self.hyper,
+                                                           self.exp_avg_sq[lo:hi], norm, self.hyper,
                                                            self.state, self.wbf_flat[lo:hi] if self.bf16 else None))
                 if self.bf16:
                     self.refresh_weights_bf16(transposes_only=True, lins=names)

@@ -945,3 +945,30 @@ def test_checkpoint_resume_is_bit_identical(jam, tmp_path, sampler, mode):
     with pytest.raises(ValueError):
         with contextlib.redirect_stdout(io.StringIO()):
             jam.JAMIE(epoch_DNN=8, **{**kw, 'output_dim': 4}).fit_transform(dataset=data, resume_from=ck)
+
+
+def test_fused_gradient_norm_equals_the_norm_of_the_gradient(jam):
+    """bf16 single-GPU mode: the dW launches emit per-tile sums of squares and jamie_grad_sqnorm_ranges adds the rest;
+    together they are ||g||^2 of the whole flat gradient (clip_grad_norm_, jamie.py:739), also when gradients
+    accumulate (batch_step=False) and after a fall-back to the one-pass kernel."""
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    dims, L, B = (520, 264), 32, 512
+    torch.manual_seed(3)
+    model = edModelVar(dims, L)
+    eng = TrainEngine(model, B, compute_dtype='bf16')
+    assert eng.fused_norm
+    g = torch.Generator().manual_seed(1)
+    for step in range(4):
+        eng.set_batch([torch.randn(B, d, generator=g).cuda() for d in dims])
+        eng.accumulate = step == 2                      # step 2 adds its gradient to step 1's buffer
+        fall_back = step == 3
+        eng.forward_backward()
+        if fall_back:
+            eng._norm_ready = False                     # what a reduced (multi-GPU) gradient does
+        want = float(eng.grad.double().norm())
+        eng.optimizer_step()
+        n_live = eng.n_norm if fall_back else eng.n_dw_partials + eng.sq_ranges.blocks
+        got = float(torch.sqrt(eng.norm_partials[:n_live].double().sum()))
+        assert abs(got - want) < 2e-6 * want, (step, got, want)
+    assert int(eng.state[1].item()) == 4
