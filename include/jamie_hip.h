@@ -71,6 +71,9 @@ typedef struct {
     int b_tr;                   /* jamie_gemm_bf16 only: B is stored [K, N] row-major (N contiguous, ldb >= N) -- the dX
                                  * product dy W reads the weights W [out, in] as they are (model.py Linear backward), no
                                  * transposed copy; large-tile configurations with 128 columns (23, 24, 25) */
+    int a_tr;                   /* jamie_gemm_bf16 only, with b_tr: A is stored [K, M] row-major (lda >= M) -- dW = dy^T a
+                                 * reads dy [B, out] and a [B, in] as the layers produced them, no transposed activation
+                                 * copies; 128 x 128 large-tile configurations (24, 25) */
 } jamie_gemm_problem;
 
 /* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */

@@ -34,6 +34,7 @@ struct GemmBDev {
     int splitk, kchunk, tiles_m, tiles_n, n_tiles;
     int epi, accumulate, vec;
     int b_tr;            // B is [K, N] row-major (N contiguous): staged as [k][n] rows, fragments by ds_read_b64_tr_b16
+    int a_tr;            // A is [K, M] row-major (M contiguous), likewise (dW = dy^T a reads dy [B, out] and a [B, in])
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -479,7 +480,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
 // tile kt+NB and the first fragment reads of tile kt+1, all of it covered by that sub-step's MFMAs; and the MFMA
 // operands are swapped (D = W-fragment x a-fragment), which transposes the accumulator map: a lane then holds 4
 // CONSECUTIVE n for one m, stored as one 16-byte access (4x fewer store instructions).
-template <int BM, int BN, int WM, int WN, int TAG, int NB>
+// TRM = 0: no problem of the launch has a k-row-major operand (forward launches): the a_tr / b_tr paths are compiled out,
+// TRM = 1: per-problem flags (backward launches: dX reads W as stored, dW reads dy and a as stored)
+template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup g) {
     constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -530,16 +533,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     const int r = lane & 31, h = lane >> 5;
     const int lrow = lane >> 3, pch = lane & 7;
     const unsigned short* a_src[PA]; const unsigned short* b_src[PB];
+    const bool a_tr = TRM != 0 && P.a_tr != 0;
+    const long long a_kstep = a_tr ? (long long)P.lda : 1;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int row = 8 * (wid + NW * i) + lrow;
-        a_src[i] = P.A + (long long)min(m0 + row, P.M - 1) * P.lda + ((pch ^ ((row >> 1) & 7)) * 8);
+        if (a_tr) {      // A stored [K, M]: the same [k][m] image as the b_tr operand (below)
+            const int piece = wid + NW * i, krow = 4 * piece + (lane >> 4);
+            const int lc = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+            a_src[i] = P.A + (long long)krow * P.lda + min(m0 + lc * 8, P.M - 8);
+        } else {
+            const int row = 8 * (wid + NW * i) + lrow;
+            a_src[i] = P.A + (long long)min(m0 + row, P.M - 1) * P.lda + ((pch ^ ((row >> 1) & 7)) * 8);
+        }
     }
     // B operand as stored: [N, K] with K contiguous (forward, dW) or, b_tr, [K, N] with N contiguous (dX = dy W reads
     // the weights W [out, in] as they are: no transposed copy).  The b_tr tile is [64 k][BN n] with 256-byte rows, one
     // 1-KiB DMA piece = 4 k-rows, 16-byte chunks XOR-swizzled by ((k & 3) << 2) | ((k >> 2) & 3): the image on which
     // both DMA fills and the 32x32x16 transposed reads are conflict-free (cdna_hip_programming.md T10 (b)).
-    const bool b_tr = P.b_tr != 0;
+    const bool b_tr = TRM != 0 && P.b_tr != 0;
     const long long b_kstep = b_tr ? (long long)P.ldb : 1;
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -561,18 +572,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
         if (kt < nfull) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0 * a_kstep), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < PB; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
         } else {   // partial k-tile: masked loads through registers into the same swizzled image
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                const int f = tid + j * NT, row = f >> 3, c = f & 7;
-                const int gm = min(m0 + row, P.M - 1);
+                const int f = tid + j * NT;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.A + (long long)gm * P.lda + k0 + c * 8);
-                *reinterpret_cast<uint4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+                if (a_tr) {
+                    const int krow = f / (BM / 8), lc = f % (BM / 8);
+                    if (k0 + krow < kend)
+                        v = *reinterpret_cast<const uint4*>(P.A + (long long)(k0 + krow) * P.lda + min(m0 + lc * 8, P.M - 8));
+                    *reinterpret_cast<uint4*>(As + krow * (BM * 2) + ((lc ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)) = v;
+                } else {
+                    const int row = f >> 3, c = f & 7;
+                    const int gm = min(m0 + row, P.M - 1);
+                    if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.A + (long long)gm * P.lda + k0 + c * 8);
+                    *reinterpret_cast<uint4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+                }
             }
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
@@ -615,14 +634,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     // block and lane i receives column i of the 4 rows; lane (n = lane & 31, kh = lane >> 5) of the MFMA operand needs
     // k = 16 s + 8 kh + 0..7 of column n: two reads (k-rows +0..3, +4..7).  Row 16 s + 8 kh + 4 t + q has row & 3 = q
     // and (row >> 2) & 3 = (2 kh + t) & 3 in the swizzle.
-    const int tq = (lane >> 2) & 3, tp = lane & 3, tc0 = wn0 + 16 * ((lane >> 4) & 1);
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tc0 = wn0 + 16 * ((lane >> 4) & 1), ta0 = wm0 + 16 * ((lane >> 4) & 1);
     typedef s16x4 __attribute__((address_space(3)))* trp_t;
-    auto read_frags = [&](const unsigned char* As, int fb, int s, auto tr) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto read_frags = [&](const unsigned char* As, int fb, int s, auto tr, auto tra) {
         const unsigned char* Bs = As + A_SZ;
         const int off = ((2 * s + h) ^ swz) << 4;
+        if constexpr (decltype(tra)::value) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            af[fb][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * 128 + off);
+            for (int i = 0; i < TM; ++i) {
+                const int ch = ((ta0 + 32 * i) >> 3) + (tp >> 1);
+                const unsigned char* base = As + s * (16 * BM * 2) + 8 * (tp & 1);
+                const int o0 = (8 * h + tq) * (BM * 2) + ((ch ^ ((tq << 2) | ((2 * h) & 3))) << 4);
+                const int o1 = (8 * h + 4 + tq) * (BM * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o1));
+                af[fb][i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[fb][i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + r) * 128 + off);
+        }
         if constexpr (decltype(tr)::value) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -634,7 +667,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                 const int o1 = (8 * h + 4 + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o0));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o1));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
                 const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 bf[fb][j] = __builtin_bit_cast(bf16x8, both);
             }
@@ -653,8 +685,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     JB_STAMP(1);
-    auto k_loop = [&](auto tr) {
-    read_frags(smem, 0, 0, tr);
+    auto k_loop = [&](auto tr, auto tra) {
+    read_frags(smem, 0, 0, tr, tra);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char* As = smem + cur * T_SZ;
@@ -668,7 +700,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s & 1][0], af[s & 1][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < BK / 16) {
-                read_frags(As, (s + 1) & 1, s + 1, tr);
+                read_frags(As, (s + 1) & 1, s + 1, tr, tra);
             } else if (kt + 1 < nk) {
                 // tile kt+1 becomes visible and buffer `cur` free (every wave holds its last fragments of tile kt in
                 // registers: lgkmcnt(0)); tile kt+NB goes into it and the first fragments of tile kt+1 are fetched
@@ -678,7 +710,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (kt + NB < nk) stage(cur, kt + NB);
-                read_frags(smem + nxt * T_SZ, 0, 0, tr);
+                read_frags(smem + nxt * T_SZ, 0, 0, tr, tra);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -691,7 +723,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
         cur = nxt;
     }
     };
-    if (b_tr) k_loop(std::true_type{}); else k_loop(std::false_type{});
+    if (a_tr) k_loop(std::true_type{}, std::true_type{});            // dW on the row-major activations / gradients
+    else if (b_tr) k_loop(std::true_type{}, std::false_type{});      // dX on the weights as stored
+    else k_loop(std::false_type{}, std::false_type{});
     __syncthreads();
     JB_STAMP(2);
 
@@ -805,7 +839,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
-        if (s.b_tr) return jamie_fail(-1, "%s: b_tr needs a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
+        if (s.b_tr || s.a_tr) return jamie_fail(-1, "%s: a_tr / b_tr need a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         if (s.partial && s.epi == JAMIE_EPI_STORE)
             return jamie_fail(-1, "%s: sum-of-squares partials of a plain store need a large-tile configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         d.a_bytes = (unsigned)(((long long)(s.M - 1) * s.lda + s.K) * 2);
@@ -843,7 +877,10 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
-        d.b_tr = s.b_tr;
+        d.b_tr = s.b_tr; d.a_tr = s.a_tr;
+        if (s.a_tr && !(V2 && BM == 128 && BN == 128 && s.b_tr))
+            return jamie_fail(-1, "%s: a_tr (A stored [K, M]) needs b_tr and a 128 x 128 large-tile configuration (24, 25) [%lld %lld]",
+                              "jamie_gemm_bf16", BM, BN);
         if (s.partial && s.epi == JAMIE_EPI_STORE && (!V2 || d.splitk != 1))
             return jamie_fail(-1, "%s: sum-of-squares partials of a plain store need a large-tile configuration and splitk == 1 [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);
@@ -860,10 +897,21 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
                          (!s.bias || (uintptr_t)s.bias % 16 == 0) &&
                          (s.epi != JAMIE_EPI_MSE || (s.aux_ld % 4 == 0 && (uintptr_t)s.aux0 % 16 == 0));
         }
+        bool trm = false;
+        for (int i = 0; i < count; ++i) trm = trm || pr[i].a_tr || pr[i].b_tr;
+        if constexpr (BN == 128) {
+            if (trm) {
+                if (big)
+                    hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 1, NB, 1>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+                else
+                    hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 0, NB, 1>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+                return jamie_launch_status("jamie_gemm_bf16");
+            }
+        }
         if (big)
-            hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+            hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 1, NB, 0>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
         else
-            hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 0, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
+            hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 0, NB, 0>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
         return jamie_launch_status("jamie_gemm_bf16");
     }
     if (big)
@@ -891,12 +939,13 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         const jamie_gemm_problem& s = pr[i];
         JAMIE_ARG(s.A && s.B && s.C, "null operand");
         JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
-        JAMIE_ARG(s.ldc >= s.N && s.lda >= s.K && s.ldb >= (s.b_tr ? s.N : s.K), "leading dimensions");
+        JAMIE_ARG(s.ldc >= s.N && s.lda >= (s.a_tr ? s.M : s.K) && s.ldb >= (s.b_tr ? s.N : s.K), "leading dimensions");
+        JAMIE_ARG(!s.a_tr || (s.M % 8 == 0 && s.M >= 8), "a_tr: M must be a multiple of 8");
         if (s.K < min_k) min_k = s.K;
         JAMIE_ARG(s.K % 8 == 0 && s.lda % 8 == 0 && s.ldb % 8 == 0, "bf16 operands need K, lda, ldb multiples of 8");
         JAMIE_ARG(!s.b_tr || (s.N % 8 == 0 && s.N >= 8 && s.epi == JAMIE_EPI_STORE), "b_tr: N must be a multiple of 8, plain store epilogue");
         JAMIE_ARG(((uintptr_t)s.A % 16) == 0 && ((uintptr_t)s.B % 16) == 0, "bf16 operands must be 16-byte aligned");
-        JAMIE_ARG(((long long)(s.M - 1) * s.lda + s.K) * 2 < 0xFFFFFFF0LL &&
+        JAMIE_ARG((s.a_tr ? ((long long)(s.K - 1) * s.lda + s.M) : ((long long)(s.M - 1) * s.lda + s.K)) * 2 < 0xFFFFFFF0LL &&
                       (s.b_tr ? ((long long)(s.K - 1) * s.ldb + s.N) : ((long long)(s.N - 1) * s.ldb + s.K)) * 2 < 0xFFFFFFF0LL,
                   "operands must stay below 4 GiB");
         JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.epi == JAMIE_EPI_MSE, "bf16 GEMM epilogues: STORE, MSE");

@@ -141,6 +141,15 @@ class TrainEngine:
                                   ('d_a1', [(2 * d, d) for d in self.dims], True)):
                 self.gcfg[key], plan_sk[key] = (plan_bf16_bwd if (bwd and grouped) else plan_bf16_rows)(B, shp)
             self.gcfg['dw'] = BF16_CFG_DW if _big_enough(B, [(d, d) for d in self.dims]) else -1
+        # dW = dy^T a: the 128 x 128 large-tile kernel reads dy [B, out] and a [B, in] as the layers wrote them (a_tr + b_tr),
+        # so only operands of the launches that do not take that kernel (skinny head / latent layers, small models) still
+        # need a transposed [features, B] copy
+        self.need_T = set()
+        if self.bf16:
+            for dy_key, a_key, lin in (('dxhat', 'e2', 'dec2'), ('de2', 'e1', 'dec1'), ('de1', 'comb', 'dec0'),
+                                       ('dml', 'a2', 'head'), ('da2', 'a1', 'enc1'), ('da1', 'x', 'enc0')):
+                if not self._dw_tr(lin):
+                    self.need_T.update((dy_key, a_key))
         for i, d in enumerate(self.dims):
             w = {}
             sk = {'enc0': choose_splitk(B, 2 * d, d), 'enc1': choose_splitk(B, d, 2 * d),
@@ -372,7 +381,7 @@ class TrainEngine:
         for w in self.ws:
             src = w[key]
             src2 = src[0] if src.dim() == 3 else src
-            probs.append(nv.cast_problem(src2, w[key + '_bf'], w[key + '_T']))
+            probs.append(nv.cast_problem(src2, w[key + '_bf'], w[key + '_T'] if key in self.need_T else None))
         nv.cast_transpose(probs)
 
     # ---- pieces ----
@@ -394,7 +403,8 @@ class TrainEngine:
             pr.out, pr.mask = nv.ptr(w[out_key]), nv.ptr(self._mask(noise, kind, i, j))
             pr.B, pr.N, pr.rng_stream = self.B, h.shape[2], stream_base + 8 * i
             if self.fuse_bf16:      # bf16 + transposed bf16 copies straight from the strip; no fp32 activation
-                pr.out, pr.out_bf16, pr.outT_bf16 = None, nv.ptr(w[out_key + '_bf']), nv.ptr(w[out_key + '_T'])
+                pr.out, pr.out_bf16 = None, nv.ptr(w[out_key + '_bf'])
+                pr.outT_bf16 = nv.ptr(w[out_key + '_T']) if out_key in self.need_T else None
             probs.append(pr)
         nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE)
 
@@ -412,7 +422,8 @@ class TrainEngine:
             pr.mask = nv.ptr(self._mask(noise, kind, i, j))
             pr.B, pr.N, pr.rng_stream, pr.accumulate = self.B, h.shape[2], stream_base + 8 * i, int(self.accumulate)
             if self.fuse_bf16:
-                pr.dh_bf16, pr.dhT_bf16, pr.skip_f32 = nv.ptr(w[da_key + '_bf']), nv.ptr(w[da_key + '_T']), 1
+                pr.dh_bf16, pr.skip_f32 = nv.ptr(w[da_key + '_bf']), 1
+                pr.dhT_bf16 = nv.ptr(w[da_key + '_T']) if da_key in self.need_T else None
             probs.append(pr)
         nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE)
 
@@ -461,16 +472,33 @@ class TrainEngine:
             w = self.ws[i]
             dy, a, dW = w[dy_key], w[a_key], self.g[f'm{i}.{lin}.W']
             nout, nin = dW.shape
-            if self.bf16:     # dW = dy^T a  ==  (dy^T) (a^T)^T, both [features, B] copies are K(=batch)-contiguous
-                probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B,
-                                             nin, accumulate=self.accumulate, partial=self._dw_partial(i, lin)))
+            if self.bf16:
+                probs.append(self._dw_problem(i, dy_key, a_key, lin))
             else:
                 probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
         if self.bf16:
-            big = all(min(self.g[f'm{i}.{lin}.W'].shape) >= 256 for i in range(self.M))
-            nv.gemm_bf16(probs, self.gcfg['dw'] if big else -1)
+            nv.gemm_bf16(probs, self._dw_cfg(lin))
         else:
             nv.gemm(probs, nv.TN)
+
+    def _dw_cfg(self, lin):
+        """Tile configuration of the dW launch of layer `lin` (-1: the library default for small / skinny problems)."""
+        big = all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 256 for i in range(self.M))
+        return self.gcfg.get('dw', -1) if big else -1
+
+    def _dw_tr(self, lin):
+        return self.bf16 and self._dw_cfg(lin) in (24, 25)
+
+    def _dw_problem(self, i, dy_key, a_key, lin):
+        w = self.ws[i]
+        dW = self.g[f'm{i}.{lin}.W']
+        nout, nin = dW.shape
+        if self._dw_tr(lin):      # dy [B, out], a [B, in] row-major as produced: no transposed copies
+            return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], dW, nout, nin, self.B, nout, nin, nin,
+                                   accumulate=self.accumulate, partial=self._dw_partial(i, lin), a_tr=True, b_tr=True)
+        # (dy^T) (a^T)^T on the [features, B] copies, K (= batch) contiguous
+        return nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
+                               accumulate=self.accumulate, partial=self._dw_partial(i, lin))
 
     def _dw_partial(self, i, lin):
         """Slice of `norm_partials` the dW launch of m{i}.{lin} fills (None: the separate norm kernel reads the gradient)."""
@@ -499,11 +527,7 @@ class TrainEngine:
                 probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
                                              nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         for i, d in enumerate(self.dims):
-            w = self.ws[i]
-            dW = self.g[f'm{i}.{lin}.W']
-            nout, nin = dW.shape
-            probs.append(nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
-                                         accumulate=self.accumulate, partial=self._dw_partial(i, lin)))
+            probs.append(self._dw_problem(i, dy_key, a_key, lin))
         nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
@@ -562,8 +586,8 @@ class TrainEngine:
     def load_batch(self, data, idx):
         """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors."""
         if self.bf16:      # gather + bf16 copy + transposed bf16 copy of the batch in one launch
-            nv.cast_transpose([nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'], rows=idx[i],
-                                               dst32=self.ws[i]['x']) for i in range(self.M)])
+            nv.cast_transpose([nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'] if 'x' in self.need_T else None,
+                                               rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)])
             return
         for i in range(self.M):
             nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
@@ -646,7 +670,7 @@ class TrainEngine:
             probs, off = [], 0
             for i, d in enumerate(self.dims):
                 w = self.ws[i]
-                probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w['dxhat_bf'], w['dxhat_T'],
+                probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w['dxhat_bf'], w['dxhat_T'] if 'dxhat' in self.need_T else None,
                                             partial=self.rec_partials[off:off + self.rec_tiles[i]],
                                             scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
                 off += self.rec_tiles[i]

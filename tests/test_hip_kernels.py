@@ -548,6 +548,33 @@ def test_gemm_bf16_b_stored_k_by_n(nv, M, N, K, cfg):
         close(o2, a2.double() @ w2.double().t(), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (264, 520, 512), (2000, 1000, 512), (136, 72, 200), (8, 8, 24)])
+@pytest.mark.parametrize('cfg', [24, 25])
+def test_gemm_bf16_both_operands_stored_k_major(nv, M, N, K, cfg):
+    """a_tr + b_tr: C [M,N] = A^T B for A [K,M], B [K,N] row-major (dW = dy^T a on dy [B,out], a [B,in] as the layers
+    wrote them), with the per-tile sum-of-squares partials the gradient-norm kernel consumes; accumulate; grouped with
+    a dX (b_tr) problem as the backward launch issues them."""
+    import math
+    g = torch.Generator().manual_seed(M + N + K + cfg)
+    a, b = _bf16(torch.randn(K, M, generator=g)), _bf16(torch.randn(K, N, generator=g))
+    out = torch.full((M, N), float('nan'), device='cuda')
+    part = torch.full((math.ceil(M / 128) * math.ceil(N / 128),), float('nan'), device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(a), dev(b), out, M, N, K, M, N, N, a_tr=True, b_tr=True, partial=part)], cfg)
+    ref = a.double().t() @ b.double()
+    close(out, ref, rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)
+    close(part.sum(), (out.double() ** 2).sum().cpu(), rtol=1e-5, atol=0)
+    ai = _bf16(torch.randint(-4, 5, (K, M), generator=g).float())
+    bi = _bf16((torch.arange(K * N, dtype=torch.float32).reshape(K, N) % 13) - 6)
+    out2 = torch.ones(M, N, device='cuda')
+    w = _bf16(torch.randn(K, 136, generator=g))
+    dy = _bf16(torch.randn(72, K, generator=g))
+    o3 = torch.zeros(72, 136, device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(dev(dy), dev(w), o3, 72, 136, K, K, 136, 136, b_tr=True),
+                  nv.gemm_problem(dev(ai), dev(bi), out2, M, N, K, M, N, N, a_tr=True, b_tr=True, accumulate=True)], cfg)
+    assert torch.equal(out2.cpu(), ai.float().t() @ bi.float() + 1.0)
+    close(o3, dy.double() @ w.double(), rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)
+
+
 def test_gemm_bf16_b_tr_needs_a_128_column_large_tile(nv):
     a, w = dev(_bf16(torch.randn(64, 64))), dev(_bf16(torch.randn(64, 64)))
     out = torch.zeros(64, 64, device='cuda')
