@@ -391,6 +391,228 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the NT layout (both operands K-contiguous: the forward Linear products and the eval path).
+// The counters on the register-staged kernel above (tools/pmc_gemm_f32.sh) show the matrix pipe busy 61 % of the launch
+// at full clock, and its ablations charge 20 % of the time to the VGPR -> LDS staging writes (16 ds_write_b128 per
+// workgroup and k-step) and 6 % to exposed global loads.  Here whole k-tiles of 32 floats (128-byte rows) go
+// global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB = 8 rows per wave-instruction: no staging registers, no
+// ds_write), NB buffers deep, with hand-counted `s_waitcnt vmcnt(N)` and a raw `s_barrier` (a __syncthreads() would
+// drain vmcnt(0)).  The LDS image is lane-linear, so rows cannot be padded: 16-byte chunk c of row r sits at chunk
+// c ^ ((r >> 1) & 7) -- applied to the SOURCE address of the DMA and to the fragment read -- which keeps the
+// ds_read_b128 of the 32 rows of an MFMA operand conflict-free (the image of the bf16 kernel, gemm_bf16.hip).
+// Rows beyond M / N re-read the last valid row (never stored); a partial last k-tile goes through registers, masked.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int TAG, int NB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g) {
+    constexpr int BK = 32, NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_SZ = BM * 128, B_SZ = BN * 128;      // bytes, unpadded 128-byte rows
+    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB pieces per wave
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;    // 16-byte chunks per thread (register tail path)
+    constexpr int GL = PA + PB;
+    static_assert(PA >= 1 && PB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+    static_assert(GL * (NB - 1) <= 60 && NB >= 2 && NB <= 4, "vmcnt immediate");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * (A_SZ + B_SZ)];
+    float* red = reinterpret_cast<float*>(smem);
+
+    JF_STAMP(0);
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    int pi = 0, t = 0, rot = 0;
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+        if (i < g.count) {
+            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
+            const int j = (xcd - rot) & 7;
+            const int cp = qp + (j < rp ? 1 : 0);
+            if (slot >= 0 && slot < cp) {
+                pi = i;
+                t = j * qp + min(j, rp) + slot;
+                slot = -1;
+            } else if (slot >= 0) {
+                slot -= cp;
+            }
+            rot = (rot + rp) & 7;
+        }
+    }
+    const GemmDev& P = g.p[pi];
+    const int tm_i = t % P.tiles_m;
+    const int tn_i = (t / P.tiles_m) % P.tiles_n;
+    const int ks = t / (P.tiles_m * P.tiles_n);
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int kbeg = ks * P.kchunk;
+    const int kend = min(P.K, kbeg + P.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nfull = (kend - kbeg) / BK;
+    JF_STAMPV(4, pi * 1000 + nk);
+    JF_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WN) * (TM * 32), wn0 = (wid % WN) * (TN * 32);
+    const int r = lane & 31, h = lane >> 5;
+    const int lrow = lane >> 3, pch = lane & 7;
+    const float* a_src[PA]; const float* b_src[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = 8 * (wid + NW * i) + lrow;
+        a_src[i] = P.A + (long long)min(m0 + row, P.M - 1) * P.lda + ((pch ^ ((row >> 1) & 7)) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = 8 * (wid + NW * i) + lrow;
+        b_src[i] = P.B + (long long)min(n0 + row, P.N - 1) * P.ldb + ((pch ^ ((row >> 1) & 7)) * 4);
+    }
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto tail_ld = [&](const float* p, int k) {      // 4 floats of a row from column k, zero beyond kend
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 3 < kend) v = *reinterpret_cast<const float4*>(p + k);
+        else {
+            if (k < kend) v.x = p[k];
+            if (k + 1 < kend) v.y = p[k + 1];
+            if (k + 2 < kend) v.z = p[k + 2];
+        }
+        return v;
+    };
+    auto stage = [&](int buf, int kt) {
+        unsigned char* As = smem + buf * (A_SZ + B_SZ);
+        unsigned char* Bs = As + A_SZ;
+        const int k0 = kbeg + kt * BK;
+        if (kt < nfull) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int f = tid + j * NT, row = f >> 3, c = f & 7;
+                const float4 v = tail_ld(P.A + (long long)min(m0 + row, P.M - 1) * P.lda, k0 + c * 4);
+                *reinterpret_cast<float4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const int f = tid + j * NT, row = f >> 3, c = f & 7;
+                const float4 v = tail_ld(P.B + (long long)min(n0 + row, P.N - 1) * P.ldb, k0 + c * 4);
+                *reinterpret_cast<float4*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int swz = (r >> 1) & 7;
+    // prologue: tiles 0 .. NB-2 in flight
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u)
+        if (u < nk) stage(u, u);
+    JF_STAMP(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // my pieces of tile kt have landed: DMA tiles younger than kt already issued = kt+1 .. kt+NB-2 (full tiles only)
+        const int younger = max(0, min(kt + NB - 2, nfull - 1) - kt);
+        if (kt >= nfull || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 3 ? 2 * GL : 0) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // tile kt visible to all; buffer (kt-1) % NB free
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NB - 1 < nk) stage((kt + NB - 1) % NB, kt + NB - 1);
+        const unsigned char* As = smem + (kt % NB) * (A_SZ + B_SZ);
+        const unsigned char* Bs = As + A_SZ;
+        float4 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int buf, int gk) {
+            const int off = ((2 * gk + h) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const float4*>(As + (wm0 + i * 32 + r) * 128 + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const float4*>(Bs + (wn0 + j * 32 + r) * 128 + off);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            const float* a0 = reinterpret_cast<const float*>(&af[gk & 1][0]);
+            const float* b0 = reinterpret_cast<const float*>(&bf[gk & 1][0]);
+            // the prefetch goes AFTER the first MFMA of the group (hipcc puts an uncounted lgkmcnt(0) before an MFMA that
+            // follows a pending LDS-DMA: the wait then only covers reads that have had a whole group to land)
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gk + 1 < BK / 8) read_frags((gk + 1) & 1, gk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (s4 + i + j > 0)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(reinterpret_cast<const float*>(&af[gk & 1][i])[s4],
+                                                                             reinterpret_cast<const float*>(&bf[gk & 1][j])[s4],
+                                                                             acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    JF_STAMP(2);
+
+    // ---- epilogue, as gemm_f32_kernel.  C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+    float* Cout = P.C + (long long)ks * P.slab_stride;
+    const bool add_bias = (P.bias != nullptr) && ks == 0;
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + r;
+        if (n >= P.N) continue;
+        const float bv = add_bias ? P.bias[n] : 0.f;
+        float e_mean = 0.f, e_scale = 1.f, e_shift = 0.f;
+        if (P.epi == JAMIE_EPI_BN_EVAL) {
+            e_mean = P.aux0[n];
+            e_scale = rsqrtf(P.aux1[n] + P.eps) * P.aux2[n];
+            e_shift = P.aux3[n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= P.M) continue;
+                float v = acc[i][j][e] + bv;
+                float* cp = Cout + (long long)m * P.ldc + n;
+                if (P.epi == JAMIE_EPI_STORE) {
+                    if (P.accumulate) v += *cp;
+                    *cp = v;
+                } else if (P.epi == JAMIE_EPI_MSE) {
+                    const float d = v - P.aux0[(long long)m * P.aux_ld + n];
+                    local += d * d;
+                    *cp = d * P.scale;
+                } else {  // JAMIE_EPI_BN_EVAL
+                    const float y = (v - e_mean) * e_scale + e_shift;
+                    *cp = y > 0.f ? y : P.slope * y;
+                }
+            }
+        }
+    }
+    if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+#ifdef JAMIE_GEMMB_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    JF_STAMP(3);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -445,6 +667,49 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     return jamie_launch_status("jamie_gemm_f32");
 }
 
+// NT launches through the LDS-DMA kernel when every problem qualifies (16-byte aligned operands, lda / ldb multiples
+// of 4, no row gather, < 4 GiB); otherwise the register-staged kernel with the same 64x64 tile.
+template <int NB>
+static int launch_dma_nt(const jamie_gemm_problem* pr, int count, hipStream_t st) {
+    constexpr int BM = 64, BN = 64, BK = 32;
+    GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.count = count;
+    int tiles = 0;
+    bool ok = true, big = true;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        GemmDev& d = g.p[i];
+        d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias;
+        d.aux0 = s.aux0; d.aux1 = s.aux1; d.aux2 = s.aux2; d.aux3 = s.aux3;
+        d.partial = s.partial; d.a_rows = s.a_rows;
+        d.slab_stride = s.slab_stride;
+        d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.aux_ld = s.aux_ld;
+        d.splitk = s.splitk < 1 ? 1 : s.splitk;
+        int kc = (s.K + d.splitk - 1) / d.splitk;
+        kc = ((kc + BK - 1) / BK) * BK;
+        d.kchunk = kc;
+        d.tiles_m = (s.M + BM - 1) / BM;
+        d.tiles_n = (s.N + BN - 1) / BN;
+        d.tile_begin = tiles;
+        d.epi = s.epi; d.accumulate = s.accumulate;
+        d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
+        d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        tiles += d.n_tiles;
+        if ((s.lda % 4) || (s.ldb % 4) || ((uintptr_t)s.A % 16) || ((uintptr_t)s.B % 16) || s.a_rows ||
+            ((long long)(s.M - 1) * s.lda + s.K) * 4 >= 0xFFFFFFF0LL || ((long long)(s.N - 1) * s.ldb + s.K) * 4 >= 0xFFFFFFF0LL)
+            ok = false;
+        if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
+    }
+    if (!ok) return launch_cfg<64, 64, 32, 2, 2, true, true>(pr, count, st);
+    if (tiles == 0) return 0;
+    if (big)
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, 2, 2, 1, NB>), dim3(tiles), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, 2, 2, 0, NB>), dim3(tiles), dim3(256), 0, st, g);
+    return jamie_launch_status("jamie_gemm_f32");
+}
+
 // Tile configurations (BM, BN, BK, WM, WN).  cfg < 0 selects by shape (see pick_cfg).
 //   0: 64x128x32, 4 waves of 32x64   1: 64x64x32, 4 waves of 32x32    2: 128x128x16, 4 waves of 64x64
 //   3: 128x64x32, 4 waves of 64x32   4: 128x128x32, 8 waves of 64x32  5: 32x128x32, 4 waves of 32x32
@@ -458,6 +723,12 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
         case 4: return launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC>(pr, count, st);
         case 5: return launch_cfg<32, 128, 32, 1, 4, A_KC, B_KC>(pr, count, st);
         case 6: return launch_cfg<64, 64, 64, 2, 2, A_KC, B_KC>(pr, count, st);
+        case 7: case 8: case 9:      // 64x64x32 LDS-DMA, 3 / 2 / 4 buffers (NT only; other layouts: the register-staged 64x64)
+            if constexpr (A_KC && B_KC) {
+                return cfg == 7 ? launch_dma_nt<3>(pr, count, st) : cfg == 8 ? launch_dma_nt<2>(pr, count, st) : launch_dma_nt<4>(pr, count, st);
+            } else {
+                return launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC>(pr, count, st);
+            }
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
 }
@@ -507,9 +778,9 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[7][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}};
+    static const int T[10][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 6 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 9 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

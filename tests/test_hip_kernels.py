@@ -57,6 +57,56 @@ def test_gemm_layouts(nv, layout, M, N, K):
     close(out, ref, rtol=1e-5, atol=2e-6 * scale)
 
 
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES + [(512, 2000, 1000), (130, 72, 1002), (64, 64, 20)])
+@pytest.mark.parametrize('cfg', [7, 8, 9])
+def test_gemm_f32_lds_dma_nt(nv, M, N, K, cfg):
+    """The LDS-DMA NT kernel (64x64x32, 3 / 2 / 4 buffers): exact-fp32 products against fp64, bit-exact on small integers,
+    ragged M / N, partial k-tiles, K % 4 != 0 falls back to the register-staged kernel, split-K slabs, MSE and
+    eval-BatchNorm epilogues, grouped problems."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + cfg)
+    a, w, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    out = torch.full((M, N), float('nan'), device='cuda')
+    nv.gemm([nv.gemm_problem(dev(a), dev(w), out, M, N, K, K, K, N, bias=dev(bias))], nv.NT, cfg)
+    close(out, a.double() @ w.double().t() + bias.double(), rtol=1e-5, atol=4e-6 * float(np.sqrt(K)))   # 1M outputs: 4.5 sigma
+    ai = torch.randint(-4, 5, (M, K), generator=g).float()
+    wi = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 13) - 6
+    out2 = torch.ones(M, N, device='cuda')
+    nv.gemm([nv.gemm_problem(dev(ai), dev(wi), out2, M, N, K, K, K, N, accumulate=True)], nv.NT, cfg)
+    assert torch.equal(out2.cpu(), ai @ wi.t() + 1.0)
+    if K >= 128:
+        slabs = torch.full((3, M, N), float('nan'), device='cuda')
+        x1, w1 = torch.randn(40, 66 * 4, generator=g), torch.randn(72, 66 * 4, generator=g)
+        o1 = torch.zeros(40, 72, device='cuda')
+        nv.gemm([nv.gemm_problem(dev(a), dev(w), slabs, M, N, K, K, K, N, bias=dev(bias), splitk=3, slab_stride=M * N),
+                 nv.gemm_problem(dev(x1), dev(w1), o1, 40, 72, 264, 264, 264, 72)], nv.NT, cfg)
+        close(slabs.sum(0), a.double() @ w.double().t() + bias.double(), rtol=1e-5, atol=1e-4)
+        close(o1, x1.double() @ w1.double().t(), rtol=1e-5, atol=5e-5)
+
+
+def test_gemm_f32_lds_dma_epilogues(nv):
+    import math
+    B, d, K = 100, 150, 80
+    g = torch.Generator().manual_seed(9)
+    e2, W, b, X = (torch.randn(B, K, generator=g), torch.randn(d, K, generator=g), torch.randn(d, generator=g),
+                   torch.randn(B, d, generator=g))
+    part = torch.zeros(math.ceil(B / 64) * math.ceil(d / 64), device='cuda')
+    out = torch.zeros(B, d, device='cuda')
+    scale = 2.0 / (B * d)
+    nv.gemm([nv.gemm_problem(dev(e2), dev(W), out, B, d, K, K, K, d, bias=dev(b), epi=nv.EPI_MSE,
+                             aux=(dev(X), None, None, None), aux_ld=d, partial=part, scale=scale, pscale=1.0 / (B * d))], nv.NT, 7)
+    diff = e2.double() @ W.double().t() + b.double() - X.double()
+    close(out, diff * scale, rtol=1e-5, atol=1e-7)
+    close(part.sum(), (diff ** 2).mean(), rtol=1e-5, atol=0)
+    rm, rv = torch.randn(d, generator=g), torch.rand(d, generator=g) + .5
+    ga, be = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    nv.gemm([nv.gemm_problem(dev(e2), dev(W), out, B, d, K, K, K, d, bias=dev(b), epi=nv.EPI_BN_EVAL,
+                             aux=(dev(rm), dev(rv), dev(ga), dev(be)), slope=0.01, eps=1e-5)], nv.NT, 7)
+    h = torch.nn.functional.linear(e2.double(), W.double(), b.double())
+    ref = torch.nn.functional.leaky_relu(
+        torch.nn.functional.batch_norm(h, rm.double(), rv.double(), ga.double(), be.double(), False, 0.1, 1e-5), 0.01)
+    close(out, ref, rtol=1e-4, atol=1e-5)
+
+
 def test_gemm_identity_asymmetric(nv):
     """A = I with an asymmetric B catches a swapped C/D register map (cdna_hip_programming.md §3)."""
     n = 96

@@ -30,7 +30,10 @@ cases = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], [(1, 1), (2, 1), (4, 2)
          ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], [(2, 3), (4, 2), (2, 1), (8, 4)]),
          ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], [(2, 3), (4, 2), (2, 1)]),
          ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], [(1, 1), (2, 1), (4, 2)])]
+cfgs = [int(c) for c in os.environ.get('CFGS', '-1').split(',')]
 for name, layout, shapes, skl in cases:
-    for sks in skl:
-        us, tf = run(layout, shapes, sks)
-        print(f'{name:12s} sk {sks}: {us:8.1f} us {tf:7.1f} TFLOP/s', flush=True)
+    for cfg in cfgs:
+        if cfg >= 7 and layout != nv.NT: continue
+        for sks in skl:
+            us, tf = run(layout, shapes, sks, cfg)
+            print(f'{name:12s} cfg {cfg:2d} sk {sks}: {us:8.1f} us {tf:7.1f} TFLOP/s', flush=True)
