@@ -238,6 +238,12 @@ int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,
                     void* p_bf16 /* optional bf16 copy of the updated parameters (same layout) or NULL */, void* stream);
+/* The same two steps on a bf16 gradient: the reduced gradient of the data-parallel exchange is left in its bf16 message
+ * buffer (same offsets as the flat fp32 gradient) and read from there -- no fp32 copy-back pass, 2 instead of 4 bytes of
+ * gradient per parameter in both kernels. */
+int jamie_grad_sqnorm_bf16(const void* g_bf16, long long n, float* partials, int n_partials, uint64_t* state, void* stream);
+int jamie_clip_adam_g16(float* p, const void* g_bf16, float* m, float* v, long long n, const float* partials,
+                        int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batch assembly (jamie.py:552-604).

@@ -128,6 +128,9 @@ EXPORTS = {
     'jamie_latent_m_bwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p]),
     'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
     'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_grad_sqnorm_bf16': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'jamie_clip_adam_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'jamie_grad_sqnorm_ranges': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p]),
     'jamie_sqnorm_range_blocks': (C.c_int, [C.c_void_p, C.c_int]),
@@ -378,11 +381,14 @@ def optim_blocks(n):
 
 
 def grad_sqnorm(g, partials, state):
-    _call('jamie_grad_sqnorm', ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream())
+    name = 'jamie_grad_sqnorm_bf16' if g.dtype == torch.bfloat16 else 'jamie_grad_sqnorm'
+    _call(name, ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream())
 
 
 def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None):
-    _call('jamie_clip_adam', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),
+    """`g`: the fp32 gradient, or (a bf16 tensor) the reduced gradient left in its bf16 message buffer."""
+    name = 'jamie_clip_adam_g16' if g.dtype == torch.bfloat16 else 'jamie_clip_adam'
+    _call(name, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),
           ptr(hyper), ptr(state), ptr(p_bf16), _stream())
 
 

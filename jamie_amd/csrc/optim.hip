@@ -30,12 +30,40 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
     }
 }
 
+// bf16 gradient (the reduced gradient of the data-parallel exchange, left in its bf16 message buffer): 8 values per lane
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+__global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned short* __restrict__ g, long long n,
+                                                               float* partials, uint64_t* state) {
+    __shared__ float red[4];
+    const long long n8 = n >> 3;
+    const uint4* g8 = reinterpret_cast<const uint4*>(g);
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const uint4 u = g8[i];
+        const float a0 = bf16_lo(u.x), a1 = bf16_hi(u.x), a2 = bf16_lo(u.y), a3 = bf16_hi(u.y);
+        const float a4 = bf16_lo(u.z), a5 = bf16_hi(u.z), a6 = bf16_lo(u.w), a7 = bf16_hi(u.w);
+        acc += (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3) + (a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7);
+    }
+    if (blockIdx.x == 0) {
+        const long long i = (n8 << 3) + threadIdx.x;
+        if (i < n) { const float a = bf16_lo(g[i]); acc += a * a; }
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t;
+        if (blockIdx.x == 0 && state) state[1] += 1;
+    }
+}
+
 template <int U>
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* partials, int n_partials,
                                                         const float* hyper, const uint64_t* state,
-                                                        unsigned short* __restrict__ p_bf16) {
+                                                        unsigned short* __restrict__ p_bf16,
+                                                        const unsigned short* __restrict__ g_bf16) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
@@ -67,7 +95,15 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long i = i0 + u * 256;
-            if (i < n4) { pp[u] = p4[i]; mm[u] = m4[i]; vv[u] = v4[i]; gg[u] = g4[i]; }
+            if (i < n4) {
+                pp[u] = p4[i]; mm[u] = m4[i]; vv[u] = v4[i];
+                if (g_bf16) {      // reduced gradient read straight from the bf16 message buffer (no fp32 copy-back pass)
+                    const uint2 q = reinterpret_cast<const uint2*>(g_bf16)[i];
+                    gg[u] = make_float4(bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y));
+                } else {
+                    gg[u] = g4[i];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -88,7 +124,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     if (blockIdx.x == 0) {
         const long long i = (n4 << 2) + threadIdx.x;
         if (i < n) {
-            upd(p[i], g[i], m[i], v[i]);
+            upd(p[i], g_bf16 ? bf16_lo(g_bf16[i]) : g[i], m[i], v[i]);
             if (p_bf16) p_bf16[i] = __builtin_bit_cast(unsigned short, (__bf16)p[i]);
         }
     }
@@ -163,11 +199,11 @@ extern "C" int jamie_grad_sqnorm(const float* g, long long n, float* partials, i
     return jamie_launch_status("jamie_grad_sqnorm");
 }
 
-extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
-                               int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
-    JAMIE_ARG(p && g && m && v && partials && hyper && state && n > 0, "null pointer / empty");
+static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m, float* v, long long n, const float* partials,
+                          int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
+    JAMIE_ARG(p && (g || g_bf16) && m && v && partials && hyper && state && n > 0, "null pointer / empty");
     JAMIE_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
-                  ((uintptr_t)v % 16) == 0, "buffers must be 16-byte aligned");
+                  ((uintptr_t)v % 16) == 0 && ((uintptr_t)g_bf16 % 8) == 0, "buffers must be 16-byte aligned (bf16 gradient: 8)");
     JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
     JAMIE_ARG(p_bf16 == nullptr || ((uintptr_t)p_bf16 % 8) == 0, "p_bf16 must be 8-byte aligned");
     // one workgroup per CU, two float4 per thread and array in flight: fewer, longer streams keep more DRAM pages open
@@ -175,8 +211,31 @@ extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, lon
     long long need = (n / 4 + 511) / 512;
     const int grid = (int)(need < 1 ? 1 : (need > 256 ? 256 : need));
     hipLaunchKernelGGL(clip_adam_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, partials,
-                       n_partials, hyper, state, (unsigned short*)p_bf16);
+                       n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16);
     return jamie_launch_status("jamie_clip_adam");
+}
+
+extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
+                               int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
+    JAMIE_ARG(g != nullptr, "null gradient");
+    return clip_adam_impl(p, g, nullptr, m, v, n, partials, n_partials, hyper, state, p_bf16, stream);
+}
+
+extern "C" int jamie_clip_adam_g16(float* p, const void* g_bf16, float* m, float* v, long long n, const float* partials,
+                                   int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
+    JAMIE_ARG(g_bf16 != nullptr, "null gradient");
+    return clip_adam_impl(p, nullptr, g_bf16, m, v, n, partials, n_partials, hyper, state, p_bf16, stream);
+}
+
+extern "C" int jamie_grad_sqnorm_bf16(const void* g_bf16, long long n, float* partials, int n_partials, uint64_t* state,
+                                      void* stream) {
+    JAMIE_ARG(g_bf16 && partials && n > 0, "null pointer / empty");
+    JAMIE_ARG(((uintptr_t)g_bf16 % 16) == 0, "g must be 16-byte aligned");
+    const int grid = grid_for(n);
+    JAMIE_ARG(n_partials == grid, "n_partials must equal jamie_optim_blocks(n)");
+    hipLaunchKernelGGL(grad_sqnorm_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g_bf16, n,
+                       partials, state);
+    return jamie_launch_status("jamie_grad_sqnorm_bf16");
 }
 
 extern "C" int jamie_optim_blocks(long long n) { return grid_for(n); }

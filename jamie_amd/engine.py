@@ -725,9 +725,15 @@ class TrainEngine:
         self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
 
-    def optimizer_step(self):
-        """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step)."""
-        if self._norm_ready:         # the dW launches of this backward pass wrote their tiles' sums of squares
+    def optimizer_step(self, g16=None):
+        """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step).
+        `g16`: the reduced gradient as a flat bf16 tensor with the layout of `self.grad` (data-parallel exchange with
+        bf16 messages); default: `self.grad`."""
+        grad = self.grad if g16 is None else g16
+        if g16 is not None:
+            norm = self.norm_partials[:self.n_norm]
+            nv.grad_sqnorm(grad, norm, self.state)
+        elif self._norm_ready:         # the dW launches of this backward pass wrote their tiles' sums of squares
             n_live = self.n_dw_partials + self.sq_ranges.blocks
             norm = self.norm_partials[:n_live]
             nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state)
@@ -736,7 +742,7 @@ class TrainEngine:
             nv.grad_sqnorm(self.grad, norm, self.state)
         self._norm_ready = False
         if not self.pipeline:
-            self._launch('adam', lambda: nv.clip_adam(self.m.flat, self.grad, self.exp_avg, self.exp_avg_sq,
+            self._launch('adam', lambda: nv.clip_adam(self.m.flat, grad, self.exp_avg, self.exp_avg_sq,
                                                        norm, self.hyper, self.state,
                                                        self.wbf_flat if self.bf16 else None))
             if self.bf16 and self.side_transposes:
@@ -763,7 +769,7 @@ class TrainEngine:
             regions = self.m.layout.regions
             for g, names in enumerate(self.PIPE_GROUPS):
                 lo, hi = regions[names[0]][0], regions[names[-1]][1]
-                self._launch('adam', lambda: nv.clip_adam(self.m.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi],
+                self._launch('adam', lambda: nv.clip_adam(self.m.flat[lo:hi], grad[lo:hi], self.exp_avg[lo:hi],
                                                            self.exp_avg_sq[lo:hi], norm, self.hyper,
                                                            self.state, self.wbf_flat[lo:hi] if self.bf16 else None))
                 if self.bf16:
@@ -778,11 +784,20 @@ class TrainEngine:
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
         `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
         self.forward_backward(corr, Fblk, noise, allreduce)
+        g16 = None
         if allreduce is not None:
-            fn = allreduce.finish if hasattr(allreduce, 'finish') else (lambda: allreduce(self.grad))
+            # bf16 messages: the reduced gradient stays in the exchange's bf16 buffer; norm and Adam read it there
+            in_place = (getattr(allreduce, 'comm_dtype', None) == torch.bfloat16 and getattr(allreduce, 'world', 1) > 1
+                        and self.grad.is_cuda)
+            if in_place:
+                fn = lambda: allreduce.finish(copy_back=False)     # noqa: E731
+            else:
+                fn = allreduce.finish if hasattr(allreduce, 'finish') else (lambda: allreduce(self.grad))
             nv.record_callable(fn)
             fn()
-        self.optimizer_step()
+            if in_place:
+                g16 = allreduce.comm
+        self.optimizer_step(g16)
 
     # ---- recorded launch plan: one foreign call per launch, no descriptor rebuilding (host cost ~3 us/launch) ----
     def make_plan(self, data, idx, n_rows, replace=False, allreduce=None):

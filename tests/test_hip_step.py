@@ -361,12 +361,27 @@ if mode == 'f32_buckets':
         eng.load_batch(data, idx)
         eng.step(None, None, None, ar)
 else:
+    init = model.flat.clone()
     eng = TrainEngine(model, 64, seed=1 + rank, world_size=world, compute_dtype='bf16')
     ar = jd.OverlappedGradAllReduce(min_bytes=16384, comm_dtype=torch.bfloat16)
     plan = eng.make_plan(data, idx[0], 512, False, ar)
     for s in range(4):
         eng.run_plan(plan)
     assert ar.comm is not None and ar.comm.dtype == torch.bfloat16 and not ar.works
+    # the step above leaves the reduced gradient in the bf16 message buffer (norm and Adam read it there); casting it
+    # back into the fp32 gradient first, as a caller of finish() + optimizer_step() does, is the same update up to the
+    # summation order of the norm (the clip coefficient's last bit)
+    model2 = edModelVar((96, 64), 8, device=dev)
+    model2.flat.copy_(init)
+    eng2 = TrainEngine(model2, 64, seed=1 + rank, world_size=world, compute_dtype='bf16')
+    ar2 = jd.OverlappedGradAllReduce(min_bytes=16384, comm_dtype=torch.bfloat16)
+    for s in range(5):
+        nv.sample_indices(idx[0], 512, 0, False, eng2.state, 200)
+        eng2.load_batch(data, [idx[0], idx[0]])
+        eng2.forward_backward(None, None, None, ar2)
+        ar2.finish()
+        eng2.optimizer_step()
+    assert torch.allclose(model.flat, model2.flat, rtol=1e-5, atol=1e-7), (model.flat - model2.flat).abs().max()
 flat = model.flat.clone()
 others = [torch.zeros_like(flat) for _ in range(world)]
 torch.distributed.all_gather(others, flat)
