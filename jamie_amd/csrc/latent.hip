@@ -26,6 +26,7 @@ struct LatDev {
     int cosine; int rng_stream;
     const float* dz_ext[2]; const float* dmu_ext[2]; const float* dlv_ext;
     unsigned short* comb_bf[2]; unsigned short* combT_bf[2]; unsigned short* dml_bf[2]; unsigned short* dmlT_bf[2];
+    int ident;      // corr == identity (NULL): corr z_j = z_j and the row / column sums are 1 -- no [B,B] x [B,L] launches
 };
 
 __device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
@@ -47,6 +48,8 @@ static LatDev to_dev(const jamie_latent* a) {
     d.fte = a->fte; d.dsigma = a->dsigma;
     d.rec_partials = a->rec_partials; d.n_rec_partials = a->n_rec_partials; d.losses = a->losses;
     d.cosine = a->cosine; d.rng_stream = a->rng_stream;
+    d.ident = a->corr == nullptr;
+    if (d.ident) { d.cz[0] = a->z[1]; d.cz[1] = a->z[0]; }      // corr z_1 = z_1, corr^T z_0 = z_0: read z itself
     for (int i = 0; i < 2; ++i) { d.dz_ext[i] = a->dz_ext[i]; d.dmu_ext[i] = a->dmu_ext[i]; }
     d.dlv_ext = a->dlv_ext;
     for (int i = 0; i < 2; ++i) {
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256) void latent_combine_kernel(LatDev a) {
         const int b = e / L;
         const float s0 = a.sigma[0], s1 = a.sigma[1];
         const float z0 = a.z[0][e], z1 = a.z[1][e];
-        const float c0 = (s0 * z0 + s1 * a.cz[0][e]) / (s0 + s1 * a.rsum[b]);
-        const float c1 = (s1 * z1 + s0 * a.cz[1][e]) / (s1 + s0 * a.qsum[b]);
+        const float c0 = (s0 * z0 + s1 * a.cz[0][e]) / (s0 + s1 * (a.ident ? 1.f : a.rsum[b]));
+        const float c1 = (s1 * z1 + s0 * a.cz[1][e]) / (s1 + s0 * (a.ident ? 1.f : a.qsum[b]));
         a.comb[0][e] = c0;
         a.comb[1][e] = c1;
         // bf16 compute mode: the decoder's first GEMM and its dW read bf16 [B,L] / [L,B] copies (tiny: B*L elements)
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void latent_bwd_a_kernel(LatDev a) {
         G0 += gc;
         align_grads(a, 1, e, b, l, w_al, invBL, gz, gc);
         G1 += gc;
-        const float r = a.rsum[b], q = a.qsum[b];
+        const float r = a.ident ? 1.f : a.rsum[b], q = a.ident ? 1.f : a.qsum[b];
         const float H0 = G0 / (s0 + s1 * r), H1 = G1 / (s1 + s0 * q);
         a.H[0][e] = H0;
         a.H[1][e] = H1;
@@ -346,9 +349,11 @@ extern "C" int jamie_latent_fwd(const jamie_latent* a, const uint64_t* rng, void
     const LatDev d = to_dev(a);
     const int nblk = (a->B * a->L + 255) / 256;
     hipLaunchKernelGGL(latent_reparam_kernel, dim3(nblk), dim3(256), 0, st, d, rng);
-    MmJob j0 = {a->corr, a->z[1], a->cz[0], a->rsum, 0, 1};
-    MmJob j1 = {a->corr, a->z[0], a->cz[1], a->qsum, 1, 1};
-    launch_mm(st, a->B, a->L, j0, j1);
+    if (!d.ident) {
+        MmJob j0 = {a->corr, a->z[1], a->cz[0], a->rsum, 0, 1};
+        MmJob j1 = {a->corr, a->z[0], a->cz[1], a->qsum, 1, 1};
+        launch_mm(st, a->B, a->L, j0, j1);
+    }
     hipLaunchKernelGGL(latent_combine_kernel, dim3(nblk), dim3(256), 0, st, d);
     if (a->cosine)
         hipLaunchKernelGGL(latent_cosine_loss_kernel, dim3(nblk), dim3(256), 0, st, d);  // nblk >= ceil(B/256): every partial slot written
@@ -378,10 +383,15 @@ extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
         launch_mm(st, a->B, a->L, f0, f1);
     }
     hipLaunchKernelGGL(latent_bwd_a_kernel, dim3(nblk), dim3(256), 0, st, d);
-    MmJob j0 = {a->corr, a->H[1], a->ch[0], nullptr, 0, 1};
-    MmJob j1 = {a->corr, a->H[0], a->ch[1], nullptr, 1, 1};
-    launch_mm(st, a->B, a->L, j0, j1);
-    hipLaunchKernelGGL(latent_bwd_b_kernel, dim3(nblk), dim3(256), 0, st, d);
+    LatDev db = d;
+    if (d.ident) {        // corr H_1 = H_1, corr^T H_0 = H_0: the last kernel reads H itself
+        db.ch[0] = a->H[1]; db.ch[1] = a->H[0];
+    } else {
+        MmJob j0 = {a->corr, a->H[1], a->ch[0], nullptr, 0, 1};
+        MmJob j1 = {a->corr, a->H[0], a->ch[1], nullptr, 1, 1};
+        launch_mm(st, a->B, a->L, j0, j1);
+    }
+    hipLaunchKernelGGL(latent_bwd_b_kernel, dim3(nblk), dim3(256), 0, st, db);
     return jamie_launch_status("jamie_latent_bwd");
 }
 
