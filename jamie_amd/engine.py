@@ -77,7 +77,7 @@ def kl_anneal(epoch, min_epochs, epoch_DNN):
 
 class TrainEngine:
     def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
-                 world_size=1, compute_dtype='f32', dx_from_weights=True):
+                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=False):
         """compute_dtype 'f32': exact-fp32 MFMA GEMMs (the parity configuration).  'bf16': bf16 MFMA GEMMs with
         fp32 accumulation, fp32 master weights / optimiser / BatchNorm / losses (BASELINE config 2); needs every
         feature count, the latent size and the batch size to be multiples of 8."""
@@ -141,6 +141,11 @@ class TrainEngine:
                                   ('d_a1', [(2 * d, d) for d in self.dims], True)):
                 self.gcfg[key], plan_sk[key] = (plan_bf16_bwd if (bwd and grouped) else plan_bf16_rows)(B, shp)
             self.gcfg['dw'] = BF16_CFG_DW if _big_enough(B, [(d, d) for d in self.dims]) else -1
+            # experiment: the skinny head / latent backward launches through the 128 x 128 k-row-major kernel as well
+            # (no transposed copies at all)
+            self.skinny_tr = bool(skinny_tr) and self.gcfg['dw'] == BF16_CFG_DW and L % 8 == 0 and 2 * self.M <= nv.MAX_GROUP
+            if self.skinny_tr:
+                self.gcfg['d_comb'] = self.gcfg['d_a2'] = BF16_CFG_DW
         # dW = dy^T a: the 128 x 128 large-tile kernel reads dy [B, out] and a [B, in] as the layers wrote them (a_tr + b_tr),
         # so only operands of the launches that do not take that kernel (skinny head / latent layers, small models) still
         # need a transposed [features, B] copy
@@ -484,6 +489,8 @@ class TrainEngine:
     def _dw_cfg(self, lin):
         """Tile configuration of the dW launch of layer `lin` (-1: the library default for small / skinny problems)."""
         big = all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 256 for i in range(self.M))
+        if getattr(self, 'skinny_tr', False) and lin in ('head', 'dec0'):
+            big = True
         return self.gcfg.get('dw', -1) if big else -1
 
     def _dw_tr(self, lin):
