@@ -43,6 +43,11 @@ def run(name, shapes, cfg, sks, iters=13):
         nk = a[m, 4] % 1000
         print(f'  problem {pi}: {m.sum()} wgs, nk {nk.min()}..{nk.max()}, loop med {np.median(loop[m]):.2f} us = {np.median(loop[m]) / np.median(nk) * 1e3:.0f} ns/k-step, epi med {np.median(epi[m]):.2f}, start med {np.median(st[m]):.2f}, end max {end[m].max():.2f}')
     cu = a[:, 5]
+    if os.environ.get('PERCU'):
+        order = np.argsort(end)
+        for c in np.unique(cu)[:6]:
+            m = cu == c
+            print('   CU', c, 'tiles (problem*1000+nk, start, end):', [(int(x), round(float(y), 1), round(float(z), 1)) for x, y, z in zip(a[m, 4], st[m], end[m])])
     cnt = np.unique(cu, return_counts=True)[1]
     print(f'  distinct CUs {len(cnt)}, workgroups per CU min {cnt.min()} max {cnt.max()}')
     busy = {}
@@ -55,6 +60,7 @@ cases = {
  'bwd_dec1': ([(2 * x, x, B) for x in d] + [(B, x, 2 * x) for x in d], 25, (1, 1, 4, 2)),
  'bwd_enc1': ([(x, 2 * x, B) for x in d] + [(B, 2 * x, x) for x in d], 25, (1, 1, 2, 1)),
  'f32_fwd_d2d': ([(B, 2 * x, x) for x in d], -1, (1, 1)),
+ 'f32_fwd_d2d_sk21': ([(B, 2 * x, x) for x in d], -1, (2, 1)),
  'f32_fwd_2dd': ([(B, x, 2 * x) for x in d], -1, (2, 3)),
  'dw_only': ([(2 * x, x, B) for x in d], 25, (1, 1)),
  'bwd_dec1_r': ([(B, x, 2 * x) for x in d] + [(2 * x, x, B) for x in d], 25, (4, 2, 1, 1)),      # dX problems first
