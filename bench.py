@@ -128,6 +128,7 @@ def main():
     ap.add_argument('--transposed-weight-copies', action='store_true',
                     help='bf16 A/B: dX products on transposed bf16 weight copies (the earlier scheme) instead of reading W as stored')
     ap.add_argument('--skinny-tr', action='store_true', help='bf16 experiment: head / latent backward launches through the 128x128 k-row-major kernel')
+    ap.add_argument('--prefetch', action='store_true', help='A/B: sample + gather the next batch on a side stream under clip + Adam (measured -1 %)')
     ap.add_argument('--side-transposes', action='store_true',
                     help='bf16: transposed weight copies on a side stream under the next forward pass')
     ap.add_argument('--opt-priority', type=int, default=0, help='HIP stream priority of the optimiser stream')
@@ -171,7 +172,7 @@ def main():
         eng.enable_side_transposes()
     eng.enable_kernel_timing('enc_gemm', 'adam')
     # the step is a fixed launch sequence on static buffers: record it once, replay it (one foreign call per launch)
-    plan = eng.make_plan(data, idx, hi - lo, rep, allreduce)
+    plan = eng.make_plan(data, idx, hi - lo, rep, allreduce, prefetch=args.prefetch)
 
     def step():
         eng.run_plan(plan)

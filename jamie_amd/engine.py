@@ -732,7 +732,7 @@ class TrainEngine:
         self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
 
-    def optimizer_step(self, g16=None):
+    def optimizer_step(self, g16=None, after_norm=None):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step).
         `g16`: the reduced gradient as a flat bf16 tensor with the layout of `self.grad` (data-parallel exchange with
         bf16 messages); default: `self.grad`."""
@@ -748,6 +748,8 @@ class TrainEngine:
             norm = self.norm_partials[:self.n_norm]
             nv.grad_sqnorm(self.grad, norm, self.state)
         self._norm_ready = False
+        if after_norm is not None:       # e.g. the next batch's sampler + gather on a side stream, under clip + Adam
+            after_norm()
         if not self.pipeline:
             self._launch('adam', lambda: nv.clip_adam(self.m.flat, grad, self.exp_avg, self.exp_avg_sq,
                                                        norm, self.hyper, self.state,
@@ -787,7 +789,7 @@ class TrainEngine:
             nv.set_stream(None)
         self._opt_pending = True
 
-    def step(self, corr=None, Fblk=None, noise=None, allreduce=None):
+    def step(self, corr=None, Fblk=None, noise=None, allreduce=None, after_norm=None):
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
         `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
         self.forward_backward(corr, Fblk, noise, allreduce)
@@ -804,23 +806,55 @@ class TrainEngine:
             fn()
             if in_place:
                 g16 = allreduce.comm
-        self.optimizer_step(g16)
+        self.optimizer_step(g16, after_norm)
 
     # ---- recorded launch plan: one foreign call per launch, no descriptor rebuilding (host cost ~3 us/launch) ----
-    def make_plan(self, data, idx, n_rows, replace=False, allreduce=None):
+    def make_plan(self, data, idx, n_rows, replace=False, allreduce=None, prefetch=False):
         """Record one full step (device sampler -> gather -> step) on static buffers and return the plan.
-        The recording step is a real step.  'diag' sampling: both modalities use the same index tensor."""
-        nv.begin_record()
-        try:
+        The recording step is a real step.  'diag' sampling: both modalities use the same index tensor.
+        `prefetch`: the sampler and the gather of the NEXT batch run on a side stream right after the gradient-norm
+        kernel (which advances the step counter the sampler draws from), i.e. under clip + Adam, instead of in front of
+        the next forward pass: the same index stream and the same bits.  Measured: -1 % (clip + Adam loses more to the
+        interference than the 16 us are worth, like every other overlap tried on this step), so it is off by default."""
+        def next_batch():
             nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
             self.load_batch(data, [idx] * self.M)
-            corr = None
             if replace:
                 nv.corr_from_indices(idx, idx, self.corr)
-                corr = self.corr
-            self.step(corr, None, None, allreduce)
+        corr = self.corr if replace else None
+        if not prefetch:
+            nv.begin_record()
+            try:
+                next_batch()
+                self.step(corr, None, None, allreduce)
+            finally:
+                plan = nv.end_record()
+            return plan
+        side = torch.cuda.Stream(device=self.dev)
+        ev_norm, ev_batch = torch.cuda.Event(), torch.cuda.Event()
+        pending = [False]
+        next_batch()                                    # the recording step's own batch, on the main stream
+
+        def wait_batch():
+            if pending[0]:
+                nv.current_stream().wait_event(ev_batch)
+
+        def after_norm():
+            self._both(lambda: (ev_norm.record(nv.current_stream()), side.wait_event(ev_norm)))
+            nv.set_stream(side)
+            try:
+                next_batch()
+                self._both(lambda: ev_batch.record(side))
+            finally:
+                nv.set_stream(None)
+            pending[0] = True
+        nv.begin_record()
+        try:
+            self._both(wait_batch)
+            self.step(corr, None, None, allreduce, after_norm)
         finally:
             plan = nv.end_record()
+        self._plan_keep = (side, ev_norm, ev_batch)
         return plan
 
     def run_plan(self, plan):

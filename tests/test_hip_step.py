@@ -477,13 +477,13 @@ def test_plan_replay_equals_eager_steps(jam, mode):
     g = torch.Generator().manual_seed(0)
     data = [torch.randn(N, d, generator=g).cuda() for d in dims]
     flats = []
-    for use_plan in (False, True):
+    for use_plan in (False, True, 'prefetch'):         # 'prefetch': next batch sampled + gathered under clip + Adam
         torch.manual_seed(9)
         model = edModelVar(dims, L)
         eng = TrainEngine(model, B, compute_dtype=mode, seed=21)
         idx = torch.zeros(B, dtype=torch.int32, device='cuda')
         if use_plan:
-            plan = eng.make_plan(data, idx, N)
+            plan = eng.make_plan(data, idx, N, prefetch=(use_plan == 'prefetch'))
             for _ in range(5):
                 eng.run_plan(plan)
         else:
@@ -493,7 +493,7 @@ def test_plan_replay_equals_eager_steps(jam, mode):
                 eng.step()
         assert int(eng.state[1].item()) == 6 and model.num_batches_tracked == 6
         flats.append(model.flat.clone())
-    assert torch.equal(flats[0], flats[1])
+    assert torch.equal(flats[0], flats[1]) and torch.equal(flats[0], flats[2])
 
 
 @pytest.mark.parametrize('mode,variant', [('f32', 'pipeline'), ('bf16', 'pipeline'), ('bf16', 'side')])
