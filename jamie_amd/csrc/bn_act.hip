@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
 // two slabs in flight at a time, column sums by xor-shuffles over the 16 row phases of a wave + a 4-wave LDS step.
 // ------------------------------------------------------------------------------------------------
 #define BN4_RP 128
-#define BN4_MAXR 4
+#define BN4_MAXR 4      // rows per thread of the default instance (B <= 512); the kernels are templates on R (4 or 8: B <= 1024)
 #define BN4_NW 8          // waves per workgroup (512 threads)
 typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -430,12 +430,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
 }
 // bf16 outputs of a strip held as val[j] = 4 columns of row rp + 64 j
-__device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[BN4_MAXR], unsigned short* out_bf, unsigned short* outT_bf,
+template <int R>
+__device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigned short* out_bf, unsigned short* outT_bf,
                                                  unsigned short* tl, int B, int N, int col0, int cq, int rp, bool cok) {
     const int col = col0 + 4 * cq;
     if (out_bf && cok) {
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) {
+        for (int j = 0; j < R; ++j) {
             const int row = rp + j * BN4_RP;
             if (row < B)
                 *reinterpret_cast<uint2*>(out_bf + (long long)row * N + col) =
@@ -445,28 +446,29 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[BN4_MAXR], 
     if (!outT_bf) return;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
-        tl[(4 * cq) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].x);
-        tl[(4 * cq + 1) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].y);
-        tl[(4 * cq + 2) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].z);
-        tl[(4 * cq + 3) * BN_TS + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].w);
+        tl[(4 * cq) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].x);
+        tl[(4 * cq + 1) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].y);
+        tl[(4 * cq + 2) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].z);
+        tl[(4 * cq + 3) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].w);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = threadIdx.x + 512 * i, cc = q >> 6, r8 = (q & 63) * 8;
+    for (int i = 0; i < R / 2; ++i) {
+        const int q = threadIdx.x + 512 * i, cc = q / (16 * R), r8 = (q % (16 * R)) * 8;
         if (col0 + cc < N && r8 < B) {        // B is a multiple of 8 in bf16 mode
-            const unsigned* sp = reinterpret_cast<const unsigned*>(tl + cc * BN_TS + r8);
+            const unsigned* sp = reinterpret_cast<const unsigned*>(tl + cc * (128 * R + 2) + r8);
             *reinterpret_cast<uint4*>(outT_bf + (long long)(col0 + cc) * B + r8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
         }
     }
 }
 
+template <int R>
 __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                           float slope, const uint64_t* rng) {
     __shared__ float sh[BN4_NW][BN_CW];
-    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * BN_TS];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * (128 * R + 2)];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
@@ -480,9 +482,9 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.h, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
-    unsigned roff[BN4_MAXR];
+    unsigned roff[R];
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
     }
@@ -501,26 +503,26 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thr = drop_threshold16(p_drop);
-    unsigned mk[BN4_MAXR];
+    unsigned mk[R];
     if (drop && P.mask) {
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+        for (int j = 0; j < R; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
     }
-    float4 v[BN4_MAXR];
+    float4 v[R];
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < R; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned keepbits = 0xFFFFFFFFu;              // bit 4 j + e: element (row j, column e) of this thread is kept
     for (int s = 0; s < nslab; s += 2) {
-        float4 a[BN4_MAXR], b[BN4_MAXR];
+        float4 a[R], b[R];
         const bool two = s + 1 < nslab;
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) a[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
+        for (int j = 0; j < R; ++j) a[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
+        for (int j = 0; j < R; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
         if (s == 0 && drop) {                     // VALU work under the loads just issued
             keepbits = 0u;
 #pragma unroll
-            for (int j = 0; j < BN4_MAXR; ++j) {
+            for (int j = 0; j < R; ++j) {
                 if (P.mask) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) keepbits |= (((mk[j] >> (8 * e)) & 0xFFu) != 0 ? 1u : 0u) << (4 * j + e);
@@ -535,20 +537,20 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
             }
         }
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) {
+        for (int j = 0; j < R; ++j) {
             v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w;
             v[j].x += b[j].x; v[j].y += b[j].y; v[j].z += b[j].z; v[j].w += b[j].w;
         }
     }
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
+    for (int j = 0; j < R; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
     float4 mean = col_reduce4(sum, sh, tid);
     const float fB = (float)B;
     mean.x /= fB; mean.y /= fB; mean.z /= fB; mean.w /= fB;
     float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         if (rp + j * BN4_RP < B) {
             const float dx = v[j].x - mean.x, dy = v[j].y - mean.y, dz = v[j].z - mean.z, dw = v[j].w - mean.w;
             sq.x += dx * dx; sq.y += dy * dy; sq.z += dz * dz; sq.w += dw * dw;
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
         }
     }
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < B && cok) {
@@ -592,10 +594,11 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     if ((P.out_bf || P.outT_bf) && (!(JAMIE_BN_ABL & 2) || v[0].x == 123.456f)) strip_out_bf16x4(v, P.out_bf, P.outT_bf, tl, B, N, col0, cq, rp, cok);
 }
 
+template <int R>
 __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng) {
     __shared__ float sh[BN4_NW][BN_CW];
     __shared__ float sh2[BN4_NW][2 * BN_CW];
-    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * BN_TS];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * (128 * R + 2)];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
@@ -618,27 +621,27 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
         (void*)P.da, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)((unsigned)B * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
-    unsigned roff[BN4_MAXR];
+    unsigned roff[R];
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
     }
-    float4 dyv[BN4_MAXR], xnv[BN4_MAXR];
+    float4 dyv[R], xnv[R];
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) xnv[j] = buf_f32x4(h_rs, roff[j]);
+    for (int j = 0; j < R; ++j) xnv[j] = buf_f32x4(h_rs, roff[j]);
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) dyv[j] = buf_f32x4(d_rs, roff[j]);
-    unsigned mk[BN4_MAXR];
+    for (int j = 0; j < R; ++j) dyv[j] = buf_f32x4(d_rs, roff[j]);
+    unsigned mk[R];
     if (drop && P.mask) {
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+        for (int j = 0; j < R; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
     }
     unsigned keepbits = 0xFFFFFFFFu;              // Philox keep words under the loads in flight (see the forward kernel)
     if (drop) {
         keepbits = 0u;
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) {
+        for (int j = 0; j < R; ++j) {
             if (P.mask) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) keepbits |= (((mk[j] >> (8 * e)) & 0xFFu) != 0 ? 1u : 0u) << (4 * j + e);
@@ -653,15 +656,15 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
         }
     }
     for (int s = 1; s < nslab; ++s) {
-        float4 a[BN4_MAXR];
+        float4 a[R];
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) a[j] = buf_f32x4(d_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
+        for (int j = 0; j < R; ++j) a[j] = buf_f32x4(d_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
 #pragma unroll
-        for (int j = 0; j < BN4_MAXR; ++j) { dyv[j].x += a[j].x; dyv[j].y += a[j].y; dyv[j].z += a[j].z; dyv[j].w += a[j].w; }
+        for (int j = 0; j < R; ++j) { dyv[j].x += a[j].x; dyv[j].y += a[j].y; dyv[j].z += a[j].z; dyv[j].w += a[j].w; }
     }
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         const bool ok = cok && row < B;
         float d[4] = {dyv[j].x, dyv[j].y, dyv[j].z, dyv[j].w}, x[4] = {xnv[j].x, xnv[j].y, xnv[j].z, xnv[j].w};
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     const float k2[4] = {dgamma.x * invB, dgamma.y * invB, dgamma.z * invB, dgamma.w * invB};
     float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < BN4_MAXR; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         float dh[4] = {0.f, 0.f, 0.f, 0.f};
         if (cok && row < B) {
@@ -726,7 +729,7 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     memset(&g, 0, sizeof(g));
     g.count = count;
     int blocks = 0, maxB = 0;
-    bool need_rng = false, wide = true;
+    bool need_rng = false, wide = true, any_bf = false;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_fwd_problem& s = pr[i];
         JAMIE_ARG(s.h && s.gamma && s.beta && s.running_mean && s.running_var && s.save_mean && s.save_invstd,
@@ -739,8 +742,9 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
         d.h = s.h; d.gamma = s.gamma; d.beta = s.beta; d.rmean = s.running_mean; d.rvar = s.running_var;
         d.smean = s.save_mean; d.sinvstd = s.save_invstd; d.out = s.out; d.mask = s.mask;
         d.out_bf = (unsigned short*)s.out_bf16; d.outT_bf = (unsigned short*)s.outT_bf16;
-        JAMIE_ARG((!s.out_bf16 && !s.outT_bf16) || (s.B <= BN_MAXR * BN_RP && s.B % 8 == 0),
-                  "fused bf16 outputs need B <= 512 and B % 8 == 0");
+        JAMIE_ARG((!s.out_bf16 && !s.outT_bf16) || (s.B <= 8 * BN4_RP && s.B % 8 == 0),
+                  "fused bf16 outputs need B <= 1024 and B % 8 == 0");
+        if (s.out_bf16 || s.outT_bf16) any_bf = true;
         JAMIE_ARG(s.out || s.out_bf16 || s.outT_bf16, "no output requested");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.blk_begin = blocks;
@@ -753,8 +757,11 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     }
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
+    JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel, dim3(blocks), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel<4>, dim3(blocks), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng);
+    else if (wide && maxB <= 8 * BN4_RP)
+        hipLaunchKernelGGL(bn_act_fwd4_kernel<8>, dim3(blocks), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
     else
@@ -770,7 +777,7 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
     memset(&g, 0, sizeof(g));
     g.count = count;
     int blocks = 0, maxB = 0;
-    bool need_rng = false, wide = true;
+    bool need_rng = false, wide = true, any_bf = false;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_bwd_problem& s = pr[i];
         JAMIE_ARG(s.da && s.h && s.gamma && s.beta && s.save_mean && s.save_invstd && s.dgamma && s.dbeta,
@@ -783,8 +790,9 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
         d.da = s.da; d.h = s.h; d.gamma = s.gamma; d.beta = s.beta; d.smean = s.save_mean;
         d.sinvstd = s.save_invstd; d.dgamma = s.dgamma; d.dbeta = s.dbeta; d.dbias = s.dbias_lin; d.mask = s.mask;
         d.dh_bf = (unsigned short*)s.dh_bf16; d.dhT_bf = (unsigned short*)s.dhT_bf16; d.skip_f32 = s.skip_f32;
-        JAMIE_ARG((!s.dh_bf16 && !s.dhT_bf16) || (s.B <= BN_MAXR * BN_RP && s.B % 8 == 0),
-                  "fused bf16 outputs need B <= 512 and B % 8 == 0");
+        JAMIE_ARG((!s.dh_bf16 && !s.dhT_bf16) || (s.B <= 8 * BN4_RP && s.B % 8 == 0),
+                  "fused bf16 outputs need B <= 1024 and B % 8 == 0");
+        if (s.dh_bf16 || s.dhT_bf16) any_bf = true;
         JAMIE_ARG(!s.skip_f32 || s.dh_bf16 || s.dhT_bf16, "skip_f32 without a bf16 output");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.accumulate = s.accumulate; d.blk_begin = blocks;
@@ -797,8 +805,11 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
     }
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
+    JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel, dim3(blocks), dim3(512), 0, st, g, p_drop, slope, rng);
+        hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks), dim3(512), 0, st, g, p_drop, slope, rng);
+    else if (wide && maxB <= 8 * BN4_RP)
+        hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks), dim3(512), 0, st, g, p_drop, slope, rng);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
     else

@@ -86,8 +86,8 @@ class TrainEngine:
             raise ValueError("compute_dtype must be 'f32' or 'bf16'")
         self.bf16 = compute_dtype == 'bf16'
         self.compute_dtype = compute_dtype
-        # BN kernels emit the bf16 / transposed copies themselves when the strip is register-resident (B <= 512)
-        self.fuse_bf16 = self.bf16 and int(batch_size) <= 512
+        # BN kernels emit the bf16 / transposed copies themselves when the strip is register-resident (B <= 1024)
+        self.fuse_bf16 = self.bf16 and int(batch_size) <= 1024     # (8 rows per thread in the float4 BN kernels above 512)
         self.m = model
         self.dev = model.device
         self.B = B = int(batch_size)

@@ -215,7 +215,8 @@ def _bn_ref(h, gamma, beta, mask, p, da):
     return y.detach(), rm, rv, h.grad, gamma.grad, beta.grad
 
 
-@pytest.mark.parametrize('B,N,p,nslab', [(32, 40, 0.6, 1), (512, 100, 0.6, 2), (100, 33, 0.0, 1), (700, 24, 0.25, 3)])
+@pytest.mark.parametrize('B,N,p,nslab', [(32, 40, 0.6, 1), (512, 100, 0.6, 2), (100, 33, 0.0, 1), (700, 24, 0.25, 3),
+                                          (1024, 100, 0.6, 2), (1000, 36, 0.0, 1), (1032, 24, 0.25, 1)])
 def test_bn_act_fwd_bwd(nv, B, N, p, nslab):
     g = torch.Generator().manual_seed(B + N)
     hs = torch.randn(nslab, B, N, generator=g) * 2 + 0.5
