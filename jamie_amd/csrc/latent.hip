@@ -107,39 +107,66 @@ __global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uin
 struct MmJob { const float* Mtx; const float* Z; float* out; float* sums; int transpose; int active; };
 struct MmJobs { MmJob j[2]; int B, L; };
 
+// 256 threads = R rows x Lp latent columns (Lp = L rounded up to a power of two, R = 256 / Lp); the [B,B] matrix and Z are
+// streamed through LDS in 64-column chunks (coalesced: a chunk of Z is one contiguous block), every thread adds its 64
+// products in ascending column order with fmaf -- the order of the first version of this kernel (one thread per output
+// walking a whole matrix row from global memory: 1024 dependent round trips, 150-290 us per launch at B = 512-1024; the
+// general correspondence / F blocks of partial-correspondence training pay four to six such products per step).
+#define MM_CH 64
 __global__ __launch_bounds__(256) void small_mm_kernel(MmJobs js) {
+    __shared__ float Msh[256 / 4][MM_CH + 1];       // R <= 64 rows (Lp >= 4)
+    __shared__ float Zsh[MM_CH][64 + 1];            // Lp <= 64 per pass
     const MmJob& J = js.j[blockIdx.y];
     if (!J.active) return;
-    const int B = js.B, L = js.L, n = B * L;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const int row = e / L, l = e % L;
-    float acc = 0.f, sm = 0.f;
-    if (J.Mtx == nullptr) {
-        acc = J.Z[e];
-        sm = 1.f;
-    } else if (!J.transpose) {
-        const float* mr = J.Mtx + (long long)row * B;
-        for (int c = 0; c < B; ++c) {
-            const float w = mr[c];
-            acc = fmaf(w, J.Z[c * L + l], acc);
-            sm += w;
+    const int B = js.B, L = js.L;
+    int Lp = 4;
+    while (Lp < L && Lp < 64) Lp <<= 1;
+    const int R = 256 / Lp;
+    const int r = threadIdx.x / Lp, lq = threadIdx.x % Lp;
+    const int row0 = blockIdx.x * R, row = row0 + r;
+    for (int l0 = 0; l0 < L; l0 += Lp) {            // L > 64: several passes over the latent columns
+        const int l = l0 + lq;
+        float acc = 0.f, sm = 0.f;
+        if (J.Mtx == nullptr) {
+            if (row < B && l < L) { J.out[(long long)row * L + l] = J.Z[(long long)row * L + l]; if (J.sums && l == 0) J.sums[row] = 1.f; }
+            continue;
         }
-    } else {
-        for (int c = 0; c < B; ++c) {
-            const float w = J.Mtx[(long long)c * B + row];
-            acc = fmaf(w, J.Z[c * L + l], acc);
-            sm += w;
+        for (int c0 = 0; c0 < B; c0 += MM_CH) {
+            for (int i = threadIdx.x; i < R * MM_CH; i += 256) {
+                int rr, cc;
+                if (!J.transpose) { rr = i / MM_CH; cc = i % MM_CH; } else { cc = i / R; rr = i % R; }
+                const int gr = row0 + rr, gc = c0 + cc;
+                float w = 0.f;
+                if (gr < B && gc < B) w = J.transpose ? J.Mtx[(long long)gc * B + gr] : J.Mtx[(long long)gr * B + gc];
+                Msh[rr][cc] = w;
+            }
+            for (int i = threadIdx.x; i < MM_CH * Lp; i += 256) {
+                const int cc = i / Lp, ll = l0 + i % Lp, gc = c0 + cc;
+                Zsh[cc][i % Lp] = (gc < B && ll < L) ? J.Z[(long long)gc * L + ll] : 0.f;
+            }
+            __syncthreads();
+            const int nc = min(MM_CH, B - c0);
+            for (int cc = 0; cc < nc; ++cc) {
+                const float w = Msh[r][cc];
+                acc = fmaf(w, Zsh[cc][lq], acc);
+                sm += w;
+            }
+            __syncthreads();
+        }
+        if (row < B && l < L) {
+            J.out[(long long)row * L + l] = acc;
+            if (J.sums && l == 0) J.sums[row] = sm;
         }
     }
-    J.out[e] = acc;
-    if (J.sums && l == 0) J.sums[row] = sm;
 }
 
 static void launch_mm(hipStream_t st, int B, int L, const MmJob& j0, const MmJob& j1) {
     MmJobs js;
     js.j[0] = j0; js.j[1] = j1; js.B = B; js.L = L;
-    hipLaunchKernelGGL(small_mm_kernel, dim3((B * L + 255) / 256, 2), dim3(256), 0, st, js);
+    int Lp = 4;
+    while (Lp < L && Lp < 64) Lp <<= 1;
+    const int R = 256 / Lp;
+    hipLaunchKernelGGL(small_mm_kernel, dim3((B + R - 1) / R, 2), dim3(256), 0, st, js);
 }
 
 // per-row cosine pieces: s = a.c / (|a||c|)
