@@ -255,6 +255,12 @@ int jamie_gather_rows(const float* src, long long n_rows, int d, const int32_t* 
  * (device-side counterpart of np.random.choice, jamie.py:556); one workgroup, deterministic. */
 int jamie_sample_indices(int32_t* idx, int B, long long N, long long offset, int replace,
                          const uint64_t* rng, int rng_stream, void* stream);
+/* 'hybrid' sampler of partial-correspondence training on the device (jamie.py:559-573, corrected): slot b is, with
+ * probability true_ratio, known pair pairs[pidx[b] % num_corr] = (row of modality 0, row of modality 1), else (r0[b], r1[b]);
+ * pidx / r0 / r1: candidate draws from jamie_sample_indices */
+int jamie_hybrid_assemble(const int32_t* pairs /*[num_corr,2]*/, const int32_t* pidx, const int32_t* r0, const int32_t* r1,
+                          int B, int num_corr, float true_ratio, const uint64_t* rng, int rng_stream, int32_t* idx0,
+                          int32_t* idx1, void* stream);
 /* corr[a,b] = (idx0[a] == idx1[b]) row-normalised (P = I_N block, jamie.py:586-589) */
 int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1, int B, float* corr, void* stream);
 /* blk[a,b] = P[idx0[a] + row_off, idx1[b] + col_off] for P in CSR form (int32 indptr / indices sorted within each

@@ -140,6 +140,8 @@ EXPORTS = {
                                     C.c_void_p]),
     'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
                                        C.c_int, C.c_void_p]),
+    'jamie_hybrid_assemble': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'jamie_corr_from_indices': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_csr_block': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     'jamie_colsum_group': (C.c_int, [C.POINTER(ColsumProblem), C.c_int, C.c_void_p]),
@@ -469,3 +471,8 @@ class SqRanges:
 def grad_sqnorm_ranges(g, ranges, partials, state):
     _call('jamie_grad_sqnorm_ranges', ptr(g), ranges.off, ranges.len, ranges.count, ptr(partials), partials.numel(),
           ptr(state), _stream())
+
+
+def hybrid_assemble(pairs, pidx, r0, r1, num_corr, true_ratio, rng, rng_stream, idx0, idx1):
+    _call('jamie_hybrid_assemble', ptr(pairs), ptr(pidx), ptr(r0), ptr(r1), idx0.numel(), int(num_corr), float(true_ratio),
+          ptr(rng), int(rng_stream), ptr(idx0), ptr(idx1), _stream())

@@ -357,3 +357,39 @@ extern "C" int jamie_standardise(const void* X, int is_f64, long long N, int d, 
     else hipLaunchKernelGGL(standardise_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)X, N, d, ld, mean, sd, out);
     return jamie_launch_status("jamie_standardise");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Device counterpart of the 'hybrid' sampler of partial-correspondence training (reference jamie.py:559-573, with the
+// correction described in jamie_amd/jamie.py): every batch slot is, with probability `true_ratio`, one of the known
+// cell pairs (modality 0 gets the pair's row, modality 1 its column), otherwise an independent random cell of each
+// modality.  The candidate draws (B distinct pair numbers, B distinct rows per modality) come from jamie_sample_indices;
+// this kernel only picks per slot.  Philox keyed by (seed, step, stream): deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hybrid_assemble_kernel(const int32_t* __restrict__ pairs, const int32_t* __restrict__ pidx,
+                                                              const int32_t* __restrict__ r0, const int32_t* __restrict__ r1,
+                                                              int B, int num_corr, float true_ratio, const uint64_t* rng,
+                                                              int rng_stream, int32_t* idx0, int32_t* idx1) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const Philox4 u = jamie_rand4(rng, (uint32_t)rng_stream, (uint64_t)b);
+    const float x = (float)u.v[0] * 2.3283064365386963e-10f;
+    const bool paired = num_corr > 0 && x < true_ratio;
+    if (paired) {
+        const int k = pidx[b] % num_corr;
+        idx0[b] = pairs[2 * k];
+        idx1[b] = pairs[2 * k + 1];
+    } else {
+        idx0[b] = r0[b];
+        idx1[b] = r1[b];
+    }
+}
+
+extern "C" int jamie_hybrid_assemble(const int32_t* pairs, const int32_t* pidx, const int32_t* r0, const int32_t* r1, int B,
+                                     int num_corr, float true_ratio, const uint64_t* rng, int rng_stream, int32_t* idx0,
+                                     int32_t* idx1, void* stream) {
+    JAMIE_ARG(pidx && r0 && r1 && rng && idx0 && idx1 && B > 0 && (num_corr == 0 || pairs), "null pointer / empty");
+    JAMIE_ARG(true_ratio >= 0.f && true_ratio <= 1.f && num_corr >= 0, "0 <= true_ratio <= 1, num_corr >= 0");
+    hipLaunchKernelGGL(hybrid_assemble_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pairs, pidx, r0, r1, B,
+                       num_corr, true_ratio, rng, rng_stream, idx0, idx1);
+    return jamie_launch_status("jamie_hybrid_assemble");
+}

@@ -347,6 +347,25 @@ class JAMIE:
         plan = None
         use_plan = (self.sampler == 'device' and method == 'diag' and P_dense is None and F_dense is None
                     and P_csr is None and self.PF_Ratio == 1 and self.batch_step)
+        # partial correspondence from a sparse P with the device sampler: pair / rest candidates from jamie_sample_indices,
+        # jamie_hybrid_assemble picks per slot, jamie_csr_block builds the [B,B] block -- the whole step stays on the GPU and
+        # is recorded as a plan too (the numpy sampler costs 2 ms of host time per step at 100k cells: np.random.choice without
+        # replacement permutes all N rows)
+        plan_hybrid = (self.sampler == 'device' and method == 'hybrid' and P_csr is not None and F_dense is None
+                       and self.PF_Ratio == 1 and self.batch_step and world == 1 and B <= 2048)
+        if plan_hybrid:
+            pairs_dev = torch.from_numpy(np.ascontiguousarray(self.corr_samples.astype(np.int32))).to(dev)
+            hy = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(3)]
+
+            def hybrid_step():
+                nv.sample_indices(hy[0], self.num_corr, 0, rep or self.num_corr < B, eng.state, 202)
+                nv.sample_indices(hy[1], rows[0], 0, rep, eng.state, 200)
+                nv.sample_indices(hy[2], rows[1], 0, rep, eng.state, 201)
+                nv.hybrid_assemble(pairs_dev, hy[0], hy[1], hy[2], self.num_corr, self.true_ratio, eng.state, 203,
+                                   idx_dev[0], idx_dev[1])
+                eng.load_batch(data, idx_dev)
+                nv.csr_block(*P_csr, idx_dev[0], idx_dev[1], eng.corr, bounds[0][0], bounds[1][0])
+                eng.step(eng.corr, None, None, allreduce)
         epoch_sum = torch.zeros((), device=dev)      # batch_step=False: epoch loss = mean of the batch losses (jamie.py:728)
         start_epoch = 0
         if self._resume_from is not None:
@@ -360,6 +379,16 @@ class JAMIE:
                 if use_plan:
                     if plan is None:
                         plan = eng.make_plan(data, idx_dev[0], rows[0], rep, allreduce)
+                    else:
+                        eng.run_plan(plan)
+                    continue
+                if plan_hybrid:
+                    if plan is None:
+                        nv.begin_record()
+                        try:
+                            hybrid_step()                  # the recording step is a real step
+                        finally:
+                            plan = nv.end_record()
                     else:
                         eng.run_plan(plan)
                     continue

@@ -882,6 +882,56 @@ def test_facade_sparse_P_equals_dense_P(jam):
     assert jm.sampling_method == 'diag'
 
 
+def test_hybrid_assemble_kernel(jam):
+    """Device 'hybrid' sampler: the share of paired slots follows true_ratio, paired slots carry a known pair, the others
+    the candidate rows; deterministic for a given (seed, step)."""
+    from jamie_amd import _native as nv
+    B, K = 512, 300
+    pairs = torch.stack([torch.arange(K, dtype=torch.int32) * 3, torch.arange(K, dtype=torch.int32) * 5 + 1], 1).cuda().contiguous()
+    pidx = torch.randint(0, K, (B,), dtype=torch.int32).cuda()
+    r0 = (torch.arange(B, dtype=torch.int32) + 100000).cuda()
+    r1 = (torch.arange(B, dtype=torch.int32) + 200000).cuda()
+    state = torch.tensor([5, 9, 0, 0], dtype=torch.int64, device='cuda')
+    out = []
+    for _ in range(2):
+        i0, i1 = torch.zeros(B, dtype=torch.int32, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
+        nv.hybrid_assemble(pairs, pidx, r0, r1, K, 0.8, state, 203, i0, i1)
+        out.append((i0.cpu(), i1.cpu()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    i0, i1 = out[0]
+    paired = i0 < 100000
+    assert 0.72 < paired.float().mean().item() < 0.88
+    k = pidx.cpu().long()
+    assert torch.equal(i0[paired], pairs.cpu()[k[paired], 0]) and torch.equal(i1[paired], pairs.cpu()[k[paired], 1])
+    assert torch.equal(i0[~paired], r0.cpu()[~paired]) and torch.equal(i1[~paired], r1.cpu()[~paired])
+    state[1] = 10
+    nv.hybrid_assemble(pairs, pidx, r0, r1, K, 0.8, state, 203, i0 := torch.zeros(B, dtype=torch.int32, device='cuda'),
+                       torch.zeros(B, dtype=torch.int32, device='cuda'))
+    assert not torch.equal(i0.cpu() < 100000, paired)            # another step, another choice of slots
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_facade_sparse_P_device_sampler_plan_path(jam, mode):
+    """Partial correspondence (sparse P) with sampler='device': hybrid sampling, CSR block lookup and the step are one
+    recorded plan; the known pairs pull the two modalities together (the alignment of the PAIRED cells improves)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    N, dims = 1536, (72, 40)
+    Z = rng.standard_normal((N, 5))
+    data = [Z @ rng.standard_normal((5, d)) + .05 * rng.standard_normal((N, d)) for d in dims]
+    known = np.sort(rng.choice(N, N // 2, replace=False))
+    P = sp.csr_matrix((np.ones(len(known), np.float32), (known, known)), shape=(N, N))
+    jm = jam.JAMIE(output_dim=8, batch_size=128, epoch_DNN=40, min_epochs=10, pca_dim=None, use_f_tilde=False,
+                   log_DNN=10 ** 9, sampler='device', compute_dtype=mode)
+    emb = _quiet(lambda: jm.fit_transform(dataset=data, P=P))
+    assert jm.sampling_method == 'hybrid' and jm.num_corr == N // 2
+    assert int(jm.engine.state[1].item()) == 40 * (N // 128)
+    assert all(np.isfinite(v).all() for v in jm.loss_history.values())
+    assert jm.loss_history['CosSim'][-1] > 0                 # a general correspondence block: the alignment term is live
+    assert jm.loss_history['Rec'][-1] < jm.loss_history['Rec'][0]
+    assert jm.test_closer([e[known] for e in emb]) < 0.25    # FOSCTTM of the paired cells
+
+
 # ---- SURVEY.md §8(f) rank 4: device-side preprocessing and training checkpoints ----
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_device_standardisation_matches_numpy(jam, dtype):
