@@ -426,14 +426,15 @@ class JAMIE:
                         nv.csr_block(*P_csr, idx_dev[0], idx_dev[1], eng.corr, bounds[0][0], bounds[1][0])
                         Pb = eng.corr
                     elif P_dense is not None:
-                        Pb = _row_normalise(P_dense[i0 + bounds[0][0]][:, i1 + bounds[1][0]])
+                        Pb = _row_normalise(P_dense[(i0 + bounds[0][0])[:, None], (i1 + bounds[1][0])[None, :]])   # B x B gather
                     elif method == 'diag':
                         nv.corr_from_indices(idx_dev[0], idx_dev[1], eng.corr)
                         Pb = eng.corr
                     else:
                         Pb = torch.zeros(B, B, device=dev)
                     if F_dense is not None:
-                        Fblk = _row_normalise(F_dense[i0 + bounds[0][0]][:, i1 + bounds[1][0]]).contiguous()
+                        # one B x B gather (F[i0][:, i1] would first materialise a [B, N] slab: 205 MB at 100k cells)
+                        Fblk = _row_normalise(F_dense[(i0 + bounds[0][0])[:, None], (i1 + bounds[1][0])[None, :]]).contiguous()
                         corr = (self.PF_Ratio * Pb + (1 - self.PF_Ratio) * Fblk).contiguous()
                     else:
                         corr = (self.PF_Ratio * Pb).contiguous() if self.PF_Ratio != 1 else Pb
