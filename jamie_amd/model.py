@@ -262,6 +262,16 @@ class edModelVar:
         x = torch.as_tensor(x)
         return x.to(self.device, torch.float32).contiguous()
 
+    @staticmethod
+    def _eval_cfg(n, nout, k):
+        """fp32 GEMM tile for the eval path: many rows make these large, square-ish products, where the 128x128x32 tile
+        (8 waves) runs at 120-130 TFLOP/s against ~110 for the 64x64 default of the skinny training shapes
+        (tools/bench_gemm_sq.py, tools/bench_infer.py); JAMIE_EVAL_GEMM_CFG overrides (diagnostics)."""
+        import os
+        if 'JAMIE_EVAL_GEMM_CFG' in os.environ:
+            return int(os.environ['JAMIE_EVAL_GEMM_CFG'])
+        return 4 if (n >= 2048 and nout >= 512 and k >= 512) else -1
+
     def _lin_bn_act(self, i, x, lin, bn):
         W, b = self.p[f'm{i}.{lin}.W'], self.p[f'm{i}.{lin}.b']
         n, k = x.shape[0], x.shape[1]
@@ -270,13 +280,13 @@ class edModelVar:
                              aux=(self.bn[f'm{i}.{bn}.mean'], self.bn[f'm{i}.{bn}.var'],
                                   self.p[f'm{i}.{bn}.g'], self.p[f'm{i}.{bn}.b']),
                              slope=LRELU_SLOPE, eps=BN_EPS)
-        nv.gemm([pr], nv.NT)
+        nv.gemm([pr], nv.NT, self._eval_cfg(n, W.shape[0], k))
         return out
 
     def _linear(self, x, W, b):
         n, k = x.shape[0], x.shape[1]
         out = torch.empty(n, W.shape[0], device=self.device)
-        nv.gemm([nv.gemm_problem(x, W, out, n, W.shape[0], k, k, k, W.shape[0], bias=b)], nv.NT)
+        nv.gemm([nv.gemm_problem(x, W, out, n, W.shape[0], k, k, k, W.shape[0], bias=b)], nv.NT, self._eval_cfg(n, W.shape[0], k))
         return out
 
     def _encode_eval(self, i, x):
