@@ -69,6 +69,25 @@ def plan_bf16_bwd(B, shapes):
     return BF16_CFG_DW, [int(max(1, min(round(K / 1000), 4, K // 256))) for (N, K) in shapes]
 
 
+F32_CFG_ROWS = 4            # 128x128x32 tile, 8 waves of 64x32 (gemm_f32.hip)
+
+
+def plan_f32_rows(B, shapes, target=2 * N_CU):
+    """fp32 forward / dX launch with shapes = [(N_i, K_i)]: the 128x128x32 tile with K slices of one common length such
+    that the launch has at most two workgroups per CU (tools/bench_gemm_f32_tiles.py: d -> 2d (3, 2) slices 110 us
+    against 119-122 us for the unsplit 64x64 tiles; 2d -> d (6, 3) 102 against 107 us).  (-1, None): keep the default."""
+    if B < 256 or any(N < 512 or K < 512 for (N, K) in shapes):
+        return -1, None
+    tiles = [math.ceil(B / 128) * math.ceil(N / 128) for (N, K) in shapes]
+    best = None
+    for kc in range(256, max(K for (_, K) in shapes) + 1, 8):
+        sk = [min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes]
+        total = sum(t * s for t, s in zip(tiles, sk))
+        if total <= target and (best is None or total > best[0]):
+            best = (total, sk)
+    return (F32_CFG_ROWS, best[1]) if best else (-1, None)
+
+
 def kl_anneal(epoch, min_epochs, epoch_DNN):
     """jamie.py:630-631."""
     c = (min_epochs / 2) if min_epochs > 0 else (epoch_DNN / 2)
@@ -149,6 +168,17 @@ class TrainEngine:
         # dW = dy^T a: the 128 x 128 large-tile kernel reads dy [B, out] and a [B, in] as the layers wrote them (a_tr + b_tr),
         # so only operands of the launches that do not take that kernel (skinny head / latent layers, small models) still
         # need a transposed [features, B] copy
+        # fp32: tile + slices of the forward launches and of the dX launches with K = 2d (plan_f32_rows); the x_hat product is
+        # split too and its MSE / gradient come from jamie_mse_cast (a fused epilogue needs an unsplit K: 126 us)
+        self.fcfg = {}
+        if not self.bf16:
+            for key, shp in (('enc0', [(2 * d, d) for d in self.dims]), ('enc1', [(d, 2 * d) for d in self.dims]),
+                             ('dec1', [(2 * d, d) for d in self.dims]), ('dec2', [(d, 2 * d) for d in self.dims]),
+                             ('d_e1', [(d, 2 * d) for d in self.dims])):
+                cfg, sks = plan_f32_rows(B, shp)
+                if cfg >= 0:
+                    self.fcfg[key] = cfg
+                    plan_sk[key] = sks
         self.need_T = set()
         if self.bf16:
             for dy_key, a_key, lin in (('dxhat', 'e2', 'dec2'), ('de2', 'e1', 'dec1'), ('de1', 'comb', 'dec0'),
@@ -176,7 +206,7 @@ class TrainEngine:
             w['g1'] = torch.empty(1, B, d, **f32); w['e1'] = torch.empty(B, d, **f32)
             w['g2'] = torch.empty(sk['dec1'], B, 2 * d, **f32); w['e2'] = torch.empty(B, 2 * d, **f32)
             w['dxhat'] = torch.empty(B, d, **f32)
-            if self.gcfg.get('dec2', -1) >= 0:          # bf16: split-K x_hat slabs, MSE in jamie_mse_cast
+            if self.gcfg.get('dec2', -1) >= 0 or self.fcfg.get('dec2', -1) >= 0:   # split-K x_hat slabs, MSE in jamie_mse_cast
                 w['xh'] = torch.empty(sk['dec2'], B, d, **f32)
             w['de2'] = torch.empty(sk['d_e2'], B, 2 * d, **f32)
             w['de1'] = torch.empty(sk['d_e1'], B, d, **f32)
@@ -445,9 +475,10 @@ class TrainEngine:
                                          bias=P[f'm{i}.{lin}.b'] if with_bias else None,
                                          splitk=w['sk'][sk_key], slab_stride=self.B * nout))
         cfg = self.gcfg.get(sk_key, -1)
+        fcfg = self.fcfg.get(sk_key, -1)
         self._wait_params(lin)
-        self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') else lin,
-                     (lambda: nv.gemm_bf16(probs, cfg)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))
+        self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') or (lin == 'dec2' and fcfg >= 0) else lin,
+                     (lambda: nv.gemm_bf16(probs, cfg)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT, fcfg)))
 
     def _dx_gemm(self, dy_key, lin, out_key, sk_key):
         """dx[B, in_f] (slabs) = dy[B, out_f] W."""
@@ -468,7 +499,7 @@ class TrainEngine:
         if self.bf16:
             nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
         else:
-            nv.gemm(probs, nv.NN)
+            nv.gemm(probs, nv.NN, self.fcfg.get(sk_key, -1))
 
     def _dw_gemm(self, dy_key, a_key, lin):
         """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer."""
@@ -672,12 +703,12 @@ class TrainEngine:
                     w['xhat'] = torch.empty(1, B, d, device=self.dev, dtype=torch.float32)
             self._fwd_gemm('e2', 'dec2', 'xhat', 'dec0')
             return lat
-        if self.bf16 and self.gcfg.get('dec2', -1) >= 0:                  # split-K x_hat GEMM, then MSE + casts
+        if (self.bf16 and self.gcfg.get('dec2', -1) >= 0) or self.fcfg.get('dec2', -1) >= 0:   # split-K x_hat GEMM, then MSE (+ casts)
             self._fwd_gemm('e2', 'dec2', 'xh', 'dec2')
             probs, off = [], 0
             for i, d in enumerate(self.dims):
                 w = self.ws[i]
-                probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w['dxhat_bf'], w['dxhat_T'] if 'dxhat' in self.need_T else None,
+                probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w.get('dxhat_bf'), w['dxhat_T'] if 'dxhat' in self.need_T else None,
                                             partial=self.rec_partials[off:off + self.rec_tiles[i]],
                                             scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
                 off += self.rec_tiles[i]
