@@ -282,7 +282,7 @@ class TrainEngine:
         self._timing = None
         self._timing_every, self._timing_step = 1, 0
         self.pipeline = False            # enable_pipeline(): optimiser on its own stream, overlapped with the next forward
-        self.side_transposes, self._wT_pending = False, False
+        self.side_transposes, self._wT_pending, self._wT_stale = False, False, False
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
     # Adam is HBM-bound (28 B/parameter) and the forward GEMMs are bound by the L2 -> LDS fabric and the matrix pipe, so
@@ -342,6 +342,9 @@ class TrainEngine:
                 torch.cuda.current_stream().wait_event(ev)
         if self.side_transposes and self._wT_pending:
             torch.cuda.current_stream().wait_event(self._ev_wT)
+        if self.bf16 and self._wT_stale:                 # the skinny weights' transposed copies ride on the next batch launch
+            self.refresh_weights_bf16(transposes_only=True)
+            self._wT_stale = False
 
     # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
     def set_kl_anneal(self, anneal):
@@ -406,6 +409,10 @@ class TrainEngine:
                     probs.append(nv.cast_problem(W, self.wbf[f'm{i}.{lin}.W'], wt))
         if probs:
             nv.cast_transpose(probs)
+
+    def _wT_problems(self):
+        """cast_transpose problems of the transposed bf16 weight copies that exist (the skinny layers' only)."""
+        return [nv.cast_problem(self.wbf[k + '.W'], None, wt) for k, wt in self.wT.items()]
 
     def _cast(self, key):
         """fp32 activation / gradient `key` ([B, n] or slab 0 of [S, B, n]) -> bf16 [B, n] and bf16 [n, B]."""
@@ -621,11 +628,15 @@ class TrainEngine:
         return d
 
     # ---- the step ----
-    def load_batch(self, data, idx):
-        """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors."""
-        if self.bf16:      # gather + bf16 copy + transposed bf16 copy of the batch in one launch
-            nv.cast_transpose([nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'] if 'x' in self.need_T else None,
-                                               rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)])
+    def load_batch(self, data, idx, with_wT=True):
+        """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors.  `with_wT=False`: the batch is being
+        loaded while the optimiser may still be writing the weights (prefetch): leave the weight transposes to _backward."""
+        if self.bf16:      # gather + bf16 copy (+ transposed copy) of the batch, and the skinny weights' transposes: one launch
+            probs = [nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'] if 'x' in self.need_T else None,
+                                     rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)]
+            nv.cast_transpose(probs + (self._wT_problems() if with_wT else []))
+            if with_wT:
+                self._wT_stale = False
             return
         for i in range(self.M):
             nv.gather_rows(data[i], idx[i], self.ws[i]['x'])
@@ -643,6 +654,9 @@ class TrainEngine:
         for i in range(self.M):
             self.ws[i]['x'].copy_(X[i])
         self._cast('x')
+        if self.bf16 and self._wT_stale:
+            self.refresh_weights_bf16(transposes_only=True)
+            self._wT_stale = False
 
     def forward_backward(self, corr=None, Fblk=None, noise=None, allreduce=None):
         """Forward, losses and backward for the batch already in the workspace.  `corr` None = identity,
@@ -733,6 +747,9 @@ class TrainEngine:
         B, L = self.B, self.L
         acc = self.accumulate
         self._wait_wT()
+        if self.bf16 and self._wT_stale:          # an optimiser step without a new batch since (tests): refresh here
+            self.refresh_weights_bf16(transposes_only=True)
+            self._wT_stale = False
         self._fuse_now = self.fused_norm and allreduce is None      # a reduced gradient needs its norm taken afterwards
         nv.colsum_group([(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
@@ -798,7 +815,10 @@ class TrainEngine:
                     nv.set_stream(None)
                 self._wT_pending = True
             elif self.bf16:
-                self.refresh_weights_bf16(transposes_only=True)
+                # the transposed copies of the skinny head / latent weights (0.6 MB; the big layers need none) are only read
+                # by the next backward pass: they ride on the next batch's gather / cast launch (load_batch, set_batch)
+                # instead of a launch of their own; _backward refreshes them itself if no batch was loaded in between
+                self._wT_stale = True
             return
         # pipelined: the optimiser stream takes over once the gradient norm is known; it hands the parameter groups
         # back one by one (events) while the main stream already runs the next step's sampler, gather and forward
@@ -849,7 +869,7 @@ class TrainEngine:
         interference than the 16 us are worth, like every other overlap tried on this step), so it is off by default."""
         def next_batch():
             nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
-            self.load_batch(data, [idx] * self.M)
+            self.load_batch(data, [idx] * self.M, with_wT=not prefetch)
             if replace:
                 nv.corr_from_indices(idx, idx, self.corr)
         corr = self.corr if replace else None
@@ -865,6 +885,7 @@ class TrainEngine:
         ev_norm, ev_batch = torch.cuda.Event(), torch.cuda.Event()
         pending = [False]
         next_batch()                                    # the recording step's own batch, on the main stream
+        self._wT_stale = self.bf16                      # the recorded backward pass refreshes the weight transposes itself
 
         def wait_batch():
             if pending[0]:

@@ -434,6 +434,7 @@ def test_bf16_compute_mode_tracks_fp32_oracle(jam, B, dims, L, p):
     assert torch.equal(eng.wbf['m0.enc0.W'].float(), model.p['m0.enc0.W'].to(torch.bfloat16).float())
     # the big layers' dX products read W as stored (b_tr): only the skinny head / latent layers keep a transposed copy
     assert ('m1.dec1' not in eng.wT) == (min(dims) >= 256) and len(eng.wT) > 0
+    eng.flush()            # the transposed copies are refreshed with the next batch launch, or on flush()
     for k, wt in eng.wT.items():
         assert torch.equal(wt.float(), model.p[k + '.W'].t().to(torch.bfloat16).float()), k
 
