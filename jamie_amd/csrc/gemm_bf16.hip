@@ -879,7 +879,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
         d.b_tr = s.b_tr; d.a_tr = s.a_tr;
         if (s.a_tr && !(V2 && BM == 128 && BN == 128 && s.b_tr))
-            return jamie_fail(-1, "%s: a_tr (A stored [K, M]) needs b_tr and a 128 x 128 large-tile configuration (24, 25) [%lld %lld]",
+            return jamie_fail(-1, "%s: a_tr (A stored [K, M]) needs b_tr and a 128 x 128 large-tile configuration (24, 25, 29, 30) [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);
         if (s.partial && s.epi == JAMIE_EPI_STORE && (!V2 || d.splitk != 1))
             return jamie_fail(-1, "%s: sum-of-squares partials of a plain store need a large-tile configuration and splitk == 1 [%lld %lld]",
@@ -921,10 +921,10 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
-static const int BT[29][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
+static const int BT[33][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
                               {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128},
                               {64, 64}, {128, 128}, {256, 128}, {256, 128}, {64, 64},
-                              {256, 128}, {128, 128}, {128, 128}, {128, 256}, {64, 64}, {256, 256}};
+                              {256, 128}, {128, 128}, {128, 128}, {128, 256}, {64, 64}, {256, 256}, {128, 128}, {128, 128}, {256, 128}, {128, 128}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
@@ -989,13 +989,17 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         case 26: return launch_dma<128, 256, 2, 4, 3, 0, 1>(pr, count, st);
         case 27: return launch_dma<64, 64, 2, 2, 3, 0, 1>(pr, count, st);
         case 28: return launch_dma<256, 256, 4, 4, 2, 0, 1>(pr, count, st);
+        case 29: return launch_dma<128, 128, 2, 4, 2, 0, 1>(pr, count, st);      // 8 waves of 64x32, 2 buffers
+        case 30: return launch_dma<128, 128, 4, 2, 2, 0, 1>(pr, count, st);      // 8 waves of 32x64, 2 buffers
+        case 31: return launch_dma<256, 128, 4, 4, 3, 0, 1>(pr, count, st);      // 16 waves of 64x32, 3 buffers
+        case 32: return launch_dma<128, 128, 2, 4, 3, 0, 1>(pr, count, st);      // 8 waves of 64x32, 3 buffers
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
 }
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, 1 << 30);
-    if (cfg > 28 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
+    if (cfg > 32 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
     *bm = BT[cfg][0]; *bn = BT[cfg][1];
     return 0;
 }

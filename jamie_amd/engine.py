@@ -41,9 +41,12 @@ def choose_splitk(M, N, K, bm=64, bn=64):
 #   rows launch  ([B, N_i] = [B, K_i] x [N_i, K_i]^T, forward and dX):  256x128 tiles when every N_i >= K_i (d -> 2d),
 #                 else 128x128; slices proportional to K_i such that the launch has ~one workgroup per CU
 #                 (config 2: (3, 2) slices -> 256 workgroups; 37.5 -> 30.5 us and 34.2 -> 26.7 us per launch)
-#   dW (+ dX) grouped launch: 128x128 tiles, two LDS buffers (two workgroups per CU); dX slices ~ K_i / 1000
-BF16_CFG_ROWS_WIDE, BF16_CFG_ROWS, BF16_CFG_DW = 23, 24, 25
-BF16_TILE = {23: (256, 128), 24: (128, 128), 25: (128, 128)}
+#   dW (+ dX) grouped launch: 128x128 tiles on 8 waves of 64x32 (cfg 29; +2.4 % end to end over 4 waves of 64x64, cfg 25),
+#                 two LDS buffers (two workgroups per CU); dX slices ~ K_i / 1000
+# (more waves per tile measured faster at equal tiles: 256x128 on 16 waves of 64x32 instead of 8 of 64x64: 26.8 -> 24.8 us per
+#  forward launch; 128x128 on 8 waves of 64x32 instead of 4 of 64x64: 25.1 -> 22.4 us forward, +2.4 % end to end backward)
+BF16_CFG_ROWS_WIDE, BF16_CFG_ROWS, BF16_CFG_DW = 31, 32, 29
+BF16_TILE = {23: (256, 128), 24: (128, 128), 25: (128, 128), 29: (128, 128), 30: (128, 128), 31: (256, 128), 32: (128, 128)}
 N_CU = 256
 
 
@@ -532,7 +535,7 @@ class TrainEngine:
         return self.gcfg.get('dw', -1) if big else -1
 
     def _dw_tr(self, lin):
-        return self.bf16 and self._dw_cfg(lin) in (24, 25)
+        return self.bf16 and self._dw_cfg(lin) in (24, 25, 29, 30, 32)
 
     def _dw_problem(self, i, dy_key, a_key, lin):
         w = self.ws[i]
