@@ -227,7 +227,7 @@ def main():
                 traffic = None
         if args.dtype == 'f32':
             achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128, 128, 32, 2, 4, true, true, true, 1> (Linear d<->2d forward '
+            roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1> (Linear d<->2d forward '
                                               'GEMM, both modalities in one launch; 4 launches/step)',
                     'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop,

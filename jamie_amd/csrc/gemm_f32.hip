@@ -723,6 +723,9 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
         case 4: return launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC>(pr, count, st);
         case 5: return launch_cfg<32, 128, 32, 1, 4, A_KC, B_KC>(pr, count, st);
         case 6: return launch_cfg<64, 64, 64, 2, 2, A_KC, B_KC>(pr, count, st);
+        case 10: return launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC>(pr, count, st);     // 8 waves of 32x32
+        case 11: return launch_cfg<128, 64, 32, 4, 2, A_KC, B_KC>(pr, count, st);     // 8 waves of 32x32
+        case 12: return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC>(pr, count, st);    // 16 waves of 32x32
         case 7: case 8: case 9:      // 64x64x32 LDS-DMA, 3 / 2 / 4 buffers (NT only; other layouts: the register-staged 64x64)
             if constexpr (A_KC && B_KC) {
                 return cfg == 7 ? launch_dma_nt<3>(pr, count, st) : cfg == 8 ? launch_dma_nt<2>(pr, count, st) : launch_dma_nt<4>(pr, count, st);
@@ -778,9 +781,10 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[10][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64}};
+    static const int T[13][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
+                                 {64, 128}, {128, 64}, {128, 128}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 9 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 12 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

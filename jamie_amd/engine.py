@@ -72,7 +72,7 @@ def plan_bf16_bwd(B, shapes):
     return BF16_CFG_DW, [int(max(1, min(round(K / 1000), 4, K // 256))) for (N, K) in shapes]
 
 
-F32_CFG_ROWS = 4            # 128x128x32 tile, 8 waves of 64x32 (gemm_f32.hip)
+F32_CFG_ROWS = 12           # 128x128x32 tile on 16 waves of 32x32 (gemm_f32.hip; 8 waves of 64x32, cfg 4, is 5-7 % slower)
 
 
 def plan_f32_rows(B, shapes, target=2 * N_CU):

@@ -27,11 +27,12 @@ def run(layout, shapes, sks, cfg, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms * 1e3, fl / ms / 1e9
-tests = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 2: [(3, 2)], 4: [(3, 2), (4, 3)]}),
-         ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 4), (6, 3), (7, 4), (7, 3)], 2: [(6, 3), (7, 4)]}),
-         ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 4), (6, 3), (7, 4)], 2: [(6, 4), (6, 3)]}),
-         ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 2: [(3, 2)]}),
-         ('TN dW 2dxd', nv.TN, [(2 * x, x, B) for x in d], {1: [(1, 1)], 4: [(1, 1)], 2: [(1, 1)], 0: [(1, 1)]})]
+tests = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 12: [(3, 2)]}),
+         ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 3)], 12: [(6, 3), (6, 4)]}),
+         ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 3)], 12: [(6, 3), (6, 4)]}),
+         ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 12: [(3, 2)]}),
+         ('TN dW 2dxd', nv.TN, [(2 * x, x, B) for x in d], {1: [(1, 1)], 12: [(1, 1)], 4: [(1, 1)]}),
+         ('TN dW dx2d', nv.TN, [(x, 2 * x, B) for x in d], {1: [(1, 1)], 12: [(1, 1)]})]
 for name, layout, shapes, plan in tests:
     for cfg, skl in plan.items():
         for sks in skl:
