@@ -265,12 +265,12 @@ class edModelVar:
     @staticmethod
     def _eval_cfg(n, nout, k):
         """fp32 GEMM tile for the eval path: many rows make these large, square-ish products, where the 128x128x32 tile
-        (8 waves) runs at 120-130 TFLOP/s against ~110 for the 64x64 default of the skinny training shapes
+        (16 waves of 32x32) runs at 120-130 TFLOP/s against ~110 for the 64x64 default of the skinny training shapes
         (tools/bench_gemm_sq.py, tools/bench_infer.py); JAMIE_EVAL_GEMM_CFG overrides (diagnostics)."""
         import os
         if 'JAMIE_EVAL_GEMM_CFG' in os.environ:
             return int(os.environ['JAMIE_EVAL_GEMM_CFG'])
-        return 4 if (n >= 2048 and nout >= 512 and k >= 512) else -1
+        return 12 if (n >= 2048 and nout >= 512 and k >= 512) else -1
 
     def _lin_bn_act(self, i, x, lin, bn):
         W, b = self.p[f'm{i}.{lin}.W'], self.p[f'm{i}.{lin}.b']
