@@ -57,16 +57,16 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
     }
 }
 
-template <int U>
-__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <int U, int T>
+__global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* partials, int n_partials,
                                                         const float* hyper, const uint64_t* state,
                                                         unsigned short* __restrict__ p_bf16,
                                                         const unsigned short* __restrict__ g_bf16) {
-    __shared__ float red[4];
+    __shared__ float red[T / 64];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
+    for (int i = threadIdx.x; i < n_partials; i += T) s += partials[i];
     s = block_sum(s, red);
     const float lr = hyper[8], b1 = hyper[9], b2 = hyper[10], eps = hyper[11], max_norm = hyper[12];
     const float gscale = hyper[13];
@@ -89,12 +89,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    for (long long i0 = (long long)blockIdx.x * (256 * U) + threadIdx.x; i0 < n4; i0 += (long long)gridDim.x * (256 * U)) {
+    for (long long i0 = (long long)blockIdx.x * (T * U) + threadIdx.x; i0 < n4; i0 += (long long)gridDim.x * (T * U)) {
         // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
         float4 pp[U], mm[U], vv[U], gg[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = i0 + u * 256;
+            const long long i = i0 + u * T;
             if (i < n4) {
                 pp[u] = p4[i]; mm[u] = m4[i]; vv[u] = v4[i];
                 if (g_bf16) {      // reduced gradient read straight from the bf16 message buffer (no fp32 copy-back pass)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = i0 + u * 256;
+            const long long i = i0 + u * T;
             if (i >= n4) continue;
             upd(pp[u].x, gg[u].x, mm[u].x, vv[u].x);
             upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
@@ -206,11 +206,12 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
                   ((uintptr_t)v % 16) == 0 && ((uintptr_t)g_bf16 % 8) == 0, "buffers must be 16-byte aligned (bf16 gradient: 8)");
     JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
     JAMIE_ARG(p_bf16 == nullptr || ((uintptr_t)p_bf16 % 8) == 0, "p_bf16 must be 8-byte aligned");
-    // one workgroup per CU, two float4 per thread and array in flight: fewer, longer streams keep more DRAM pages open
-    // (tools/bench_adam.py, 40.3 M parameters: 2048 workgroups x 1 float4 4.77 TB/s, 256 x 2 5.70-5.78 TB/s)
     long long need = (n / 4 + 511) / 512;
     const int grid = (int)(need < 1 ? 1 : (need > 256 ? 256 : need));
-    hipLaunchKernelGGL(clip_adam_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, partials,
+    // one workgroup per CU (fewer, longer streams keep more DRAM pages open: 2048 workgroups x 1 float4 4.8 TB/s), eight
+    // waves each with one float4 per array in flight: 5.8 TB/s where four waves x two float4 reached 5.0-5.2 on the slower
+    // boxes of the pool and 5.7 on the faster ones (tools/bench_adam.py; in the step 231 -> 209 us on a slow box)
+    hipLaunchKernelGGL((clip_adam_kernel<1, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n, partials,
                        n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16);
     return jamie_launch_status("jamie_clip_adam");
 }
