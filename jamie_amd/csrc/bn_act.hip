@@ -22,6 +22,14 @@
 #endif
 
 #define BN_CW 16
+// Strip order: a problem gets 8 * ceil(strips / 8) workgroups and workgroup lb handles strip (lb & 7) * q + (lb >> 3),
+// q = ceil(strips / 8): blocks are dealt round-robin over the 8 XCDs (lb & 7), so every XCD owns a CONTIGUOUS range of
+// strips.  Neighbouring strips share 128-byte lines (a strip is 64 bytes of an fp32 row, 32 bytes of a bf16 row): the
+// two halves of a line are then read through ONE L2 and the partial-line stores of neighbours merge there.
+__device__ __forceinline__ int bn_strip(int lb, int n_cols) {
+    const int nst = (n_cols + 15) / 16, q = (nst + 7) >> 3;
+    return (lb & 7) * q + (lb >> 3);
+}
 #define BN_RP 16
 #define BN_MAXR 32
 #define BN_OOB 0xFFFFFFF0u
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnFwdDev& P = g.p[pi];
     const int c = threadIdx.x % BN_CW, rp = threadIdx.x / BN_CW;
-    const int col = ((int)blockIdx.x - P.blk_begin) * BN_CW + c;
+    const int col = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW + c;
     const bool cok = col < P.N;
     const int B = P.B, N = P.N;
     const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnFwdGroup g, float p_d
         }
         if constexpr (CACHED) {
             if (P.out_bf || P.outT_bf)
-                strip_out_bf16(v, P.out_bf, P.outT_bf, tl, B, N, ((int)blockIdx.x - P.blk_begin) * BN_CW, c, rp, cok);
+                strip_out_bf16(v, P.out_bf, P.outT_bf, tl, B, N, bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW, c, rp, cok);
         }
     } else {
         for (int row = rp; row < B; row += BN_RP) {
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnBwdDev& P = g.p[pi];
     const int c = threadIdx.x % BN_CW, rp = threadIdx.x / BN_CW;
-    const int col = ((int)blockIdx.x - P.blk_begin) * BN_CW + c;
+    const int col = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW + c;
     const bool cok = col < P.N;
     const int B = P.B, N = P.N;
     const float mean = cok ? P.smean[col] : 0.f, invstd = cok ? P.sinvstd[col] : 0.f;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
         }
         if constexpr (CACHED) {
             if (P.dh_bf || P.dhT_bf)
-                strip_out_bf16(dyv, P.dh_bf, P.dhT_bf, tl, B, N, ((int)blockIdx.x - P.blk_begin) * BN_CW, c, rp, cok);
+                strip_out_bf16(dyv, P.dh_bf, P.dhT_bf, tl, B, N, bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW, c, rp, cok);
         }
     } else {
         if (cok)
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnFwdDev& P = g.p[pi];
     const int tid = threadIdx.x, cq = tid & 3, rp = tid >> 2;
-    const int col0 = ((int)blockIdx.x - P.blk_begin) * BN_CW, col = col0 + 4 * cq;
+    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW, col = col0 + 4 * cq;
     const bool cok = col < P.N;                       // N % 4 == 0: a quad is wholly in or out
     const int B = P.B, N = P.N, nslab = P.nslab;
     const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnBwdDev& P = g.p[pi];
     const int tid = threadIdx.x, cq = tid & 3, rp = tid >> 2;
-    const int col0 = ((int)blockIdx.x - P.blk_begin) * BN_CW, col = col0 + 4 * cq;
+    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW, col = col0 + 4 * cq;
     const bool cok = col < P.N;
     const int B = P.B, N = P.N, nslab = P.nslab;
     float mean[4] = {0.f, 0.f, 0.f, 0.f}, invstd[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
@@ -748,7 +756,7 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
         JAMIE_ARG(s.out || s.out_bf16 || s.outT_bf16, "no output requested");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.blk_begin = blocks;
-        blocks += (s.N + BN_CW - 1) / BN_CW;
+        blocks += 8 * (((s.N + BN_CW - 1) / BN_CW + 7) / 8);
         if (s.B > maxB) maxB = s.B;
         if (!s.mask && p_drop > 0.f) need_rng = true;
         if (s.N % 4 || s.slab_stride % 4 || (uintptr_t)s.h % 16 || (uintptr_t)s.out % 16 || (uintptr_t)s.mask % 4 ||
@@ -796,7 +804,7 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
         JAMIE_ARG(!s.skip_f32 || s.dh_bf16 || s.dhT_bf16, "skip_f32 without a bf16 output");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.accumulate = s.accumulate; d.blk_begin = blocks;
-        blocks += (s.N + BN_CW - 1) / BN_CW;
+        blocks += 8 * (((s.N + BN_CW - 1) / BN_CW + 7) / 8);
         if (s.B > maxB) maxB = s.B;
         if (!s.mask && p_drop > 0.f) need_rng = true;
         if (s.N % 4 || s.slab_stride % 4 || (uintptr_t)s.da % 16 || (uintptr_t)s.h % 16 || (uintptr_t)s.mask % 4 ||
