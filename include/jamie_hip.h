@@ -74,6 +74,9 @@ typedef struct {
     int a_tr;                   /* jamie_gemm_bf16 only, with b_tr: A is stored [K, M] row-major (lda >= M) -- dW = dy^T a
                                  * reads dy [B, out] and a [B, in] as the layers produced them, no transposed activation
                                  * copies; 128 x 128 large-tile configurations (24, 25) */
+    int store_nt;               /* non-temporal output stores (large-tile jamie_gemm_bf16 configurations, jamie_gemm_f32): for
+                                 * outputs that are next read much later, e.g. weight gradients (read by the optimiser after the
+                                 * whole backward pass) */
 } jamie_gemm_problem;
 
 /* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */

@@ -28,7 +28,7 @@ class GemmProblem(C.Structure):
                 ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('aux_ld', C.c_int),
                 ('splitk', C.c_int), ('slab_stride', C.c_longlong),
                 ('epi', C.c_int), ('accumulate', C.c_int),
-                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float), ('b_tr', C.c_int), ('a_tr', C.c_int)]
+                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float), ('b_tr', C.c_int), ('a_tr', C.c_int), ('store_nt', C.c_int)]
 
 
 class CastProblem(C.Structure):
@@ -284,9 +284,9 @@ def require_gpu():
 # ---------------------------------------------------------------------------------------------------
 def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_stride=0, epi=EPI_STORE,
                  accumulate=False, aux=(None, None, None, None), aux_ld=0, partial=None, a_rows=None,
-                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0, b_tr=False, a_tr=False):
+                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0, b_tr=False, a_tr=False, store_nt=False):
     p = GemmProblem()
-    p.b_tr, p.a_tr = int(b_tr), int(a_tr)
+    p.b_tr, p.a_tr, p.store_nt = int(b_tr), int(a_tr), int(store_nt)
     p.A, p.B, p.C, p.bias = ptr(A), ptr(B), ptr(Cout), ptr(bias)
     p.aux0, p.aux1, p.aux2, p.aux3 = (ptr(a) for a in aux)
     p.partial, p.a_rows = ptr(partial), ptr(a_rows)

@@ -35,6 +35,7 @@ struct GemmBDev {
     int epi, accumulate, vec;
     int b_tr;            // B is [K, N] row-major (N contiguous): staged as [k][n] rows, fragments by ds_read_b64_tr_b16
     int a_tr;            // A is [K, M] row-major (M contiguous), likewise (dW = dy^T a reads dy [B, out] and a [B, in])
+    int store_nt;        // non-temporal output stores (weight gradients: next read by the optimiser, a whole backward pass later)
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -785,7 +786,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                     local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
                 }
-                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                if (P.store_nt) {     // streamed past the caches: plain stores left 161 MB of dirty gradient lines per step in
+                                      // L2 / Infinity Cache, whose write-back ran into the optimiser kernel (229 -> 208 us)
+                    __builtin_nontemporal_store(v[0], cp); __builtin_nontemporal_store(v[1], cp + 1);
+                    __builtin_nontemporal_store(v[2], cp + 2); __builtin_nontemporal_store(v[3], cp + 3);
+                } else {
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -877,7 +884,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
-        d.b_tr = s.b_tr; d.a_tr = s.a_tr;
+        d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt;
         if (s.a_tr && !(V2 && BM == 128 && BN == 128 && s.b_tr))
             return jamie_fail(-1, "%s: a_tr (A stored [K, M]) needs b_tr and a 128 x 128 large-tile configuration (24, 25, 29, 30) [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);

@@ -45,7 +45,7 @@ struct GemmDev {
     long long slab_stride;
     int M, N, K, lda, ldb, ldc, aux_ld;
     int splitk, kchunk, tiles_m, tiles_n, tile_begin, n_tiles;
-    int epi, accumulate, a_vec, b_vec;
+    int epi, accumulate, a_vec, b_vec, store_nt;
     unsigned a_bytes, b_bytes;
     float scale, slope, eps, pscale;
 };
@@ -368,7 +368,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
                 float* cp = Cout + (long long)m * P.ldc + n;
                 if (P.epi == JAMIE_EPI_STORE) {
                     if (P.accumulate) v += *cp;
-                    *cp = v;
+                    if (P.store_nt) __builtin_nontemporal_store(v, cp);     // weight gradients: see gemm_bf16.hip
+                    else *cp = v;
                 } else if (P.epi == JAMIE_EPI_MSE) {
                     const float d = v - P.aux0[(long long)m * P.aux_ld + n];
                     local += d * d;
@@ -590,7 +591,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
                 float* cp = Cout + (long long)m * P.ldc + n;
                 if (P.epi == JAMIE_EPI_STORE) {
                     if (P.accumulate) v += *cp;
-                    *cp = v;
+                    if (P.store_nt) __builtin_nontemporal_store(v, cp);     // weight gradients: see gemm_bf16.hip
+                    else *cp = v;
                 } else if (P.epi == JAMIE_EPI_MSE) {
                     const float d = v - P.aux0[(long long)m * P.aux_ld + n];
                     local += d * d;
@@ -639,7 +641,7 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.tiles_m = (s.M + BM - 1) / BM;
         d.tiles_n = (s.N + BN - 1) / BN;
         d.tile_begin = tiles;
-        d.epi = s.epi; d.accumulate = s.accumulate;
+        d.epi = s.epi; d.accumulate = s.accumulate; d.store_nt = s.store_nt;
         d.a_vec = ((s.lda % 4) == 0 && ((uintptr_t)s.A % 16) == 0) ? 1 : 0;
         d.b_vec = ((s.ldb % 4) == 0 && ((uintptr_t)s.B % 16) == 0) ? 1 : 0;
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
@@ -692,7 +694,7 @@ static int launch_dma_nt(const jamie_gemm_problem* pr, int count, hipStream_t st
         d.tiles_m = (s.M + BM - 1) / BM;
         d.tiles_n = (s.N + BN - 1) / BN;
         d.tile_begin = tiles;
-        d.epi = s.epi; d.accumulate = s.accumulate;
+        d.epi = s.epi; d.accumulate = s.accumulate; d.store_nt = s.store_nt;
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;

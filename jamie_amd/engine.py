@@ -521,7 +521,8 @@ class TrainEngine:
             if self.bf16:
                 probs.append(self._dw_problem(i, dy_key, a_key, lin))
             else:
-                probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate))
+                probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate,
+                                             store_nt=True))
         if self.bf16:
             nv.gemm_bf16(probs, self._dw_cfg(lin))
         else:
@@ -538,15 +539,19 @@ class TrainEngine:
         return self.bf16 and self._dw_cfg(lin) in (24, 25, 29, 30, 32)
 
     def _dw_problem(self, i, dy_key, a_key, lin):
+        # store_nt: the weight gradient is next read by the optimiser, a whole backward pass later; stored through the caches
+        # its 161 MB per step stayed behind as dirty lines whose write-back ran into the following kernels (bench.py, bf16:
+        # 670 -> 706 k cells/s, clip + Adam 228 -> 208 us; no effect on the dword stores of the fp32 kernel)
         w = self.ws[i]
         dW = self.g[f'm{i}.{lin}.W']
         nout, nin = dW.shape
         if self._dw_tr(lin):      # dy [B, out], a [B, in] row-major as produced: no transposed copies
             return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], dW, nout, nin, self.B, nout, nin, nin,
-                                   accumulate=self.accumulate, partial=self._dw_partial(i, lin), a_tr=True, b_tr=True)
+                                   accumulate=self.accumulate, partial=self._dw_partial(i, lin), a_tr=True, b_tr=True,
+                                   store_nt=True)
         # (dy^T) (a^T)^T on the [features, B] copies, K (= batch) contiguous
         return nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
-                               accumulate=self.accumulate, partial=self._dw_partial(i, lin))
+                               accumulate=self.accumulate, partial=self._dw_partial(i, lin), store_nt=True)
 
     def _dw_partial(self, i, lin):
         """Slice of `norm_partials` the dW launch of m{i}.{lin} fills (None: the separate norm kernel reads the gradient)."""
