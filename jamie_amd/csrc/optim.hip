@@ -142,9 +142,9 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
 }
 
 // Sum of squares over a list of ranges of the gradient buffer (the parameters whose producers do not emit partial sums
-// themselves: biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices), one chunk of <= 16384
+// themselves: biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices), one chunk of <= 4096
 // elements per workgroup; also advances the step counter, as jamie_grad_sqnorm does.
-#define JAMIE_SQ_CHUNK 16384
+#define JAMIE_SQ_CHUNK 4096
 struct SqRanges { long long off[128]; int len[128]; };
 __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, SqRanges r, float* partials,
                                                                  uint64_t* state) {
@@ -176,7 +176,7 @@ extern "C" int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets
     for (int i = 0; i < count; ++i) {
         JAMIE_ARG(offsets[i] >= 0 && lengths[i] >= 0, "negative range");
         for (long long o = 0; o < lengths[i]; o += JAMIE_SQ_CHUNK) {
-            JAMIE_ARG(nb < 128, "more than 128 chunks of 16384 elements");
+            JAMIE_ARG(nb < 128, "more than 128 chunks of 4096 elements");
             r.off[nb] = offsets[i] + o;
             r.len[nb] = (int)(lengths[i] - o < JAMIE_SQ_CHUNK ? lengths[i] - o : JAMIE_SQ_CHUNK);
             ++nb;
