@@ -148,16 +148,19 @@ def main():
 
     n_cells, dims, L = CONFIGS[args.config]
     B = args.batch
-    if args.dtype == 'bf16' and any(v % 8 for v in list(dims) + [L, B]):
-        args.dtype = 'f32'          # bf16 operands need multiples of 8 (config 1 has 100 features): fp32 path
+    if args.dtype == 'bf16' and any(v % 8 for v in [L, B]):
+        args.dtype = 'f32'          # bf16 operands need a latent size and a batch that are multiples of 8
+    # feature counts that are not multiples of 8 (config 1: 100, config 4: 500): the bf16 engine pads them (model.py)
+    pad = 8 if (args.dtype == 'bf16' and any(d % 8 for d in dims)) else 1
     lo, hi = jd.shard_bounds(n_cells, rank, world)
     data = synth_shard(hi - lo, dims, 1000 + rank, dev)
     torch.manual_seed(666)
-    model = edModelVar(dims, L, device=dev)
+    model = edModelVar(dims, L, device=dev, pad_features=pad)
     if world > 1:
         jd.broadcast_flat(model.flat)
     eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype,
                       dx_from_weights=not args.transposed_weight_copies, skinny_tr=args.skinny_tr)
+    data = eng.pad_cells(data)
     # gradient exchange in the compute precision: bf16 messages in bf16 mode (80 MB instead of 161 MB per step), fp32 otherwise
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
     allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm) if world > 1 else None

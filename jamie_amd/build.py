@@ -1,11 +1,17 @@
-"""Build libjamie_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libjamie_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every `csrc/*.hip` is compiled to its own object under `csrc/_obj/` (in parallel, only when the source or a header
+is newer) and the objects are linked into `libjamie_hip.so`."""
 import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(_HERE, 'libjamie_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 
 def library_path():
@@ -16,14 +22,32 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
-def build_library(force=False, verbose=False):
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else -1.0
+
+
+def build_library(force=False, verbose=False, jobs=None):
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(_HERE, '..', 'include', '*.h'))
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in deps):
-        return LIB
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(_HERE, '..', 'include', '*.h'))
+    hnew = max([_mtime(h) for h in headers] + [_mtime(__file__)])
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', LIB] + srcs
+    extra = os.environ.get('JAMIE_HIPCC_FLAGS', '').split()
+    os.makedirs(OBJ, exist_ok=True)
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in srcs]
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or extra or _mtime(o) < max(_mtime(s), hnew)]
+    if not todo and _mtime(LIB) >= max(_mtime(o) for o in objs):
+        return LIB
+
+    def cc(so):
+        cmd = [hipcc] + FLAGS + extra + ['-c', so[0], '-o', so[1]]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(cc, todo))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB

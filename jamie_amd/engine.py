@@ -113,12 +113,16 @@ class TrainEngine:
         self.m = model
         self.dev = model.device
         self.B = B = int(batch_size)
-        self.dims = model.input_dim
+        # the feature counts the kernels see (model.pdims: rounded up when the model was built with pad_features) and the
+        # model's own (rdims: the reconstruction loss is a mean over the REAL features; the padding contributes exact zeros)
+        self.dims = list(getattr(model, 'pdims', model.input_dim))
+        self.rdims = list(model.input_dim)
         self.M = len(self.dims)
         self.L = L = model.output_dim
         self.p_drop = model.dropout
         if self.bf16 and any(v % 8 for v in list(self.dims) + [L, B]):
-            raise ValueError('bf16 compute needs feature counts, latent size and batch size that are multiples of 8')
+            raise ValueError('bf16 compute needs feature counts, latent size and batch size that are multiples of 8 '
+                             '(build the model with pad_features=8 for other feature counts)')
         self.cosine = dist_method == 'cosine'
         if dist_method not in ('euclidean', 'cosine'):
             raise ValueError("dist_method must be 'euclidean' or 'cosine' (jamie.py:483-502)")
@@ -433,7 +437,12 @@ class TrainEngine:
     def _mask(self, noise, kind, i, j):
         if noise is None or self.p_drop == 0:
             return None
-        return noise[kind][i][j]
+        m = noise[kind][i][j]
+        width = self.dims[i] * (2 if (kind == 'enc_masks') == (j == 0) else 1)
+        if m is not None and m.shape[1] != width:        # explicit masks (parity tests) of a padded model
+            m = torch.nn.functional.pad(m, (0, width - m.shape[1])).contiguous()
+            noise[kind][i][j] = m
+        return m
 
     def _bn_fwd(self, layer, h_key, out_key, stream_base, noise, kind, j):
         probs = []
@@ -657,10 +666,22 @@ class TrainEngine:
             nv.record_callable(fn)
             fn()
 
+    def pad_cells(self, data):
+        """[N, d_i] cell matrices -> [N, pdims_i] (zero columns appended) when the model is padded; else unchanged."""
+        return [x if x.shape[1] == d else torch.nn.functional.pad(x, (0, d - x.shape[1])).contiguous()
+                for x, d in zip(data, self.dims)]
+
+    def grad_view(self, name):
+        """The gradient of parameter tensor `name` without the padding."""
+        return self.m.layout.unpad(name, self.g[name])
+
     def set_batch(self, X):
         """Use the given [B, d_i] fp32 matrices as the batch (tests; the training loop uses `load_batch`)."""
         for i in range(self.M):
-            self.ws[i]['x'].copy_(X[i])
+            x = self.ws[i]['x']
+            if X[i].shape[1] != x.shape[1]:
+                x.zero_()
+            x[:, :X[i].shape[1]].copy_(X[i])
         self._cast('x')
         if self.bf16 and self._wT_stale:
             self.refresh_weights_bf16(transposes_only=True)
@@ -730,9 +751,10 @@ class TrainEngine:
             probs, off = [], 0
             for i, d in enumerate(self.dims):
                 w = self.ws[i]
+                rd = self.rdims[i]
                 probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w.get('dxhat_bf'), w['dxhat_T'] if 'dxhat' in self.need_T else None,
                                             partial=self.rec_partials[off:off + self.rec_tiles[i]],
-                                            scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
+                                            scale=self.loss_weights[1] * 2.0 / (B * rd), pscale=1.0 / (B * rd)))
                 off += self.rec_tiles[i]
             nv.mse_cast(probs)
             return lat
@@ -744,7 +766,8 @@ class TrainEngine:
                                          w['dxhat'], B, d, 2 * d, 2 * d, 2 * d, d,
                                          bias=P[f'm{i}.dec2.b'], epi=nv.EPI_MSE, aux=(w['x'], None, None, None),
                                          aux_ld=d, partial=self.rec_partials[off:off + self.rec_tiles[i]],
-                                         scale=self.loss_weights[1] * 2.0 / (B * d), pscale=1.0 / (B * d)))
+                                         scale=self.loss_weights[1] * 2.0 / (B * self.rdims[i]),
+                                         pscale=1.0 / (B * self.rdims[i])))
             off += self.rec_tiles[i]
         self._wait_params('dec2')
         self._launch('enc_gemm', (lambda: nv.gemm_bf16(probs)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT)))

@@ -2,9 +2,9 @@
 for the coupled-VAE path: `fit_transform` / `fit`, `transform`, `transform_one`, `modal_predict` /
 `impute`, `save_model`, `load_model`, `loss_history`.
 
-Scope: `project_mode='jamie'` with the correspondence `F` either absent (`use_f_tilde=False`) or supplied
-as `match_result`.  Stage A (`compute_distances`, jamie.py:839-890) and stage B (`match`/`Prime_Dual`,
-jamie.py:224-414) are dense O(N^2)/O(N^3) preprocessing outside this hot path; asking for them raises.
+Scope: `project_mode='jamie'`.  The correspondence `F` is absent (`use_f_tilde=False`), supplied as `match_result`, or
+computed like the reference does: stage A (`compute_distances`, jamie.py:839-890) on the host and stage B
+(`match` / `Prime_Dual`, jamie.py:224-414) on the GPU (jamie_amd/correspondence.py).
 Unlike the reference no N x N matrix is ever formed when `P` is the identity (the reference's default for
 equally sized datasets, jamie.py:425-426): the B x B block `P[idx][:, idx]` is index equality.
 """
@@ -310,9 +310,12 @@ class JAMIE:
             self.dataset = [p.transform(np.asarray(x)) for p, x in zip(pre, self.dataset)]
         self.col = [x.shape[1] for x in self.dataset]
         # ---- model / engine ----
+        extra = {}
+        if self.compute_dtype == 'bf16' and self.model_class is edModelVar and any(c % 8 for c in self.col):
+            extra['pad_features'] = 8        # bf16 GEMM operands need feature counts that are multiples of 8 (model.py)
         self.model = self.model_class(self.col, self.output_dim, preprocessing=[p.transform for p in pre],
                                       preprocessing_inverse=[p.inverse_transform for p in pre],
-                                      dropout=self.dropout).to(self.device)
+                                      dropout=self.dropout, **extra).to(self.device)
         if world > 1:
             jd.broadcast_flat(self.model.flat)
         self.model.train()
@@ -332,6 +335,7 @@ class JAMIE:
                           world_size=world, compute_dtype=self.compute_dtype)
         eng.accumulate = False
         self.engine = eng
+        data = eng.pad_cells(data)
         rep = min(self.col) < B and self.dataset_num == 2                    # jamie.py:553 (sic); M > 2: never
         need_block = ((method == 'diag' and rep) or method == 'zeros' or F_dense is not None or P_dense is not None
                       or P_csr is not None)

@@ -39,18 +39,24 @@ class ParamLayout:
     The two heads of a modality are adjacent so that mu and logvar come out of one GEMM.
     """
 
-    def __init__(self, input_dim, output_dim):
+    def __init__(self, input_dim, output_dim, real_dim=None):
+        """`input_dim`: the feature counts the kernels see; `real_dim` (default: the same) the model's own feature counts
+        when `input_dim` is padded (edModelVar(pad_features=8)): every tensor then holds its real block in the leading
+        rows / columns (`real[name]` = that block's shape) and zeros elsewhere."""
         self.input_dim = list(input_dim)
+        self.real_dim = list(input_dim) if real_dim is None else list(real_dim)
         self.L = output_dim
         self.M = len(input_dim)
         self.entries = OrderedDict()
+        self.real = OrderedDict()
         off = 0
         L = output_dim
 
-        def add(name, *shape):
+        def add(name, shape, real_shape=None):
             nonlocal off
             n = int(np.prod(shape))
             self.entries[name] = (off, tuple(shape))
+            self.real[name] = tuple(shape if real_shape is None else real_shape)
             off += _align4(n)
 
         # layer-major order: the backward pass finishes layers from the END of the buffer towards the start,
@@ -66,20 +72,23 @@ class ParamLayout:
         for lname, spec in layers:
             start = off
             if lname == 'head':
-                add('sigma', self.M)          # sigma's gradient is produced with the heads' (latent backward)
+                add('sigma', (self.M,))       # sigma's gradient is produced with the heads' (latent backward)
             for i, d in enumerate(input_dim):
-                for nm, shape in spec(d):
-                    add(f'm{i}.{nm}', *shape)
+                for (nm, shape), (_, rshape) in zip(spec(d), spec(self.real_dim[i])):
+                    add(f'm{i}.{nm}', shape, rshape)
             self.regions[lname] = (start, off)
         self.total = off
         # BN running statistics (not optimised): separate flat buffer
         self.bn_entries = OrderedDict()
         boff = 0
         for i, d in enumerate(input_dim):
-            for k, n in (('bn0', 2 * d), ('bn1', d), ('bn2', d), ('bn3', 2 * d)):
+            r = self.real_dim[i]
+            for k, n, nr in (('bn0', 2 * d, 2 * r), ('bn1', d, r), ('bn2', d, r), ('bn3', 2 * d, 2 * r)):
                 self.bn_entries[f'm{i}.{k}.mean'] = (boff, (n,)); boff += _align4(n)
                 self.bn_entries[f'm{i}.{k}.var'] = (boff, (n,)); boff += _align4(n)
+                self.real[f'm{i}.{k}.mean'] = self.real[f'm{i}.{k}.var'] = (nr,)
         self.bn_total = boff
+        self.padded = self.input_dim != self.real_dim
 
     def views(self, flat):
         return {k: flat[o:o + int(np.prod(s))].view(*s) for k, (o, s) in self.entries.items()}
@@ -88,8 +97,15 @@ class ParamLayout:
         return {k: flat[o:o + int(np.prod(s))].view(*s) for k, (o, s) in self.bn_entries.items()}
 
     def num_parameters(self):
-        """Reference count: sum_i(8d^2 + 3dL + 19d + 2L) + M."""
-        return sum(int(np.prod(s)) for _, s in self.entries.values())
+        """Reference count: sum_i(8d^2 + 3dL + 19d + 2L) + M; padding is not counted."""
+        return sum(int(np.prod(self.real[k])) for k in self.entries)
+
+    def unpad(self, name, t):
+        """The real block of (padded) tensor `t` of entry `name`."""
+        r = self.real[name]
+        if tuple(t.shape) == r:
+            return t
+        return t[tuple(slice(0, n) for n in r)]
 
     # ---- mapping to the reference's state_dict names (model.py:147-220) ----
     def reference_names(self):
@@ -166,7 +182,12 @@ class edModelVar:
     """
 
     def __init__(self, input_dim, output_dim, preprocessing=None, preprocessing_inverse=None, sigma=None,
-                 dropout=None, device='cuda'):
+                 dropout=None, device='cuda', pad_features=1):
+        """`pad_features=8` (what the bf16 compute mode needs when a feature count is not a multiple of 8, e.g. BASELINE
+        config 4's 500): the buffers are laid out for feature counts rounded up to that multiple (`pdims`); the padding
+        weights are zero and provably stay zero (a padded input column is 0, so a padded hidden unit's pre-activation is
+        constant 0, BatchNorm maps it to beta = 0, its outgoing weights are 0, hence every gradient in the padding is
+        exactly 0 and Adam leaves 0 at 0), so the model computes exactly what the unpadded one does."""
         nv.require_gpu()
         if not 2 <= len(input_dim) <= 4:
             raise NotImplementedError('2..4 modalities (the reference itself supports exactly two, jamie.py:420)')
@@ -180,27 +201,34 @@ class edModelVar:
             dropout = .6 if max(self.input_dim) > 64 else 0
         self.dropout = float(dropout)
         self.device = torch.device(device)
-        self.layout = ParamLayout(self.input_dim, self.output_dim)
+        pad = max(1, int(pad_features))
+        self.pdims = [(d + pad - 1) // pad * pad for d in self.input_dim]
+        self.layout = ParamLayout(self.pdims, self.output_dim, self.input_dim)
         self.training = True
         host = torch.zeros(self.layout.total)
         hv = self.layout.views(host)
         L = self.output_dim
-        # ---- reference construction order (RNG order) ----
+        # ---- reference construction order (RNG order); with padding the real block is filled, the rest stays 0 ----
+        def put(name, w, b):
+            hv[name + '.W'][:w.shape[0], :w.shape[1]] = w
+            hv[name + '.b'][:b.shape[0]] = b
         for i, d in enumerate(self.input_dim):
-            hv[f'm{i}.enc0.W'][:], hv[f'm{i}.enc0.b'][:] = _linear_init(2 * d, d)
-            hv[f'm{i}.enc1.W'][:], hv[f'm{i}.enc1.b'][:] = _linear_init(d, 2 * d)
+            put(f'm{i}.enc0', *_linear_init(2 * d, d))
+            put(f'm{i}.enc1', *_linear_init(d, 2 * d))
         for i, d in enumerate(self.input_dim):
-            hv[f'm{i}.head.W'][:L], hv[f'm{i}.head.b'][:L] = _linear_init(L, d)
+            w, b = _linear_init(L, d)
+            hv[f'm{i}.head.W'][:L, :d], hv[f'm{i}.head.b'][:L] = w, b
         for i, d in enumerate(self.input_dim):
-            hv[f'm{i}.head.W'][L:], hv[f'm{i}.head.b'][L:] = _linear_init(L, d)
+            w, b = _linear_init(L, d)
+            hv[f'm{i}.head.W'][L:, :d], hv[f'm{i}.head.b'][L:] = w, b
         for i, d in enumerate(self.input_dim):
-            hv[f'm{i}.dec0.W'][:], hv[f'm{i}.dec0.b'][:] = _linear_init(d, L)
-            hv[f'm{i}.dec1.W'][:], hv[f'm{i}.dec1.b'][:] = _linear_init(2 * d, d)
-            hv[f'm{i}.dec2.W'][:], hv[f'm{i}.dec2.b'][:] = _linear_init(d, 2 * d)
+            put(f'm{i}.dec0', *_linear_init(d, L))
+            put(f'm{i}.dec1', *_linear_init(2 * d, d))
+            put(f'm{i}.dec2', *_linear_init(d, 2 * d))
         hv['sigma'][:] = torch.rand(self.num_modalities)
         for i in range(self.num_modalities):
             for k in ('bn0', 'bn1', 'bn2', 'bn3'):
-                hv[f'm{i}.{k}.g'].fill_(1.0)
+                self.layout.unpad(f'm{i}.{k}.g', hv[f'm{i}.{k}.g']).fill_(1.0)
         self.flat = host.to(self.device)
         self.p = self.layout.views(self.flat)
         bn_host = torch.zeros(self.layout.bn_total)
@@ -235,10 +263,10 @@ class edModelVar:
     def state_dict(self):
         out = OrderedDict()
         for ref, (mine, sl) in self.layout.reference_names().items():
-            t = self.p[mine]
+            t = self.layout.unpad(mine, self.p[mine])
             out[ref] = (t if sl is None else t[sl]).detach().clone()
         for ref, mine in self.layout.reference_bn_names().items():
-            out[ref] = self.bn[mine].detach().clone()
+            out[ref] = self.layout.unpad(mine, self.bn[mine]).detach().clone()
         for i in range(self.num_modalities):
             for pre in (f'encoders.{i}.1', f'encoders.{i}.5', f'decoders.{i}.1', f'decoders.{i}.5'):
                 out[pre + '.num_batches_tracked'] = torch.tensor(self.num_batches_tracked)
@@ -248,10 +276,11 @@ class edModelVar:
         names = self.layout.reference_names()
         for ref, (mine, sl) in names.items():
             src = torch.as_tensor(sd[ref]).to(self.device, torch.float32)
-            (self.p[mine] if sl is None else self.p[mine][sl]).copy_(src)
+            dst = self.layout.unpad(mine, self.p[mine])
+            (dst if sl is None else dst[sl]).copy_(src)
         for ref, mine in self.layout.reference_bn_names().items():
             if ref in sd:
-                self.bn[mine].copy_(torch.as_tensor(sd[ref]).to(self.device, torch.float32))
+                self.layout.unpad(mine, self.bn[mine]).copy_(torch.as_tensor(sd[ref]).to(self.device, torch.float32))
         for k, v in sd.items():
             if k.endswith('num_batches_tracked'):
                 self.num_batches_tracked = int(v)
@@ -274,9 +303,9 @@ class edModelVar:
 
     def _lin_bn_act(self, i, x, lin, bn):
         W, b = self.p[f'm{i}.{lin}.W'], self.p[f'm{i}.{lin}.b']
-        n, k = x.shape[0], x.shape[1]
+        n, k = x.shape[0], x.shape[1]          # k = W.shape[1], or the real feature count of a padded first layer
         out = torch.empty(n, W.shape[0], device=self.device)
-        pr = nv.gemm_problem(x, W, out, n, W.shape[0], k, k, k, W.shape[0], bias=b, epi=nv.EPI_BN_EVAL,
+        pr = nv.gemm_problem(x, W, out, n, W.shape[0], k, k, W.stride(0), W.shape[0], bias=b, epi=nv.EPI_BN_EVAL,
                              aux=(self.bn[f'm{i}.{bn}.mean'], self.bn[f'm{i}.{bn}.var'],
                                   self.p[f'm{i}.{bn}.g'], self.p[f'm{i}.{bn}.b']),
                              slope=LRELU_SLOPE, eps=BN_EPS)
@@ -286,7 +315,8 @@ class edModelVar:
     def _linear(self, x, W, b):
         n, k = x.shape[0], x.shape[1]
         out = torch.empty(n, W.shape[0], device=self.device)
-        nv.gemm([nv.gemm_problem(x, W, out, n, W.shape[0], k, k, k, W.shape[0], bias=b)], nv.NT, self._eval_cfg(n, W.shape[0], k))
+        nv.gemm([nv.gemm_problem(x, W, out, n, W.shape[0], k, k, W.stride(0), W.shape[0], bias=b)], nv.NT,
+                self._eval_cfg(n, W.shape[0], k))
         return out
 
     def _encode_eval(self, i, x):
@@ -300,7 +330,8 @@ class edModelVar:
     def _decode_eval(self, i, z):
         h = self._lin_bn_act(i, self._dev(z), 'dec0', 'bn2')
         h = self._lin_bn_act(i, h, 'dec1', 'bn3')
-        return self._linear(h, self.p[f'm{i}.dec2.W'], self.p[f'm{i}.dec2.b'])
+        out = self._linear(h, self.p[f'm{i}.dec2.W'], self.p[f'm{i}.dec2.b'])
+        return out if not self.layout.padded else out[:, :self.input_dim[i]]
 
     def embed(self, x, i, chunk=65536):
         """fc_mus[i](encoders[i](x)) streamed over row chunks (no N x N `corr`)."""

@@ -46,3 +46,5 @@ for ref, (mine, sl) in names.items():
     nrm = g64.norm().item() + 1e-300
     print(f'{ref:28s} {g64.abs().max().item():10.3e} {(got - g64).norm().item() / nrm:10.3e} '
           f'{(g32 - g64).norm().item() / nrm:10.3e} {(got - g64).abs().max().item():11.3e} {(g32 - g64).abs().max().item():11.3e}')
+tot = lambda d: float(torch.sqrt(sum((g.double() ** 2).sum() for g in d.values())))      # noqa: E731
+print('||g||: hip', float(eng.grad.double().norm()), ' o32', tot(s32['grads']), ' o64', tot(s64['grads']))
