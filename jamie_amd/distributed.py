@@ -147,3 +147,20 @@ def broadcast_flat(flat, src=0, group=None):
     """Make every rank start from rank `src`'s parameters."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+def average_(t, group=None):
+    """In-place mean over the ranks (BatchNorm running statistics before evaluation / checkpoints)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t
+
+
+def mean_scalar(value, device, group=None):
+    """Mean of a host scalar over the ranks (rank-invariant early-stop decision)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)

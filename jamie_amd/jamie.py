@@ -117,6 +117,9 @@ class JAMIE:
         self.model = None
         self.engine = None
         self.loss_history = {}
+        # test seam: callable(step_number) -> {'eps', 'enc_masks', 'dec_masks'} device tensors fed to the step instead of
+        # the Philox streams, so that the loop users call can be replayed against the reference's fixtures
+        self._noise_source = None
 
     # ------------------------------------------------------------------------------------------
     def fit_transform(self, dataset=None, P=None, resume_from=None):
@@ -132,7 +135,7 @@ class JAMIE:
         assert self.model_pca in ('pca', 'umap')
         if self.project_mode == 'tsne':
             raise NotImplementedError("project_mode='tsne' is outside the accelerated path (SURVEY.md §8)")
-        time = time_logger(sync=torch.cuda.synchronize)
+        time = time_logger(memory_usage=self.enable_memory_logging, sync=torch.cuda.synchronize)   # jamie.py:141
         init_random_seed(self.manual_seed)                         # jamie.py:142
         self.dataset = dataset
         self.dataset_annotation = None
@@ -253,8 +256,6 @@ class JAMIE:
             if Pc.shape[0] == Pc.shape[1] and Pc.nnz == Pc.shape[0] and bool((Pc.diagonal() == 1).all()):
                 method = 'diag'
             elif Pc.nnz and float(np.abs(Pc.data).sum()) != 0:
-                if world > 1:
-                    raise NotImplementedError('hybrid sampling (partial correspondence) is single-process')
                 method = 'hybrid'                                             # corrected sampler, see the dense branch
                 coo = Pc.tocoo()
                 keep = coo.data > 0
@@ -275,8 +276,6 @@ class JAMIE:
                 # `num_corr = len(corr_samples[0])` (== 2, the pair width) and indexes `corr_samples[i]` (the i-th
                 # pair) per modality, so it never samples the known pairs as intended; here num_corr is the number
                 # of known pairs and column i of the pair list feeds modality i.
-                if world > 1:
-                    raise NotImplementedError('hybrid sampling with a dense P is single-process')
                 method = 'hybrid'
                 self.corr_samples = np.argwhere(np.asarray(self.P) > 0)
                 self.num_corr = len(self.corr_samples)
@@ -289,7 +288,10 @@ class JAMIE:
             mr = self.match_result[0]
             F_dense = (mr.to(dev, torch.float32) if torch.is_tensor(mr)
                        else torch.as_tensor(np.asarray(mr), dtype=torch.float32, device=dev))
-        timer = time_logger(sync=torch.cuda.synchronize)
+        timer = time_logger(memory_usage=self.enable_memory_logging, sync=torch.cuda.synchronize)    # jamie.py:433
+        # per-step labels of the reference ('Get subset samples', 'Step'; jamie.py:601, 742): a synchronising timer inside
+        # the loop would block the host twice per step, so it only runs when `debug` asks for the per-phase table
+        step_timer = timer if self.debug else time_logger(record=False)
         # ---- preprocessing (host, numpy/sklearn like the reference) ----
         dev_pre = self.preprocess == 'device' and (self.pca_dim is None or all(dm is None for dm in self.pca_dim))
         if dev_pre:
@@ -324,11 +326,24 @@ class JAMIE:
         bounds = [jd.shard_bounds(r, rank, world) for r in self.row]
         data = [d[lo:hi].to(dev).contiguous() for d, (lo, hi) in zip(data_all, bounds)]
         rows = [hi - lo for lo, hi in bounds]
-        len_dataloader = int(np.max(rows) / self.batch_size)                 # jamie.py:511-514
+        # every rank must run the same number of steps per epoch (each step is a collective) with the same batch size:
+        # both follow from the SMALLEST shard (shard sizes differ by at most one row), not from this rank's own
+        rows_all = [[b[1] - b[0] for b in (jd.shard_bounds(r, k, world) for r in self.row)] for k in range(world)]
+        len_dataloader = min(int(np.max(rk) / self.batch_size) for rk in rows_all)   # jamie.py:511-514
         if len_dataloader == 0:
             len_dataloader = 1
-            self.batch_size = int(np.max(rows))
+            self.batch_size = min(int(np.max(rk)) for rk in rows_all)
         B = int(self.batch_size)
+        if method == 'hybrid' and world > 1:
+            # data parallel partial correspondence: a rank samples the known pairs whose two cells both live in its row
+            # shards (contiguous shards of every modality; a pair that straddles two ranks is only reachable through the
+            # unpaired draws of its two cells); indices become shard-local
+            cs = self.corr_samples
+            keep = ((cs[:, 0] >= bounds[0][0]) & (cs[:, 0] < bounds[0][1]) & (cs[:, 1] >= bounds[1][0]) & (cs[:, 1] < bounds[1][1]))
+            self.corr_samples = cs[keep] - np.array([bounds[0][0], bounds[1][0]])
+            self.num_corr = len(self.corr_samples)
+            if self.num_corr == 0:
+                raise ValueError(f'rank {rank}: no known pair lies inside its row shards; shard paired cells together')
         self.PF_Ratio = 1 if self.PF_Ratio is None else self.PF_Ratio        # jamie.py:517
         eng = TrainEngine(self.model, B, lr=self.model_lr, loss_weights=self.loss_weights,
                           dist_method=self.dist_method, seed=int(self.manual_seed) + 7919 * rank,
@@ -376,6 +391,9 @@ class JAMIE:
             start_epoch, best_running_loss, streak = self._load_checkpoint(self._resume_from, eng)
             self._resume_from = None
         timer.log('Setup')
+        n_steps = start_epoch * len_dataloader
+        if self._noise_source is not None and (use_plan or plan_hybrid):
+            raise ValueError('explicit noise needs the eager path (sampler="numpy")')
         for epoch in range(start_epoch, self.epoch_DNN):                      # jamie.py:546
             eng.set_kl_anneal(kl_anneal(epoch, self.min_epochs, self.epoch_DNN))
             eng.reset_best()
@@ -442,15 +460,17 @@ class JAMIE:
                         corr = (self.PF_Ratio * Pb + (1 - self.PF_Ratio) * Fblk).contiguous()
                     else:
                         corr = (self.PF_Ratio * Pb).contiguous() if self.PF_Ratio != 1 else Pb
-                timer.log('Get subset samples')
+                step_timer.log('Get subset samples')
+                noise = None if self._noise_source is None else self._noise_source(n_steps)
+                n_steps += 1
                 if self.batch_step:
-                    eng.step(corr, Fblk, None, allreduce)
+                    eng.step(corr, Fblk, noise, allreduce)
                 else:
                     # jamie.py:734-749: every batch back-propagates into the same gradient buffers, ONE clip + Adam
                     # step per epoch; the gradient all-reduce rides on the last batch's backward
                     last = batch_idx == len_dataloader - 1
                     eng.accumulate = batch_idx > 0
-                    eng.forward_backward(corr, Fblk, None, allreduce if last else None)
+                    eng.forward_backward(corr, Fblk, noise, allreduce if last else None)
                     epoch_sum += eng.losses[4]
                     if not last:
                         eng.state[0] += 1          # the Philox step only advances with the optimiser: fresh noise per batch
@@ -461,7 +481,7 @@ class JAMIE:
                             allreduce.finish() if hasattr(allreduce, 'finish') else allreduce(eng.grad)
                         eng.accumulate = False
                         eng.optimizer_step()
-                timer.log('Step')
+                step_timer.log('Step')
             # ---- per-epoch bookkeeping (one device read per epoch; jamie.py:751-792) ----
             ls, total, best_batch_loss = eng.read_losses()
             if not self.batch_step:                    # jamie.py:778-781: the early-stop criterion is the epoch loss
@@ -475,6 +495,11 @@ class JAMIE:
             if (epoch + 1) % self.log_DNN == 0:
                 print(f'epoch:[{epoch + 1:d}/{self.epoch_DNN}]: loss:{total:4f}')
             if epoch > self.min_epochs:
+                if world > 1:
+                    # the ranks train on different shards, so their losses differ; the stop decision must not (a rank that
+                    # left the loop would leave the others waiting in the gradient all-reduce): mean over ranks, one scalar
+                    # per epoch, outside the step
+                    best_batch_loss = jd.mean_scalar(best_batch_loss, dev)
                 if best_running_loss - best_batch_loss > self.min_increment:
                     best_running_loss = best_batch_loss
                     streak = 0
@@ -482,8 +507,15 @@ class JAMIE:
                     streak += 1
                 if streak >= self.max_steps_without_increment and self.use_early_stop:
                     break
-            if self.checkpoint_every and self.checkpoint_path and (epoch + 1) % self.checkpoint_every == 0 and rank == 0:
-                self.save_checkpoint(self.checkpoint_path, epoch + 1, best_running_loss, streak)
+            if self.checkpoint_every and self.checkpoint_path and (epoch + 1) % self.checkpoint_every == 0:
+                if world > 1:
+                    jd.average_(self.model.bn_flat)
+                if rank == 0:
+                    self.save_checkpoint(self.checkpoint_path, epoch + 1, best_running_loss, streak)
+        if world > 1:
+            # BatchNorm running statistics are per-rank during training (no SyncBN: one collective per step); the model
+            # that is evaluated / saved carries their average, so every rank returns the same embeddings
+            jd.average_(self.model.bn_flat)
         self.model.eval()
         out = [self.model.embed(data_all[i], i).cpu().numpy() for i in range(self.dataset_num)]   # jamie.py:794-799
         timer.log('Output')

@@ -1,5 +1,6 @@
 """Host-side helpers kept in Python, mirroring the reference's `jamie/utilities.py` for the hot path:
 `preclass` (utilities.py:654-678), `identity` (:48-50) and `time_logger` (:61-132)."""
+import tracemalloc
 from time import perf_counter
 import warnings
 
@@ -49,7 +50,10 @@ class preclass:
 
 class time_logger:
     """Phase timer with the reference's interface and labels (utilities.py:61-132).  `sync` is called
-    before each reading so that phases cover the GPU work they launched (HIP launches are asynchronous)."""
+    before each reading so that phases cover the GPU work they launched (HIP launches are asynchronous).
+    `memory_usage=True` (utilities.py:78-80, 98-111, 123-130): per phase the host memory traced by `tracemalloc`
+    (stored, peak) as in the reference, and next to it the device memory of this process (HBM allocated now / peak
+    since the previous reading) in `history_mem_device`."""
 
     def __init__(self, discard_first_sample=False, record=True, verbose=False, memory_usage=False, sync=None):
         self.discard_first_sample = discard_first_sample
@@ -58,7 +62,22 @@ class time_logger:
         self.memory_usage = memory_usage
         self.sync = sync
         self.history = {}
+        if memory_usage:
+            self.history_mem, self.history_mem_device = {}, {}
+            tracemalloc.start()
         self.start_time = perf_counter()
+
+    @staticmethod
+    def _device_memory():
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return (0, 0)
+            now, peak = torch.cuda.memory_allocated(), torch.cuda.max_memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
+            return (now, peak)
+        except Exception:
+            return (0, 0)
 
     def log(self, str=''):
         if not (self.verbose or self.record):
@@ -71,6 +90,15 @@ class time_logger:
             self.history.setdefault(str, []).append(elapsed)
         if self.verbose:
             print(f'{str}: {elapsed}')
+        if self.memory_usage:
+            host, device = tracemalloc.get_traced_memory(), self._device_memory()
+            if self.record:
+                self.history_mem.setdefault(str, []).append(host)
+                self.history_mem_device.setdefault(str, []).append(device)
+            if self.verbose:
+                print(f'{str} Memory: Stored {host[0]} - Peak {host[1]} (device: allocated {device[0]} - peak {device[1]})')
+            tracemalloc.stop()
+            tracemalloc.start()               # per-phase figures, like the reference
         self.start_time = perf_counter()
 
     def aggregate(self):
@@ -79,6 +107,11 @@ class time_logger:
             v = np.array(v[1:] if (self.discard_first_sample and len(v) > 1) else v)
             running_total += v.mean()
             print(f'{k}: {v.mean()}')
+            if self.memory_usage and k in self.history_mem:
+                stored = sum(val[0] for val in self.history_mem[k])
+                peak = max(val[1] for val in self.history_mem[k])
+                dpeak = max(val[1] for val in self.history_mem_device[k])
+                print(f'{k} Memory: Stored {stored} - Peak {peak} (device peak {dpeak})')
         print(f'Total: {running_total}')
 
 

@@ -7,7 +7,7 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['g1_onestep_p0', 'g2_onestep_p06', 'g3_multistep', 'g4_replace', 'g5_F_pfratio', 'g6_zeros',
-         'g7_cosine', 'g8_klquirk']
+         'g7_cosine', 'g8_klquirk', 'g9_earlystop']
 
 
 class Golden:

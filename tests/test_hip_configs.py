@@ -191,7 +191,7 @@ def test_config4_full_size_step_vs_generalised_oracle(jam, mode):
         for k, v in P.items():
             if not orc.is_dead_bias(k):
                 assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=2e-2,
-                                    rel_l2=1e-2 if v.dim() == 1 else 1e-4, msg=k)
+                                    rel_l2=1e-2 if v.dim() == 1 else 5e-4, msg=k)
         for k, v in Bf.items():
             if 'num_batches' not in k:
                 np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
@@ -311,7 +311,7 @@ def test_config5_dims_step_vs_oracle(jam):
     for k, v in P.items():
         if not orc.is_dead_bias(k):
             assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=2e-2,
-                                rel_l2=1e-2 if v.dim() == 1 else 1e-4, msg=k)
+                                rel_l2=1e-2 if v.dim() == 1 else 5e-4, msg=k)
 
 
 def test_config5_dims_bf16_step_runs_and_tracks_oracle_losses(jam):
@@ -409,3 +409,65 @@ def test_eval_more_rows_than_one_chunk_vs_oracle(jam):
     with torch.no_grad():
         ref_i = orc.impute(P, Bf, x[rows], 1, 0).numpy()
     np.testing.assert_allclose(imp[torch.from_numpy(rows).cuda()].cpu().numpy(), ref_i, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the loop users call, against the reference's fixtures
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['g3_multistep', 'g4_replace', 'g5_F_pfratio', 'g6_zeros', 'g7_cosine', 'g8_klquirk',
+                                  'g9_earlystop'])
+def test_facade_loop_replays_reference_fixture(jam, name):
+    """`JAMIE.fit_transform` itself (not the engine driven by the test) under `np.random.seed(meta.np_seed)` with the
+    fixture's dropout masks / eps fed through the facade's noise seam, against the reference run that produced the fixture
+    (jamie/jamie.py:546-583 sampler, :630-632 KL anneal per epoch, :729-731 best batch loss, :751-761 loss history,
+    :777-792 early stop, :794-804 output):
+      * the sampler's index stream equals the reference's `np.random.choice` stream bit for bit ('diag' with and without
+        replacement, 'zeros' with unequal row counts);
+      * `loss_history` has the reference's number of epochs — g9 STOPS EARLY (12 of 60 epochs; its streak decisions have
+        margins >= 0.12 against min_increment = 0.25) — and its values (tolerances of the engine-level replay);
+      * the returned embeddings in relative L2 (eval-mode outputs after training depend on Adam-amplified rounding noise
+        in the dead biases in the reference as much as here, tests/test_hip_step.py)."""
+    import contextlib
+    import io
+    from golden_util import Golden
+    g = Golden(name)
+    m = g.meta
+    c = dict(m['ctor'])
+    data = [g['data0'].astype(np.float64), g['data1'].astype(np.float64)]
+    kw = dict(output_dim=m['L'], batch_size=m['B'], epoch_DNN=m['epochs'], pca_dim=None, use_f_tilde=m['has_F'],
+              log_DNN=10 ** 9, manual_seed=666, sampler='numpy')
+    if m['has_F']:
+        kw['match_result'] = [g['F']]
+    kw.update(c)
+    jm = jam.JAMIE(**kw)
+    jm._noise_source = lambda s: _noise_to_dev(g.noise(s), m['p'])
+    calls = []
+    orig = np.random.choice
+
+    def choice(*a, **k):
+        r = orig(*a, **k)
+        calls.append(np.asarray(r).copy())
+        return r
+    np.random.seed(m['np_seed'])
+    np.random.choice = choice
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            emb = jm.fit_transform(dataset=[d.copy() for d in data], P=g['P'] if m['has_P'] else None)
+    finally:
+        np.random.choice = orig
+    assert jm.sampling_method == m['sampling_method'] and jm.model.dropout == m['p']
+    ch = g['choice']
+    assert len(calls) == len(ch), (len(calls), len(ch))
+    for a, b in zip(calls, ch):
+        assert np.array_equal(a, b)
+    want = g['loss_history']
+    got = np.array([jm.loss_history[k] for k in m['loss_names']])
+    assert got.shape == want.shape, (got.shape, want.shape)        # same number of epochs: same stopping decision
+    if name == 'g9_earlystop':
+        assert want.shape[1] == 12 < m['epochs']
+    big_lr = c.get('model_lr', 1e-3) > 1e-2
+    np.testing.assert_allclose(got, want, rtol=5e-2 if big_lr else 2e-3, atol=1e-5)
+    for i in range(2):
+        assert emb[i].shape == g[f'emb{i}'].shape and emb[i].dtype == np.float32
+        assert_mostly_close(emb[i], g[f'emb{i}'], rtol=0, atol=0, max_bad_frac=1.0, rel_l2=0.1 if big_lr else 1.5e-2,
+                            msg=f'emb{i}')

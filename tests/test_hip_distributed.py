@@ -1,0 +1,123 @@
+"""Data-parallel path with two ranks sharing cuda:0 over gloo (everything except RCCL itself; the real multi-GPU path is
+backend "nccl" = RCCL, one GPU per rank): SURVEY.md §8(e).
+  * N ranks fed IDENTICAL batches and seeds reproduce the 1-rank weights (fp32 messages: bit for bit; bf16 messages:
+    within bf16 rounding of the gradient) -- agreement between the ranks alone would also hold with a wrong 1/world
+    scale or a dropped region;
+  * the facade with distributed=True: uneven shards, early stopping and BatchNorm statistics are rank-invariant.
+Run on the MI355X box:  pytest -m gpu"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torchrun(script, port, nproc=2, timeout=600):
+    env = dict(os.environ, JAMIE_DIST_BACKEND='gloo', JAMIE_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+                       capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16_msgs', 'bf16_f32msgs'])
+def test_two_ranks_with_identical_batches_reproduce_one_rank(tmp_path, mode):
+    script = tmp_path / 'same.py'
+    script.write_text(f'''
+import sys, torch, numpy as np
+sys.path.insert(0, {ROOT!r})
+from jamie_amd import distributed as jd, _native as nv
+from jamie_amd.engine import TrainEngine
+from jamie_amd.model import edModelVar
+rank, world, local = jd.init_from_env()
+dev = torch.device('cuda', local)
+mode = {mode!r}
+dims, L, B, N = (264, 136), 8, 128, 1024
+g = torch.Generator(device=dev).manual_seed(50)          # the SAME cells on every rank
+data = [torch.randn(N, d, generator=g, device=dev) for d in dims]
+compute = 'f32' if mode == 'f32' else 'bf16'
+comm = torch.bfloat16 if mode == 'bf16_msgs' else None
+flats = {{}}
+for label, w in (('one', 1), ('dp', world)):
+    torch.manual_seed(3)
+    model = edModelVar(dims, L, device=dev)
+    eng = TrainEngine(model, B, seed=11, world_size=w, compute_dtype=compute)      # the SAME seed on every rank
+    ar = jd.OverlappedGradAllReduce(min_bytes=1 << 16, comm_dtype=comm) if w > 1 else None
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    for s in range(4):
+        nv.sample_indices(idx, N, 0, False, eng.state, 200)
+        eng.load_batch(data, [idx, idx])
+        eng.step(None, None, None, ar)
+    flats[label] = model.flat.clone()
+    assert int(eng.state[1].item()) == 4
+a, b = flats['one'], flats['dp']
+d = (a - b).abs()
+if mode == 'f32':
+    # sum of two equal fp32 gradients times 1/2 is the gradient, and the norm comes from the same one-pass kernel
+    assert torch.equal(a, b), float(d.max())
+elif mode == 'bf16_f32msgs':
+    # fp32 messages: the same gradient; only the norm's summation order differs (dW-epilogue partials on one GPU, the
+    # one-pass kernel on the reduced gradient): the clip coefficient's last bits
+    assert float(d.max()) < 1e-6, float(d.max())
+else:
+    # bf16 messages round the gradient to 8 bits: Adam's normalised update moves by ~2^-9 relative, except where a
+    # gradient is rounding noise anyway (sign flips, bounded by 2 lr per step)
+    frac = float((d > 4 * 1e-3 * 2.0 ** -8 * 4).float().mean())
+    assert float(d.max()) <= 4 * 2e-3 + 1e-6 and frac < 5e-2, (float(d.max()), frac)
+print('SAME OK', rank, float(d.max()))
+torch.distributed.destroy_process_group()
+''')
+    out = _torchrun(script, 29581)
+    assert out.count('SAME OK') == 2, out[-2000:]
+
+
+@pytest.mark.parametrize('variant', ['diag_numpy', 'diag_device_bf16', 'hybrid_sparse'])
+def test_facade_distributed_is_rank_invariant(tmp_path, variant):
+    """JAMIE(distributed=True) with two ranks: 255 cells -> shards of 128 and 127 rows, i.e. 2 vs 1 batches of 64 per epoch
+    if every rank used its own shard size (mismatched collective counts = deadlock); early stopping is decided on the
+    rank-mean loss; BatchNorm running statistics are averaged before evaluation.  Both ranks must finish, after the same
+    number of epochs, with identical parameters, statistics and embeddings."""
+    script = tmp_path / 'facade.py'
+    script.write_text(f'''
+import sys, io, contextlib, torch, numpy as np
+sys.path.insert(0, {ROOT!r})
+import scipy.sparse as sp
+import jamie_amd
+from jamie_amd import distributed as jd
+variant = {variant!r}
+rank, world, local = jd.init_from_env()
+rng = np.random.default_rng(0)
+N, dims = 255, (48, 40)
+Z = rng.standard_normal((N, 5))
+data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
+np.random.seed(7 + rank)
+kw = dict(output_dim=8, batch_size=64, epoch_DNN=60, min_epochs=8, min_increment=0.05, max_steps_without_increment=3,
+          pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9, distributed=True)
+P = None
+if variant == 'diag_device_bf16':
+    kw.update(sampler='device', compute_dtype='bf16')
+elif variant == 'hybrid_sparse':
+    known = np.arange(0, N, 2)                                   # every other cell has a known partner (itself)
+    P = sp.csr_matrix((np.ones(len(known), np.float32), (known, known)), shape=(N, N))
+jm = jamie_amd.JAMIE(**kw)
+with contextlib.redirect_stdout(io.StringIO()):
+    emb = jm.fit_transform(dataset=data, P=P)
+epochs = len(jm.loss_history['Rec'])
+assert 9 <= epochs <= 60 and all(e.shape == (N, 8) and np.isfinite(e).all() for e in emb)
+dev = jm.model.device
+sig = torch.cat([jm.model.flat, jm.model.bn_flat, torch.from_numpy(np.concatenate(emb, 1).ravel()).to(dev),
+                 torch.tensor([float(epochs)], device=dev)])
+others = [torch.zeros_like(sig) for _ in range(world)]
+torch.distributed.all_gather(others, sig)
+assert torch.equal(others[0], others[1]), float((others[0] - others[1]).abs().max())
+print('FACADE OK', rank, epochs, jm.sampling_method)
+torch.distributed.destroy_process_group()
+''')
+    out = _torchrun(script, 29582)
+    assert out.count('FACADE OK') == 2, out[-2000:]
+    eps = {ln.split()[3] for ln in out.splitlines() if ln.startswith('FACADE OK')}
+    assert len(eps) == 1

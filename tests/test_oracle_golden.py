@@ -14,7 +14,8 @@ def _ctor(meta):
     c = dict(meta['ctor'])
     kw = dict(output_dim=meta['L'], batch_size=meta['B'] if meta['B'] <= max(meta['rows']) else meta['B'],
               epoch_DNN=meta['epochs'])
-    for k in ('dropout', 'PF_Ratio', 'loss_weights', 'dist_method', 'min_epochs', 'model_lr'):
+    for k in ('dropout', 'PF_Ratio', 'loss_weights', 'dist_method', 'min_epochs', 'model_lr', 'min_increment',
+              'max_steps_without_increment'):
         if k in c:
             kw[k] = c[k]
     return kw
@@ -66,6 +67,8 @@ def test_full_loop_replay(name):
                     assert torch.equal(o.trace[s]['noise']['dec_masks'][i][j], gn['dec_masks'][i][j])
     assert torch.allclose(o.trace[0]['corr'], torch.from_numpy(g['s0.corr']), atol=0, rtol=0)
     lh = np.array([o.loss_history[k] for k in m['loss_names']])
+    assert lh.shape == g['loss_history'].shape           # same number of epochs (g9: the reference stopped early)
+    assert m['steps'] == len(o.trace)
     np.testing.assert_allclose(lh, g['loss_history'], rtol=2e-5, atol=1e-7)
     for i in range(2):
         np.testing.assert_allclose(emb[i], g[f'emb{i}'], rtol=1e-4, atol=1e-5)

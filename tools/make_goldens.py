@@ -196,5 +196,14 @@ def main():
     run_case('g8_klquirk', 20, (12, 10), 3, 20, 12, 9, ctor=dict(model_lr=5e-2, min_epochs=2))
 
 
+def extra():
+    """Fixtures added after the first eight (generated separately so that the first eight stay byte-identical)."""
+    # G9: a run that STOPS EARLY (jamie.py:777-792): epoch_DNN = 60 but the streak of epochs without an improvement of
+    # more than min_increment reaches max_steps_without_increment first; two batches per epoch, so `best_batch_loss`
+    # (the minimum over the epoch's batches, jamie.py:729-731) differs from the last batch's loss that is recorded
+    run_case('g9_earlystop', 48, (24, 20), 4, 24, 60, 10,
+             ctor=dict(dropout=.3, min_epochs=6, min_increment=.25, max_steps_without_increment=3))
+
+
 if __name__ == '__main__':
-    main()
+    extra() if 'extra' in sys.argv[1:] else main()
