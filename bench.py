@@ -36,16 +36,22 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 d
 PEAK_HBM_GBS = 8000.0
 
 
-def synth_shard(n_rows, dims, seed, device):
-    """X_i = Z A_i + 0.1 E_i with a 16-dim latent, fp32, standardised per feature
-    (what `preclass(axis=0)` does on the host in the reference, jamie.py:462-465)."""
-    g = torch.Generator(device=device).manual_seed(1234)             # A_i shared by all ranks
-    A = [torch.randn(16, d, generator=g, device=device) for d in dims]
-    g2 = torch.Generator(device=device).manual_seed(seed)
-    Z = torch.randn(n_rows, 16, generator=g2, device=device)
+def synth_shard(n_cells, lo, hi, dims, rank, world, device):
+    """SURVEY.md §8(d) generator: rng = np.random.default_rng(0); Z ~ N(0,1) [N, 16]; X_i = Z A_i + 0.1 E_i with
+    A_i ~ N(0,1) [16, d_i], E_i ~ N(0,1); fp32; then standardised per feature (what `preclass(axis=0)` does in the
+    reference, jamie.py:462-465).  Draw order: Z, every A_i, then every E_i, so that Z and the A_i are the same for every
+    world size; with one rank the E_i continue the same generator, a rank of a larger world draws the E_i of its row shard
+    from default_rng([0, 1 + rank]) (the shared stream cannot be advanced past another rank's rows)."""
+    rng = np.random.default_rng(0)
+    Z = rng.standard_normal((n_cells, 16), dtype=np.float32)[lo:hi]
+    A = [rng.standard_normal((16, d), dtype=np.float32) for d in dims]
+    erng = rng if world == 1 else np.random.default_rng([0, 1 + rank])
+    Zd = torch.from_numpy(Z).to(device)
     out = []
     for a in A:
-        x = Z @ a + 0.1 * torch.randn(n_rows, a.shape[1], generator=g2, device=device)
+        E = torch.from_numpy(erng.standard_normal((hi - lo, a.shape[1]), dtype=np.float32)).to(device)
+        x = Zd @ torch.from_numpy(a).to(device) + 0.1 * E
+        del E
         x = (x - x.mean(0)) / x.std(0, unbiased=False)
         out.append(x.contiguous())
     return out
@@ -57,12 +63,42 @@ def flops_per_cell(dims, L):
     return 6 * pmm - 4 * sum(d * d for d in dims)
 
 
-def cpu_baseline(dims, L, B, budget_s=20.0):
-    """The CPU oracle (plain-PyTorch restatement of the reference step, pinned to the reference by the
-    golden fixtures) timed on this box's host cores: same dims, fp32, B = 512, default dropout."""
+def host_cpu():
+    """(model string, physical cores usable by this process, logical CPUs usable) from /proc/cpuinfo and the affinity mask."""
+    model, cores = 'unknown', set()
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    try:
+        cpu = phys = core = None
+        for ln in open('/proc/cpuinfo'):
+            k, _, v = ln.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'processor':
+                cpu, phys, core = int(v), 0, None
+            elif k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = int(v)
+            elif k == 'core id':
+                core = int(v)
+            elif not k and cpu is not None:
+                if cpu in allowed:
+                    cores.add((phys, core if core is not None else cpu))
+                cpu = None
+    except OSError:
+        pass
+    return model, (len(cores) or len(allowed)), len(allowed)
+
+
+def cpu_baseline(dims, L, B, budget_s=24.0):
+    """The CPU oracle (plain-PyTorch restatement of the reference step, pinned to the reference by the golden fixtures)
+    timed on this box's host cores: same dims, fp32, B = 512, default dropout, N capped at 8192, first
+    step dropped; at n = all physical cores (the primary record, `cores`), at n = 8, and at the fastest of a short probe
+    (the oracle's elementwise ops and dropout masks stop scaling well before a many-core host is full)."""
     from oracle import jamie_oracle as orc
-    threads = int(os.environ.get("JAMIE_CPU_THREADS", "0")) or min(torch.get_num_threads(), 64)
-    torch.set_num_threads(threads)
+    model, n_phys, n_logical = host_cpu()
     torch.manual_seed(666)
     P, Bf = orc.init_state(dims, L)
     for v in P.values():
@@ -72,42 +108,116 @@ def cpu_baseline(dims, L, B, budget_s=20.0):
     rng = np.random.default_rng(0)
     n = 8192
     Z = rng.standard_normal((n, 16)).astype(np.float32)
-    data = [torch.from_numpy(Z @ rng.standard_normal((16, d)).astype(np.float32)
-                             + 0.1 * rng.standard_normal((n, d)).astype(np.float32)) for d in dims]
+    A = [rng.standard_normal((16, d)).astype(np.float32) for d in dims]
+    data = [torch.from_numpy(Z @ a + 0.1 * rng.standard_normal((n, a.shape[1])).astype(np.float32)) for a in A]
     data = [(x - x.mean(0)) / x.std(0) for x in data]
     eye, zero = torch.eye(B), torch.zeros(B, B)
+    np.random.seed(42)
 
     def one():
-        idx = np.random.choice(range(n), B, replace=False)
+        idx = np.random.choice(range(n), B, replace=min(dims) < B)
         X = [d[idx] for d in data]
         noise = orc.draw_noise(dims, L, B, p)
-        orc.train_step(P, Bf, opt, X, eye, zero, noise, p, 0.5)
-    one()                                     # warm-up (first step dropped)
-    # the oracle scales poorly past a few dozen threads on many-core hosts (memory-bound elementwise ops and
-    # dropout masks): probe a few thread counts briefly and time the sample with the fastest, stated in `cores`
-    if not os.environ.get('JAMIE_CPU_THREADS'):
-        best = (0.0, threads)
-        for t in sorted({8, 16, 24, 32, 48, threads}):
-            if t > (os.cpu_count() or t):
-                continue
-            torch.set_num_threads(t)
-            one()
-            t0 = time.perf_counter()
-            one(); one()
-            rate = 2 * B / (time.perf_counter() - t0)
-            if rate > best[0]:
-                best = (rate, t)
-        threads = best[1]
+        orc.train_step(P, Bf, opt, X, eye if len(dims) == 2 else None, zero if len(dims) == 2 else None, noise, p, 0.5)
+
+    def timed(threads, max_steps, seconds):
         torch.set_num_threads(threads)
+        one()                                   # warm-up at this thread count (first step dropped)
+        t0 = time.perf_counter()
+        steps = 0
+        while steps < max_steps and (time.perf_counter() - t0 < seconds or steps < 3):
+            one()
+            steps += 1
+        dt = time.perf_counter() - t0
+        return {'value': B * steps / dt, 'unit': 'cells/s', 'cores': threads, 'steps': steps, 'seconds': round(dt, 2)}
+
+    forced = int(os.environ.get('JAMIE_CPU_THREADS', '0'))
+    n_all = forced or n_phys
+    main_rec = timed(n_all, 40, budget_s * 0.45)
+    out = dict(main_rec)
+    out.update({'kind': 'port', 'cpu_model': model, 'physical_cores': n_phys, 'logical_cpus': n_logical,
+                'sample': f"{main_rec['steps']} steps of B={B} at dims={tuple(dims)}, L={L}, N capped at {n}, fp32, "
+                          f"{main_rec['seconds']} s on {n_all} torch threads = all physical cores usable by the process "
+                          f'({model}; {n_logical} logical CPUs)'})
+    if not forced:
+        out['n8'] = timed(8, 20, budget_s * 0.35) if n_all != 8 else dict(main_rec)
+        best = None
+        for t in sorted({16, 24, 32, 48} - {n_all, 8}):
+            if t > n_logical:
+                continue
+            r = timed(t, 3, 0.0)
+            if best is None or r['value'] > best['value']:
+                best = r
+        cand = [c for c in (best, main_rec, out['n8']) if c]
+        out['fastest_probed'] = max(cand, key=lambda c: c['value'])
+    return out
+
+
+def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=30, warmup=6):
+    """The parity configuration (exact-fp32 MFMA) on the same workload: cells/s, ms/step and the roofline of ITS dominant
+    kernel, the forward d <-> 2d Linear GEMM launch (north_star: >= 60 % of the binding roofline on the encoder matmul)."""
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    torch.manual_seed(666)
+    model = edModelVar(model_dims, L, device=dev)
+    eng = TrainEngine(model, B, lr=1e-3, seed=666, compute_dtype='f32')
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    eng.set_kl_anneal(0.5)
+    plan = eng.make_plan(data, idx, n_rows, rep, None)
+    for _ in range(warmup):
+        eng.run_plan(plan)
+    torch.cuda.synchronize()
+    eng.enable_kernel_timing('enc_gemm', every=4)
     t0 = time.perf_counter()
-    steps = 0
-    while steps < 60 and (time.perf_counter() - t0 < budget_s or steps < 3):
-        one()
-        steps += 1
+    for _ in range(steps):
+        eng.run_plan(plan)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {'value': B * steps / dt, 'unit': 'cells/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{steps} steps of B={B} at dims={tuple(dims)}, L={L}, N capped at {n}, fp32, '
-                      f'{dt:.1f} s on {threads} torch threads (fastest of the probed counts; {os.cpu_count()} logical CPUs)'}
+    tm = eng.kernel_timing_ms('enc_gemm', 'all')
+    gemm_flop = 4.0 * B * sum(d * d for d in model_dims)
+    achieved = gemm_flop / (tm['median'] * 1e-3) / 1e12
+    cells_s = B * steps / dt
+    total = eng.read_losses()[1]
+    return {'value': cells_s, 'unit': 'cells/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+            'dtype': 'f32', 'final_loss': total,
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1> (Linear d<->2d forward '
+                                                     'GEMM, both modalities in one launch; 4 launches/step)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': tm['median'], 'flop_per_launch': gemm_flop,
+                         'whole_step_frac': cells_s * flops_per_cell(model_dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)}}
+
+
+def rccl_record(world, log_dir):
+    """What RCCL reported while it built the communicator (NCCL_DEBUG=INFO, subsystem INIT, rank 0's log file): evidence
+    that the collective library saw `world` ranks, the channels / rings / trees it set up and the transports it chose."""
+    import glob
+    import re
+    dist = torch.distributed
+    rec = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'algo': None}
+    try:
+        rec['version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:       # noqa: BLE001
+        rec['version'] = None
+    try:
+        text = ''
+        for f in sorted(glob.glob(os.path.join(log_dir, 'rccl_*.log'))):
+            text += open(f, errors='replace').read()
+        if text:
+            ranks = re.findall(r'nranks (\d+)', text, flags=re.I)
+            chans = re.findall(r'(\d+) coll channels', text)
+            rec['init_log'] = {
+                'nranks_seen': sorted({int(r) for r in ranks}),
+                'coll_channels': sorted({int(c) for c in chans}),
+                'rings': len(re.findall(r'Channel \d+/\d+ *:', text)),
+                'trees': len(re.findall(r'Trees \[', text)),
+                'p2p_lines': len(re.findall(r'via P2P', text)),
+                'algo_lines': [ln.split('NCCL INFO')[-1].strip()[:160] for ln in text.splitlines()
+                               if re.search(r'Algo|algorithm|protocol', ln)][:6]}
+            if rec['init_log']['algo_lines']:
+                rec['algo'] = rec['init_log']['algo_lines'][0]
+    except Exception as e:       # noqa: BLE001
+        rec['init_log'] = {'error': str(e)}
+    return rec
 
 
 def main():
@@ -120,8 +230,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'],
                     help='GEMM operand type: bf16 (BASELINE config 2; fp32 accumulate/master) or f32 (parity config)')
     ap.add_argument('--grad-comm', default='auto', choices=['auto', 'f32', 'bf16'],
-                    help='dtype of the gradient all-reduce messages (auto: the compute dtype)')
+                    help='dtype of the gradient all-reduce messages (auto: the compute dtype; tests/test_host_cpu.py::test_bf16_message_sum_keeps_the_clip_norm)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32-record', action='store_true', help='skip the short fp32 (parity configuration) leg')
     ap.add_argument('--pipeline', action='store_true',
                     help='clip + Adam on a second stream under the next forward pass (+2-3 %; default: main stream, so '
                          'that the roofline kernel is timed alone)')
@@ -132,9 +243,16 @@ def main():
     ap.add_argument('--side-transposes', action='store_true',
                     help='bf16: transposed weight copies on a side stream under the next forward pass')
     ap.add_argument('--opt-priority', type=int, default=0, help='HIP stream priority of the optimiser stream')
-    ap.add_argument('--cpu-budget', type=float, default=15.0)
+    ap.add_argument('--cpu-budget', type=float, default=24.0)
     args = ap.parse_args()
 
+    # RCCL's own account of the communicator it builds (read back into the JSON line at N > 1): init-time log only
+    log_dir = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'NCCL_DEBUG' not in os.environ:
+        import tempfile
+        log_dir = tempfile.mkdtemp(prefix='jamie_rccl_')
+        os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,GRAPH',
+                          NCCL_DEBUG_FILE=os.path.join(log_dir, 'rccl_%h_%p.log'))
     from jamie_amd import distributed as jd
     rank, world, local = jd.init_from_env()
     if world != args.gpus and world > 1:
@@ -143,7 +261,7 @@ def main():
     dev = torch.device('cuda', local)
     from jamie_amd import _native as nv
     nv.require_gpu()
-    from jamie_amd.engine import TrainEngine
+    from jamie_amd.engine import TrainEngine, kl_anneal
     from jamie_amd.model import edModelVar
 
     n_cells, dims, L = CONFIGS[args.config]
@@ -153,22 +271,31 @@ def main():
     # feature counts that are not multiples of 8 (config 1: 100, config 4: 500): the bf16 engine pads them (model.py)
     pad = 8 if (args.dtype == 'bf16' and any(d % 8 for d in dims)) else 1
     lo, hi = jd.shard_bounds(n_cells, rank, world)
-    data = synth_shard(hi - lo, dims, 1000 + rank, dev)
+    data_real = synth_shard(n_cells, lo, hi, dims, rank, world, dev)
     torch.manual_seed(666)
     model = edModelVar(dims, L, device=dev, pad_features=pad)
     if world > 1:
         jd.broadcast_flat(model.flat)
     eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype,
                       dx_from_weights=not args.transposed_weight_copies, skinny_tr=args.skinny_tr)
-    data = eng.pad_cells(data)
-    # gradient exchange in the compute precision: bf16 messages in bf16 mode (80 MB instead of 161 MB per step), fp32 otherwise
+    data = eng.pad_cells(data_real)
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
     allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm) if world > 1 else None
     idx = torch.zeros(B, dtype=torch.int32, device=dev)      # 'diag' sampling: same rows in both modalities
     # the reference's quirk `replace = min(features) < batch_size` (jamie.py:553) belongs to its two-modality loop; the
     # 3-modality generalisation always samples without replacement (duplicates would need a non-identity corr)
     rep = min(dims) < B and len(dims) == 2
-    eng.set_kl_anneal(0.5)
+    # KL anneal per epoch as in the reference's loop (jamie.py:630-632, min_epochs 2500, epoch_DNN 10000): a device scalar,
+    # rewritten (asynchronously) when the step count crosses an epoch boundary
+    steps_per_epoch = max(1, int((hi - lo) / B))
+    state = {'step': 0, 'epoch': -1}
+
+    def set_anneal():
+        ep = state['step'] // steps_per_epoch
+        if ep != state['epoch']:
+            state['epoch'] = ep
+            eng.set_kl_anneal(kl_anneal(ep, 2500, 10000))
+    set_anneal()
     if args.pipeline:
         eng.enable_pipeline(args.opt_priority)
     if args.side_transposes:
@@ -176,9 +303,12 @@ def main():
     eng.enable_kernel_timing('enc_gemm', 'adam')
     # the step is a fixed launch sequence on static buffers: record it once, replay it (one foreign call per launch)
     plan = eng.make_plan(data, idx, hi - lo, rep, allreduce, prefetch=args.prefetch)
+    state['step'] = 1
 
     def step():
+        set_anneal()
         eng.run_plan(plan)
+        state['step'] += 1
 
     def barrier():
         if world > 1:
@@ -188,7 +318,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    if os.environ.get('JAMIE_BENCH_NO_EVENTS') != '1':
+    events = os.environ.get('JAMIE_BENCH_NO_EVENTS') != '1'
+    if events:
         eng.enable_kernel_timing('enc_gemm', 'adam', every=8)   # drop the warm-up samples; sample every 8th step
     else:
         eng._timing = None
@@ -201,6 +332,11 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    if not events:          # kernel timings from extra steps AFTER the timed region -- on every rank (a step is a collective)
+        eng.enable_kernel_timing('enc_gemm', 'adam')
+        for _ in range(20):
+            step()
+        barrier()
     ls, total, _ = eng.read_losses()
     if not np.isfinite(total):
         raise SystemExit('non-finite loss in benchmark')
@@ -212,21 +348,22 @@ def main():
         #         4*B*sum(d^2) FLOP) against the exact-fp32 MFMA peak;
         #   bf16: the step is HBM-bound on optimiser traffic; the dominant kernel is clip+Adam:
         #         28 bytes per parameter (read p, g, m, v; write p, m, v) against the HBM peak.
-        if eng._timing is None:
-            eng.enable_kernel_timing('enc_gemm', 'adam')
-            for _ in range(20):
-                step()
         timing_detail = {'enc_gemm': eng.kernel_timing_ms('enc_gemm', 'all'), 'adam': eng.kernel_timing_ms('adam', 'all')}
         # event pairs bracket one launch each; a host hiccup between the two records (GC, scheduler) shows up as a
         # multi-millisecond outlier in a handful of the samples, so the per-launch duration is the MEDIAN
         gemm_ms, adam_ms = timing_detail['enc_gemm']['median'], timing_detail['adam']['median']
-        gemm_flop = 4.0 * B * sum(d * d for d in dims)
-        traffic = None
+        kdims = eng.dims                                   # what the kernels multiply (padded feature counts, if any)
+        gemm_flop = 4.0 * B * sum(d * d for d in kdims)
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(f'{args.config}_{args.dtype}', {}).get('hbm_bytes_per_launch')
-            except Exception:
+                rec = json.load(open(tf)).get(f'{args.config}_{args.dtype}', {})
+                traffic = rec.get('hbm_bytes_per_launch')
+                if traffic is not None:
+                    traffic_source = (f"profiles/traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc "
+                                      f"passes of this command, profile {rec.get('source')}; NOT measured in this run)")
+            except Exception:       # noqa: BLE001
                 traffic = None
         if args.dtype == 'f32':
             achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
@@ -234,18 +371,19 @@ def main():
                                               'GEMM, both modalities in one launch; 4 launches/step)',
                     'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop,
-                    'traffic': traffic,
+                    'traffic': traffic, 'traffic_source': traffic_source,
                     'whole_step_frac': cells_s / world * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)}
         else:
             n_par = model.layout.total
             adam_launches = len(eng.PIPE_GROUPS) if eng.pipeline else 1
-            adam_bytes = 28.0 * n_par / adam_launches
+            adam_bytes = eng.adam_bytes_per_param() * n_par / adam_launches
             achieved = adam_bytes / (adam_ms * 1e-3) / 1e9
             step_bytes = 44.0 * n_par
             roof = {'bound': 'hbm', 'kernel': f'clip_adam_kernel (global-norm clip + Adam on the flat fp32 buffers; {adam_launches} launch(es)/step'
                                        + (', on the optimiser stream under the next forward pass)' if eng.pipeline else ')'),
                     'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS,
-                    'avg_launch_ms': adam_ms, 'bytes_per_launch': adam_bytes, 'traffic': traffic,
+                    'avg_launch_ms': adam_ms, 'bytes_per_launch': adam_bytes,
+                    'bytes_per_parameter': eng.adam_bytes_per_param(), 'traffic': traffic, 'traffic_source': traffic_source,
                     'whole_step_frac': (step_bytes * cells_s / world / B) / (PEAK_HBM_GBS * 1e9),
                     'gemm_bf16_tflops': gemm_flop / (gemm_ms * 1e-3) / 1e12, 'gemm_avg_launch_ms': gemm_ms}
         out = {
@@ -253,8 +391,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.config}: {len(dims)}-modality synthetic {n_cells} cells x {tuple(dims)} features, '
-                                   f'latent={L}, B={B}/GPU, dropout={model.dropout}, ' + ('bf16 MFMA GEMMs, fp32 accumulate/master/optimiser, ' if args.dtype == 'bf16' else 'fp32 MFMA, ') + 
-                                   f'identity P (diag sampling), F=0',
+                                   f'latent={L}, B={B}/GPU, dropout={model.dropout}, '
+                                   + ('bf16 MFMA GEMMs, fp32 accumulate/master/optimiser, ' if args.dtype == 'bf16' else 'fp32 MFMA, ')
+                                   + 'identity P (diag sampling), F=0, KL anneal per epoch',
+                       'generator': 'SURVEY.md 8(d): numpy default_rng(0), 16-dim latent factor model + 0.1 noise, standardised per feature',
                        'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
                        'parallelism': f'dp{world}', 'grad_allreduce': ('none' if world == 1 else ('bf16' if comm is not None else 'f32')),
                        'parameters': model.num_parameters(),
@@ -263,9 +403,20 @@ def main():
             'kernel_event_timing_ms': timing_detail,
             'final_loss': total,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:
+            out['rccl'] = rccl_record(world, log_dir) if log_dir else {'backend': torch.distributed.get_backend(),
+                                                                        'world': torch.distributed.get_world_size(), 'algo': None}
+    if world == 1:
+        # free the timed engine's buffers before the side legs
+        del plan
+        if args.dtype == 'bf16' and not args.no_f32_record and len(dims) == 2 and not any(d % 8 for d in dims):
+            del eng, model
+            torch.cuda.empty_cache()
+            out['f32'] = f32_record(dims, L, B, data_real, hi - lo, rep, dev)
+        if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dims, L, B, args.cpu_budget)
             out['gpu_over_cpu'] = cells_s / out['cpu_baseline']['value']
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

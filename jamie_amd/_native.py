@@ -360,6 +360,29 @@ def cast_transpose(problems):
         _call('jamie_cast_transpose', arr, len(chunk), _stream())
 
 
+class FlatCast:
+    """fp32 -> bf16 copy of a contiguous range (the data-parallel message buffer): `jamie_cast_transpose` on the range
+    viewed as [R, 2048] plus a tail row; the descriptors are built once, `run(stream)` is one foreign call and is never
+    recorded into a launch plan (its caller, the gradient exchange, is itself a plan entry)."""
+
+    def __init__(self, src, dst, width=2048):
+        n = src.numel()
+        assert dst.numel() == n and src.dtype == torch.float32 and dst.dtype == torch.bfloat16
+        probs = []
+        R = n // width
+        if R:
+            probs.append(cast_problem(src[:R * width].view(R, width), dst[:R * width].view(R, width)))
+        if n - R * width:
+            probs.append(cast_problem(src[R * width:].view(1, -1), dst[R * width:].view(1, -1)))
+        self.arr = (CastProblem * len(probs))(*probs)
+        self.n = len(probs)
+        self._keep = probs
+        self.fn = load().jamie_cast_transpose
+
+    def run(self, stream):
+        _check(self.fn(self.arr, self.n, C.c_void_p(stream.cuda_stream)))
+
+
 def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01):
     arr = (BnFwdProblem * len(problems))(*problems)
     _call('jamie_bn_act_fwd', arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), _stream())

@@ -85,6 +85,7 @@ class OverlappedGradAllReduce:
         self.works = []
         self.stream = None           # side stream of the cast + collective (low-precision messages on the GPU)
         self.pending = None          # (flat, lo, hi) not yet issued
+        self._casts = {}             # (lo, hi) -> prepared fp32 -> bf16 cast launch of that region (jamie_cast_transpose)
 
     def region_done(self, flat, lo, hi):
         if self.world == 1:
@@ -116,9 +117,13 @@ class OverlappedGradAllReduce:
                 self.stream = torch.cuda.Stream(device=flat.device)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            cast = self._casts.get((lo, hi))
+            if cast is None:
+                from . import _native as nv
+                cast = self._casts[(lo, hi)] = nv.FlatCast(flat[lo:hi], buf)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                buf.copy_(flat[lo:hi])
+                cast.run(self.stream)                     # fp32 region -> bf16 message buffer (HIP launch, no ATen op)
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             buf.copy_(flat[lo:hi])

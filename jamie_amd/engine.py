@@ -945,6 +945,10 @@ class TrainEngine:
         self.m.num_batches_tracked += 1
         self._timing_step += 1
 
+    def adam_bytes_per_param(self):
+        """Algorithmic HBM bytes per parameter of one clip + Adam launch: read p, g, m, v; write p, m, v (fp32)."""
+        return 28.0
+
     def read_losses(self):
         """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""
         v = self.losses.tolist()
