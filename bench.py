@@ -95,7 +95,8 @@ def host_cpu():
 def cpu_baseline(dims, L, B, budget_s=24.0):
     """The CPU oracle (plain-PyTorch restatement of the reference step, pinned to the reference by the golden fixtures)
     timed on this box's host cores: same dims, fp32, B = 512, default dropout, N capped at 8192, first
-    step dropped; at n = all physical cores (the primary record, `cores`), at n = 8, and at the fastest of a short probe
+    step dropped; at n = all physical cores, at n = 8, and at the fastest of a short probe; the headline `value` / `cores`
+    is the fastest of them
     (the oracle's elementwise ops and dropout masks stop scaling well before a many-core host is full)."""
     from oracle import jamie_oracle as orc
     model, n_phys, n_logical = host_cpu()
@@ -133,23 +134,26 @@ def cpu_baseline(dims, L, B, budget_s=24.0):
 
     forced = int(os.environ.get('JAMIE_CPU_THREADS', '0'))
     n_all = forced or n_phys
-    main_rec = timed(n_all, 40, budget_s * 0.45)
-    out = dict(main_rec)
-    out.update({'kind': 'port', 'cpu_model': model, 'physical_cores': n_phys, 'logical_cpus': n_logical,
-                'sample': f"{main_rec['steps']} steps of B={B} at dims={tuple(dims)}, L={L}, N capped at {n}, fp32, "
-                          f"{main_rec['seconds']} s on {n_all} torch threads = all physical cores usable by the process "
-                          f'({model}; {n_logical} logical CPUs)'})
+    recs = {'all_physical_cores': timed(n_all, 40, budget_s * 0.4)}
     if not forced:
-        out['n8'] = timed(8, 20, budget_s * 0.35) if n_all != 8 else dict(main_rec)
+        recs['n8'] = timed(8, 20, budget_s * 0.3) if n_all != 8 else dict(recs['all_physical_cores'])
         best = None
         for t in sorted({16, 24, 32, 48} - {n_all, 8}):
-            if t > n_logical:
-                continue
-            r = timed(t, 3, 0.0)
-            if best is None or r['value'] > best['value']:
-                best = r
-        cand = [c for c in (best, main_rec, out['n8']) if c]
-        out['fastest_probed'] = max(cand, key=lambda c: c['value'])
+            if t <= n_logical:
+                r = timed(t, 3, 0.0)
+                if best is None or r['value'] > best['value']:
+                    best = r
+        if best is not None and best['value'] > max(r['value'] for r in recs.values()):
+            recs['fastest_probed'] = timed(best['cores'], 30, budget_s * 0.3)      # a proper sample at the fastest count
+    # the headline record is the FASTEST thread count measured (the oracle's elementwise ops and dropout masks stop scaling
+    # long before a 128-core host is full, so "all physical cores" alone would flatter the GPU/CPU ratio)
+    top = max(recs.values(), key=lambda r: r['value'])
+    out = dict(top)
+    out.update({'kind': 'port', 'cpu_model': model, 'physical_cores': n_phys, 'logical_cpus': n_logical,
+                'sample': f"{top['steps']} steps of B={B} at dims={tuple(dims)}, L={L}, N capped at {n}, fp32, "
+                          f"{top['seconds']} s on {top['cores']} torch threads (the fastest of: all {n_all} physical cores "
+                          f"usable by the process, 8, and a probe of 16/24/32/48; {model}, {n_logical} logical CPUs)"})
+    out.update(recs)
     return out
 
 

@@ -272,6 +272,15 @@ int jamie_corr_from_indices(const int32_t* idx0, const int32_t* idx1, int B, flo
 int jamie_csr_block(const int32_t* indptr, const int32_t* indices, const float* vals, const int32_t* idx0,
                     const int32_t* idx1, int B0, int B1, int row_off, int col_off, int normalise, float* out /*[B0,B1]*/,
                     void* stream);
+/* out[a,b] = w_blk * blk[a,b] + w_add * add[a,b] with blk = M[idx0[a] + row_off, idx1[b] + col_off] of a DENSE row-major
+ * matrix (leading dimension ld), row-normalised when `normalise` (zero rows keep divisor 1); `add` may be NULL.
+ * Replaces P[idx0][:, idx1] / F[idx0][:, idx1], their row normalisation and the mix corr = PF_Ratio * P + (1 - PF_Ratio) * F
+ * of jamie/jamie.py:586-604 (the reference first gathers a [B, N] slab). */
+int jamie_dense_block(const float* M, long long ld, const int32_t* idx0, const int32_t* idx1, int B0, int B1,
+                      long long row_off, long long col_off, int normalise, float w_blk, const float* add /*[B0,B1] or NULL*/,
+                      float w_add, float* out /*[B0,B1]*/, void* stream);
+/* out[i] = a * x[i] + b * y[i] (y may be NULL): PF_Ratio * P + (1 - PF_Ratio) * F on [B,B] blocks (jamie/jamie.py:604) */
+int jamie_axpby(float* out, float a, const float* x, float b, const float* y, long long n, void* stream);
 /* out[n] (+)= sum_m X[m,n]  (bias gradients of the non-BN Linear layers) */
 int jamie_colsum(const float* X, int M, int N, int ld, int nslab, long long slab_stride, float* out,
                  int accumulate, void* stream);

@@ -136,6 +136,9 @@ EXPORTS = {
     'jamie_sqnorm_range_blocks': (C.c_int, [C.c_void_p, C.c_int]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'jamie_dense_block': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
+                                    C.c_longlong, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    'jamie_axpby': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_longlong, C.c_void_p]),
     'jamie_gather_rows': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p]),
     'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
@@ -444,6 +447,16 @@ def csr_block(indptr, indices, vals, idx0, idx1, out, row_off=0, col_off=0, norm
     """out[a, b] = P[idx0[a] + row_off, idx1[b] + col_off] for a device CSR matrix (sorted column indices)."""
     _call('jamie_csr_block', ptr(indptr), ptr(indices), ptr(vals), ptr(idx0), ptr(idx1), idx0.numel(), idx1.numel(),
           int(row_off), int(col_off), int(normalise), ptr(out), _stream())
+
+
+def dense_block(Mat, idx0, idx1, out, row_off=0, col_off=0, normalise=True, w_blk=1.0, add=None, w_add=0.0):
+    """out = w_blk * rownorm(Mat[idx0 + row_off][:, idx1 + col_off]) + w_add * add  (jamie.py:586-604) for a dense matrix."""
+    _call('jamie_dense_block', ptr(Mat), Mat.stride(0), ptr(idx0), ptr(idx1), idx0.numel(), idx1.numel(), int(row_off),
+          int(col_off), int(normalise), float(w_blk), ptr(add), float(w_add), ptr(out), _stream())
+
+
+def axpby(out, a, x, b=0.0, y=None):
+    _call('jamie_axpby', ptr(out), float(a), ptr(x), float(b), ptr(y), out.numel(), _stream())
 
 
 def colsum(X, M, N, ld, out, nslab=1, slab_stride=0, accumulate=False):

@@ -196,6 +196,54 @@ extern "C" int jamie_csr_block(const int32_t* indptr, const int32_t* indices, co
     return jamie_launch_status("jamie_csr_block");
 }
 
+// ---- blk[a,b] = M[idx0[a] + row_off, idx1[b] + col_off] of a DENSE matrix (P or the correspondence F), optionally
+// row-normalised (zero rows keep divisor 1; jamie.py:586-595), then out = w_blk * blk + w_add * add (the mix
+// corr = PF_Ratio * P + (1 - PF_Ratio) * F of jamie.py:604).  One workgroup per output row: the B x B gather never
+// materialises the [B, N] slab that `M[idx0][:, idx1]` builds in the reference.
+__global__ __launch_bounds__(256) void dense_block_kernel(const float* __restrict__ M, long long ld, const int32_t* __restrict__ idx0,
+                                                          const int32_t* __restrict__ idx1, int B1, long long row_off,
+                                                          long long col_off, int normalise, float w_blk,
+                                                          const float* __restrict__ add, float w_add, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int a = blockIdx.x;
+    const float* row = M + ((long long)idx0[a] + row_off) * ld + col_off;
+    float sum = 0.f;
+    if (normalise) {
+        for (int b = threadIdx.x; b < B1; b += 256) sum += row[idx1[b]];
+        sum = block_sum(sum, red);
+    }
+    const float div = (normalise && sum != 0.f) ? sum : 1.f;
+    for (int b = threadIdx.x; b < B1; b += 256) {
+        float v = (row[idx1[b]] / div) * w_blk;
+        if (add) v += w_add * add[(long long)a * B1 + b];
+        out[(long long)a * B1 + b] = v;
+    }
+}
+
+// out = a * x + b * y (y may be NULL): the correspondence mix PF_Ratio * P + (1 - PF_Ratio) * F of jamie.py:604 on blocks that
+// other kernels produced (jamie_csr_block, jamie_corr_from_indices)
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ out, float a, const float* __restrict__ x, float b,
+                                                    const float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
+}
+
+extern "C" int jamie_axpby(float* out, float a, const float* x, float b, const float* y, long long n, void* stream) {
+    JAMIE_ARG(out && x && n > 0, "null pointer / empty");
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, a, x, b, y, n);
+    return jamie_launch_status("jamie_axpby");
+}
+
+extern "C" int jamie_dense_block(const float* M, long long ld, const int32_t* idx0, const int32_t* idx1, int B0, int B1,
+                                 long long row_off, long long col_off, int normalise, float w_blk, const float* add,
+                                 float w_add, float* out, void* stream) {
+    JAMIE_ARG(M && idx0 && idx1 && out && B0 > 0 && B1 > 0 && ld > 0, "null pointer / empty");
+    JAMIE_ARG(row_off >= 0 && col_off >= 0, "negative offset");
+    hipLaunchKernelGGL(dense_block_kernel, dim3(B0), dim3(256), 0, (hipStream_t)stream, M, ld, idx0, idx1, B1, row_off,
+                       col_off, normalise, w_blk, add, w_add, out);
+    return jamie_launch_status("jamie_dense_block");
+}
+
 // ---- out[n] (+)= sum_m sum_slabs X[m,n]: 16 columns x 16 row phases per workgroup; up to 4 matrices per launch ----
 struct ColsumDev { const float* X; float* out; long long slab_stride; int M, N, ld, nslab, accumulate, blk_begin; };
 struct ColsumGroup { ColsumDev p[JAMIE_MAX_GROUP]; int count; };

@@ -37,13 +37,6 @@ def init_random_seed(manual_seed):
     return seed
 
 
-def _row_normalise(blk):
-    """reference jamie.py:587-589 / 593-595."""
-    s = blk.sum(dim=1)
-    s = torch.where(s == 0, torch.ones_like(s), s)
-    return blk / s[:, None]
-
-
 class JAMIE:
     """MI355X drop-in for `jamie.JAMIE` (coupled-VAE path).
 
@@ -293,18 +286,33 @@ class JAMIE:
         # the loop would block the host twice per step, so it only runs when `debug` asks for the per-phase table
         step_timer = timer if self.debug else time_logger(record=False)
         # ---- preprocessing (host, numpy/sklearn like the reference) ----
-        dev_pre = self.preprocess == 'device' and (self.pca_dim is None or all(dm is None for dm in self.pca_dim))
+        dev_pre = self.preprocess == 'device'
         if dev_pre:
-            # per-feature standardisation on the GPU (jamie_col_stats / jamie_standardise: fp64 statistics in numpy's
-            # two-pass order, fp32 cells written straight into the resident training matrices); the host keeps the
-            # `preclass` objects (mean / std) for transform / inverse_transform of new data
+            # on the GPU: per-feature standardisation (jamie_col_stats / jamie_standardise: fp64
+            # statistics in numpy's two-pass order) or, where `pca_dim` names a dimension (the reference's default,
+            # jamie.py:50, 436-457), randomized PCA on the fp32 MFMA GEMM (jamie_amd/pca.py) followed by the global
+            # scaling of `preclass(sample, pca=pca)`; fp32 cells are written straight into the resident training matrices.
+            # The host keeps the `preclass` objects (statistics, fitted PCA) for transform / inverse_transform of new data
+            from .pca import DevicePCA, global_standardise
             pre, data_dev = [], []
-            for x in self.dataset:
+            dims_pca = self.pca_dim if self.pca_dim is not None else [None] * len(self.dataset)
+            for dim, x in zip(dims_pca, self.dataset):
                 xa = np.ascontiguousarray(np.asarray(x))
                 if xa.dtype not in (np.float32, np.float64):
                     xa = xa.astype(np.float64)
-                out, mean, sd = nv.standardise_columns(torch.from_numpy(xa).to(dev))
-                pre.append(preclass.from_stats(mean.cpu().numpy(), sd.cpu().numpy(), axis=0))
+                if dim is None:
+                    out, mean, sd = nv.standardise_columns(torch.from_numpy(xa).to(dev))
+                    pre.append(preclass.from_stats(mean.cpu().numpy(), sd.cpu().numpy(), axis=0))
+                else:
+                    if self.model_pca != 'pca':
+                        raise NotImplementedError("model_pca='umap' needs umap-learn (absent)")
+                    if min(*xa.shape) < dim:
+                        warnings.warn(f'PCA dim must be lower than {min(*xa.shape)}, found {dim}, '
+                                      f'adjusting to compensate.')
+                        dim = min(*xa.shape)
+                    pca = DevicePCA(dim, device=self.device)        # random_state=None: numpy's global RNG, like sklearn's
+                    out, m, sdev = global_standardise(pca.fit_transform_device(torch.from_numpy(xa).to(dev)))
+                    pre.append(preclass.from_stats(m, sdev, axis=None, pca=pca))
                 data_dev.append(out)
             self.dataset = [d.cpu().numpy() for d in data_dev]                # the reference keeps the transformed cells
         else:
@@ -353,10 +361,12 @@ class JAMIE:
         data = eng.pad_cells(data)
         rep = min(self.col) < B and self.dataset_num == 2                    # jamie.py:553 (sic); M > 2: never
         need_block = ((method == 'diag' and rep) or method == 'zeros' or F_dense is not None or P_dense is not None
-                      or P_csr is not None)
+                      or P_csr is not None or self.PF_Ratio != 1)
         if self.dataset_num > 2 and need_block:
             raise NotImplementedError('more than two modalities: min(features) must be >= batch_size (no duplicates)')
         idx_dev = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(self.dataset_num)]
+        blk_F = torch.empty(B, B, device=dev) if F_dense is not None else None
+        blk_mix = torch.empty(B, B, device=dev) if self.PF_Ratio != 1 else None
         best_running_loss = np.inf
         streak = 0
         if self.record_loss:
@@ -443,23 +453,21 @@ class JAMIE:
                 # ---- P / F blocks (jamie.py:585-604) ----
                 corr = Fblk = None
                 if need_block:
-                    i0, i1 = idx_dev[0].long(), idx_dev[1].long()
                     if P_csr is not None:
                         nv.csr_block(*P_csr, idx_dev[0], idx_dev[1], eng.corr, bounds[0][0], bounds[1][0])
-                        Pb = eng.corr
-                    elif P_dense is not None:
-                        Pb = _row_normalise(P_dense[(i0 + bounds[0][0])[:, None], (i1 + bounds[1][0])[None, :]])   # B x B gather
+                    elif P_dense is not None:         # one B x B gather + row normalisation (no [B, N] slab)
+                        nv.dense_block(P_dense, idx_dev[0], idx_dev[1], eng.corr, bounds[0][0], bounds[1][0])
                     elif method == 'diag':
                         nv.corr_from_indices(idx_dev[0], idx_dev[1], eng.corr)
-                        Pb = eng.corr
                     else:
-                        Pb = torch.zeros(B, B, device=dev)
+                        eng.corr.zero_()
+                    corr = eng.corr
                     if F_dense is not None:
-                        # one B x B gather (F[i0][:, i1] would first materialise a [B, N] slab: 205 MB at 100k cells)
-                        Fblk = _row_normalise(F_dense[(i0 + bounds[0][0])[:, None], (i1 + bounds[1][0])[None, :]]).contiguous()
-                        corr = (self.PF_Ratio * Pb + (1 - self.PF_Ratio) * Fblk).contiguous()
-                    else:
-                        corr = (self.PF_Ratio * Pb).contiguous() if self.PF_Ratio != 1 else Pb
+                        nv.dense_block(F_dense, idx_dev[0], idx_dev[1], blk_F, bounds[0][0], bounds[1][0])
+                        Fblk = blk_F
+                    if self.PF_Ratio != 1:                                     # jamie.py:604
+                        nv.axpby(blk_mix, self.PF_Ratio, eng.corr, 1 - self.PF_Ratio, Fblk)
+                        corr = blk_mix
                 step_timer.log('Get subset samples')
                 noise = None if self._noise_source is None else self._noise_source(n_steps)
                 n_steps += 1

@@ -368,7 +368,12 @@ class edModelVar:
             raise NotImplementedError('a correspondence block is only defined for two modalities')
         else:
             corr = self._dev(corr)
-            comb = [(sig[0] * mus[0] + sig[1] * (corr @ mus[1])) / (sig[0] + sig[1] * corr.sum(1, keepdim=True)),
-                    (sig[1] * mus[1] + sig[0] * (corr.t() @ mus[0])) / (sig[1] + sig[0] * corr.sum(0).reshape(-1, 1))]
+            n0, n1 = corr.shape
+            c1 = torch.empty(n0, L, device=self.device)          # corr z1 and corr^T z0 on the fp32 MFMA GEMM (NN / TN)
+            c0 = torch.empty(n1, L, device=self.device)
+            nv.gemm([nv.gemm_problem(corr, mus[1], c1, n0, L, n1, n1, L, L)], nv.NN)
+            nv.gemm([nv.gemm_problem(corr, mus[0], c0, n1, L, n0, n1, L, L)], nv.TN)
+            comb = [(sig[0] * mus[0] + sig[1] * c1) / (sig[0] + sig[1] * corr.sum(1, keepdim=True)),
+                    (sig[1] * mus[1] + sig[0] * c0) / (sig[1] + sig[0] * corr.sum(0).reshape(-1, 1))]
         X_hat = [self._decode_eval(i, comb[i]) for i in range(M)]
         return mus, comb, X_hat, mus, logvar

@@ -21,10 +21,11 @@ class preclass:
         self.std = np.asarray(sample.std(axis))
 
     @classmethod
-    def from_stats(cls, mean, std, axis=0):
-        """The same object from statistics computed elsewhere (the device path, `_native.standardise_columns`)."""
+    def from_stats(cls, mean, std, axis=0, pca=None):
+        """The same object from statistics computed elsewhere (the device path: `_native.standardise_columns`, or
+        `pca.global_standardise` behind a `pca.DevicePCA`)."""
         self = cls.__new__(cls)
-        self.pca, self.axis = None, axis
+        self.pca, self.axis = pca, axis
         self.mean, self.std = np.asarray(mean), np.asarray(std)
         return self
 

@@ -219,12 +219,39 @@ def test_gradient_exchange_world2_gloo(tmp_path):
 
 
 # ---- correspondence stage: host pieces ----
-@pytest.mark.parametrize('mode', ['euclidean', 'cosine', 'spearman', 'pearson'])
-def test_distance_matrix_matches_oracle(mode):
+@pytest.mark.parametrize('mode', ['euclidean', 'cosine', 'spearman', 'pearson', 'cityblock'])
+def test_distance_matrix_from_first_principles(mode):
+    """Stage A's distance modes (reference jamie.py:839-890) against the DEFINITIONS written out with plain numpy loops /
+    rank transforms -- not against the oracle's copy of the same scipy / sklearn calls (that would be a self-comparison)."""
     from jamie_amd.utilities import distance_matrix
-    from oracle import jamie_oracle as orc
-    X = np.random.default_rng(3).standard_normal((40, 12))
-    np.testing.assert_array_equal(distance_matrix(X, mode), orc.distance_matrix(X, mode))
+    X = np.random.default_rng(3).standard_normal((30, 12))
+    n = X.shape[0]
+    want = np.zeros((n, n))
+
+    def pearson(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float(a @ b / np.sqrt((a @ a) * (b @ b)))
+
+    def ranks(v):                           # no ties in continuous data
+        r = np.empty(len(v))
+        r[np.argsort(v)] = np.arange(1, len(v) + 1)
+        return r
+    for a in range(n):
+        for b in range(n):
+            x, y = X[a], X[b]
+            if mode == 'euclidean':
+                want[a, b] = np.sqrt(((x - y) ** 2).sum())
+            elif mode == 'cityblock':
+                want[a, b] = np.abs(x - y).sum()
+            elif mode == 'cosine':
+                want[a, b] = 1 - x @ y / np.sqrt((x @ x) * (y @ y))
+            elif mode == 'pearson':
+                want[a, b] = (1 - pearson(x, y)) / 2               # jamie.py:870-879
+            else:
+                want[a, b] = (1 - pearson(ranks(x), ranks(y))) / 2   # jamie.py:857-869
+    got = distance_matrix(X, mode)
+    assert got.shape == (n, n)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-7)    # (sklearn's euclidean uses the Gram form: 1e-8 on the diagonal)
 
 
 def test_geodesic_distances_properties():
