@@ -77,6 +77,10 @@ typedef struct {
     int store_nt;               /* non-temporal output stores (large-tile jamie_gemm_bf16 configurations, jamie_gemm_f32): for
                                  * outputs that are next read much later, e.g. weight gradients (read by the optimiser after the
                                  * whole backward pass) */
+    int c_bf16;                 /* jamie_gemm_bf16, large-tile configurations, EPI_STORE without accumulate / split-K: C points to
+                                 * bf16 [M, ldc] and the fp32 accumulators are rounded once on the way out (`partial` still sums
+                                 * the squares of the fp32 values).  The weight gradients of the bf16 compute mode: 2 instead of 4
+                                 * bytes per parameter written here and read again by jamie_clip_adam_g16 */
 } jamie_gemm_problem;
 
 /* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */
@@ -204,7 +208,8 @@ int jamie_latent_bwd(const jamie_latent* a /*host*/, void* stream);
 /* M-modality latent block (2 <= M <= 4) for fully paired cells: identity correspondence, F = 0, euclidean alignment.
  * The reference supports two modalities only (jamie.py:420, model.py:251-256); this is the build-defined
  * generalisation of SURVEY.md §8 row A14 (comb = sum_j sigma_j z_j / sum_j sigma_j; KL rows 0..M-1 of the last
- * modality's logvar).  For M = 2 it equals jamie_latent_* at corr = NULL.  Pointer arrays are indexed by modality. */
+ * modality's logvar).  For M = 2 it equals jamie_latent_* at corr = NULL and is the path the training step takes for
+ * identity correspondence.  L: a multiple of 4, <= 128.  Pointer arrays are indexed by modality. */
 typedef struct {
     int B, L, M;
     const float* ml[4]; int ml_nslab; long long ml_slab_stride;
@@ -217,9 +222,25 @@ typedef struct {
     float* dml[4]; float* dsigma;    /* dsigma [M]                                                        */
     const float* rec_partials; int n_rec_partials; float* losses;
     int rng_stream;
+    /* fused tail (all optional, NULL = off).  Forward: the SAME launch computes decoder layer 0 of every modality,
+     * g1_i [B, d_i] = comb dec0_W_i^T + dec0_b_i (reference model.py:190; exact fp32 on the vector ALU: K = L), stores comb
+     * into every `comb_alias[i]` and the bf16 copies the bf16 GEMMs of the backward pass read.  Backward: bf16 copies of
+     * d(mu | logvar) and the head-bias gradients dbias_head[i] [2L] = column sums of dml_i ((+)= when `accumulate`),
+     * which need `colpart` (jamie_latent_m_colpart_size() floats). */
+    float* g1[4]; const float* dec0_W[4] /* [d_i, L] */; const float* dec0_b[4]; int d[4];
+    float* comb_alias[4];
+    void* comb_bf16[4] /* [B, L] */; void* combT_bf16[4] /* [L, B] */;
+    void* dml_bf16[4] /* [B, 2L] */; void* dmlT_bf16[4] /* [2L, B] */;
+    float* dbias_head[4]; float* colpart; int accumulate;
+    unsigned* ticket;   /* REQUIRED for the backward launch: one zero-initialised device uint32 (count of finished workgroups;
+                         * the last one finalises the losses, d sigma and the head-bias gradients and resets it) */
 } jamie_latent_m;
+/* forward: ONE launch from the heads' split-K slabs to mu / logvar / z / comb, the loss partial sums and (fused tail) the
+ * decoder's first pre-activation; backward: ONE launch (gradients + partial sums; its last workgroup finalises the losses, d sigma
+ * and the head-bias gradients) */
 int jamie_latent_m_fwd(const jamie_latent_m* a /*host*/, const uint64_t* rng, void* stream);
 int jamie_latent_m_bwd(const jamie_latent_m* a /*host*/, void* stream);
+long long jamie_latent_m_colpart_size(int B, int L);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser: global-norm clip + Adam on one flat fp32 buffer
@@ -237,6 +258,10 @@ int jamie_grad_sqnorm(const float* g, long long n, float* partials, int n_partia
  * jamie_clip_adam sums all of them -- clip_grad_norm_ (jamie.py:739) without a second pass over the weight gradients. */
 int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets /*host*/, const long long* lengths /*host*/, int count,
                              float* partials, int n_partials, uint64_t* state, void* stream);
+/* The same, and additionally g_bf16[i] = bf16(g[i]) over those ranges (same offsets): with the dW launches writing bf16
+ * (jamie_gemm_problem.c_bf16) the whole gradient then exists in ONE bf16 buffer for jamie_clip_adam_g16. */
+int jamie_grad_sqnorm_ranges_g16(const float* g, void* g_bf16, const long long* offsets /*host*/, const long long* lengths /*host*/,
+                                 int count, float* partials, int n_partials, uint64_t* state, void* stream);
 int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,

@@ -28,7 +28,7 @@ class GemmProblem(C.Structure):
                 ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('aux_ld', C.c_int),
                 ('splitk', C.c_int), ('slab_stride', C.c_longlong),
                 ('epi', C.c_int), ('accumulate', C.c_int),
-                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float), ('b_tr', C.c_int), ('a_tr', C.c_int), ('store_nt', C.c_int)]
+                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float), ('b_tr', C.c_int), ('a_tr', C.c_int), ('store_nt', C.c_int), ('c_bf16', C.c_int)]
 
 
 class CastProblem(C.Structure):
@@ -97,7 +97,11 @@ class LatentM(C.Structure):
                 ('dcomb', C.c_void_p * 4), ('dcomb_nslab', C.c_int), ('dcomb_slab_stride', C.c_longlong),
                 ('dml', C.c_void_p * 4), ('dsigma', C.c_void_p),
                 ('rec_partials', C.c_void_p), ('n_rec_partials', C.c_int), ('losses', C.c_void_p),
-                ('rng_stream', C.c_int)]
+                ('rng_stream', C.c_int),
+                ('g1', C.c_void_p * 4), ('dec0_W', C.c_void_p * 4), ('dec0_b', C.c_void_p * 4), ('d', C.c_int * 4),
+                ('comb_alias', C.c_void_p * 4), ('comb_bf16', C.c_void_p * 4), ('combT_bf16', C.c_void_p * 4),
+                ('dml_bf16', C.c_void_p * 4), ('dmlT_bf16', C.c_void_p * 4),
+                ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p)]
 
 
 class PdState(C.Structure):
@@ -126,6 +130,7 @@ EXPORTS = {
     'jamie_latent_bwd': (C.c_int, [C.POINTER(Latent), C.c_void_p]),
     'jamie_latent_m_fwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
     'jamie_latent_m_bwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p]),
+    'jamie_latent_m_colpart_size': (C.c_longlong, [C.c_int, C.c_int]),
     'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
     'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_grad_sqnorm_bf16': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -133,6 +138,8 @@ EXPORTS = {
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'jamie_grad_sqnorm_ranges': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p]),
+    'jamie_grad_sqnorm_ranges_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
     'jamie_sqnorm_range_blocks': (C.c_int, [C.c_void_p, C.c_int]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -287,9 +294,9 @@ def require_gpu():
 # ---------------------------------------------------------------------------------------------------
 def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_stride=0, epi=EPI_STORE,
                  accumulate=False, aux=(None, None, None, None), aux_ld=0, partial=None, a_rows=None,
-                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0, b_tr=False, a_tr=False, store_nt=False):
+                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0, b_tr=False, a_tr=False, store_nt=False, c_bf16=False):
     p = GemmProblem()
-    p.b_tr, p.a_tr, p.store_nt = int(b_tr), int(a_tr), int(store_nt)
+    p.b_tr, p.a_tr, p.store_nt, p.c_bf16 = int(b_tr), int(a_tr), int(store_nt), int(c_bf16)
     p.A, p.B, p.C, p.bias = ptr(A), ptr(B), ptr(Cout), ptr(bias)
     p.aux0, p.aux1, p.aux2, p.aux3 = (ptr(a) for a in aux)
     p.partial, p.a_rows = ptr(partial), ptr(a_rows)
@@ -504,7 +511,12 @@ class SqRanges:
         self.blocks = load().jamie_sqnorm_range_blocks(self.len, self.count)
 
 
-def grad_sqnorm_ranges(g, ranges, partials, state):
+def grad_sqnorm_ranges(g, ranges, partials, state, g16=None):
+    """`g16` (flat bf16, same layout as g): also receives the bf16 copy of every range."""
+    if g16 is not None:
+        _call('jamie_grad_sqnorm_ranges_g16', ptr(g), ptr(g16), ranges.off, ranges.len, ranges.count, ptr(partials),
+              partials.numel(), ptr(state), _stream())
+        return
     _call('jamie_grad_sqnorm_ranges', ptr(g), ranges.off, ranges.len, ranges.count, ptr(partials), partials.numel(),
           ptr(state), _stream())
 

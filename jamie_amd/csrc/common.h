@@ -101,6 +101,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// wave-wide sum on the VALU's DPP lane permutations (no LDS traffic; `__shfl_xor` is a ds_bpermute per stage: with 16 waves
+// reducing 13-18 values each, the shuffles alone took 7 us of a 20 us launch -- tools/stamp_latent.sh).  Quad butterfly
+// (quad_perm), then row_half_mirror and row_mirror leave every lane of a 16-lane row with the row's sum; the four row sums
+// are read with v_readlane and added on the scalar unit.  Fixed order: deterministic.  Result uniform across the wave.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int x = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // block-wide sum; `red` is >= (blockDim.x/64) floats of LDS; result valid in every thread
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

@@ -36,6 +36,7 @@ struct GemmBDev {
     int b_tr;            // B is [K, N] row-major (N contiguous): staged as [k][n] rows, fragments by ds_read_b64_tr_b16
     int a_tr;            // A is [K, M] row-major (M contiguous), likewise (dW = dy^T a reads dy [B, out] and a [B, in])
     int store_nt;        // non-temporal output stores (weight gradients: next read by the optimiser, a whole backward pass later)
+    int c_bf16;          // C is bf16 [M, ldc]: the fp32 accumulators are rounded once on the way out (weight gradients)
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -786,7 +787,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                     local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
                 }
-                if (P.store_nt) {     // streamed past the caches: plain stores left 161 MB of dirty gradient lines per step in
+                if (P.c_bf16) {       // bf16 output (weight gradients for jamie_clip_adam_g16): one 8-byte streaming store
+                    auto bfr = [](float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); };
+                    const unsigned long long pk = (unsigned long long)(bfr(v[0]) | (bfr(v[1]) << 16)) |
+                                                  ((unsigned long long)(bfr(v[2]) | (bfr(v[3]) << 16)) << 32);
+                    unsigned long long* c16 = reinterpret_cast<unsigned long long*>(
+                        reinterpret_cast<unsigned short*>(Cout) + (long long)m * P.ldc + nc);
+                    __builtin_nontemporal_store(pk, c16);
+                } else if (P.store_nt) {     // streamed past the caches: plain stores left 161 MB of dirty gradient lines per step in
                                       // L2 / Infinity Cache, whose write-back ran into the optimiser kernel (229 -> 208 us)
                     __builtin_nontemporal_store(v[0], cp); __builtin_nontemporal_store(v[1], cp + 1);
                     __builtin_nontemporal_store(v[2], cp + 2); __builtin_nontemporal_store(v[3], cp + 3);
@@ -798,7 +806,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
                 for (int e = 0; e < 4; ++e) {
                     if (nc + e >= P.N) continue;
                     float w = v[e];
-                    if (P.epi == JAMIE_EPI_STORE) {
+                    if (P.epi == JAMIE_EPI_STORE && P.c_bf16) {
+                        (reinterpret_cast<unsigned short*>(Cout) + (long long)m * P.ldc + nc)[e] =
+                            __builtin_bit_cast(unsigned short, (__bf16)w);
+                        local += w * w;
+                    } else if (P.epi == JAMIE_EPI_STORE) {
                         if (P.accumulate) w += cp[e];
                         cp[e] = w;
                         local += w * w;
@@ -846,7 +858,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
-        if (s.b_tr || s.a_tr) return jamie_fail(-1, "%s: a_tr / b_tr need a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
+        if (s.b_tr || s.a_tr || s.c_bf16) return jamie_fail(-1, "%s: a_tr / b_tr / c_bf16 need a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         if (s.partial && s.epi == JAMIE_EPI_STORE)
             return jamie_fail(-1, "%s: sum-of-squares partials of a plain store need a large-tile configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         d.a_bytes = (unsigned)(((long long)(s.M - 1) * s.lda + s.K) * 2);
@@ -884,7 +896,10 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
-        d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt;
+        d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt; d.c_bf16 = s.c_bf16;
+        if (s.c_bf16 && !(V2 && s.epi == JAMIE_EPI_STORE && !s.accumulate && d.splitk == 1 && s.bias == nullptr))
+            return jamie_fail(-1, "%s: c_bf16 needs a large-tile configuration, a plain store, no bias, no accumulate, splitk == 1 [%lld %lld]",
+                              "jamie_gemm_bf16", BM, BN);
         if (s.a_tr && !(V2 && BM == 128 && BN == 128 && s.b_tr))
             return jamie_fail(-1, "%s: a_tr (A stored [K, M]) needs b_tr and a 128 x 128 large-tile configuration (24, 25, 29, 30) [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);
@@ -900,7 +915,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     if constexpr (V2) {
         for (int i = 0; i < count; ++i) {
             const jamie_gemm_problem& s = pr[i];
-            g.p[i].vec = (s.ldc % 4 == 0) && ((uintptr_t)s.C % 16 == 0) && (s.slab_stride % 4 == 0) &&
+            g.p[i].vec = (s.ldc % 4 == 0) && ((uintptr_t)s.C % (s.c_bf16 ? 8 : 16) == 0) && (s.slab_stride % 4 == 0) &&
                          (!s.bias || (uintptr_t)s.bias % 16 == 0) &&
                          (s.epi != JAMIE_EPI_MSE || (s.aux_ld % 4 == 0 && (uintptr_t)s.aux0 % 16 == 0));
         }
@@ -1032,11 +1047,42 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(CastGroup g) {
     const int q = threadIdx.x & 15, rr0 = threadIdx.x >> 4;          // 16 column quads x 16 rows per pass
     const bool vec = P.src && (P.ld % 4 == 0) && (((uintptr_t)P.src & 15) == 0) && (P.slab_stride % 4 == 0);
     const bool vecd = P.dst && (P.ldd % 4 == 0) && (((uintptr_t)P.dst & 7) == 0);
+    // fp32 sources with 16-byte rows (the batch gather x = data[idx], slab sums): the loads of all four passes are issued
+    // before the first store -- random rows of a matrix far larger than the caches are HBM misses, and a store between two
+    // passes' loads (the pointers may alias) serialised four such round trips
+    float4 pre[4];
+    const bool prefetch = vec && !P.src_bf && P.nslab <= 4;
+    if (prefetch) {
+        long long gr[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = r0 + rr0 + 16 * pass;
+            gr[pass] = r < P.R ? (P.rows ? (long long)P.rows[r] : (long long)r) : 0;
+        }
+        float4 t[4][4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = r0 + rr0 + 16 * pass, c = c0 + 4 * q;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                t[pass][u] = (r < P.R && c + 3 < P.C && u < P.nslab)
+                                 ? *reinterpret_cast<const float4*>(P.src + u * P.slab_stride + gr[pass] * P.ld + c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            pre[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { pre[pass].x += t[pass][u].x; pre[pass].y += t[pass][u].y; pre[pass].z += t[pass][u].z; pre[pass].w += t[pass][u].w; }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int rr = rr0 + 16 * pass, r = r0 + rr, c = c0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < P.R && P.src_bf) {       // bf16 source (the copy the Adam kernel wrote): half the read traffic
+        if (prefetch && r < P.R && c + 3 < P.C) {
+            v = pre[pass];
+        } else if (r < P.R && P.src_bf) {       // bf16 source (the copy the Adam kernel wrote): half the read traffic
             const unsigned short* sp = P.src_bf + (long long)r * P.ld + c;
             if ((P.ld % 4 == 0) && (((uintptr_t)P.src_bf & 7) == 0) && c + 3 < P.C) {
                 const uint2 u = *reinterpret_cast<const uint2*>(sp);
@@ -1159,6 +1205,35 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
     const int q = threadIdx.x & 15, rr0 = threadIdx.x >> 4;
     const bool vec = (P.C % 4 == 0) && (P.slab_stride % 4 == 0);
     float local = 0.f;
+    // every load of the four passes is issued before the first store (a store between two passes' loads serialises their
+    // round trips: the compiler must assume the pointers alias; slabs four at a time)
+    float4 yv[4], xv[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        yv[pass] = xv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = r0 + rr0 + 16 * pass, c = c0 + 4 * q;
+        if (vec && r < P.R && c < P.C) xv[pass] = *reinterpret_cast<const float4*>(P.x + (long long)r * P.C + c);
+    }
+    if (vec) {
+        for (int s0 = 0; s0 < P.nslab; s0 += 4) {
+            float4 t[4][4];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = r0 + rr0 + 16 * pass, c = c0 + 4 * q;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    t[pass][u] = (r < P.R && c < P.C && s0 + u < P.nslab)
+                                     ? *reinterpret_cast<const float4*>(P.y + (s0 + u) * P.slab_stride + (long long)r * P.C + c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    yv[pass].x += t[pass][u].x; yv[pass].y += t[pass][u].y; yv[pass].z += t[pass][u].z; yv[pass].w += t[pass][u].w;
+                }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int rr = rr0 + 16 * pass, r = r0 + rr, c = c0 + 4 * q;
@@ -1166,12 +1241,7 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
         if (r < P.R && c < P.C) {
             const long long o = (long long)r * P.C + c;
             if (vec) {
-                for (int s = 0; s < P.nslab; ++s) {
-                    const float4 u = *reinterpret_cast<const float4*>(P.y + s * P.slab_stride + o);
-                    v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
-                }
-                const float4 x = *reinterpret_cast<const float4*>(P.x + o);
-                v[0] -= x.x; v[1] -= x.y; v[2] -= x.z; v[3] -= x.w;
+                v[0] = yv[pass].x - xv[pass].x; v[1] = yv[pass].y - xv[pass].y; v[2] = yv[pass].z - xv[pass].z; v[3] = yv[pass].w - xv[pass].w;
                 local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                 v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
                 *reinterpret_cast<float4*>(P.d + o) = make_float4(v[0], v[1], v[2], v[3]);

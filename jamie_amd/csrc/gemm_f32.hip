@@ -765,6 +765,7 @@ extern "C" int jamie_gemm_f32_cfg(const jamie_gemm_problem* pr, int count, int l
         JAMIE_ARG(s.epi != JAMIE_EPI_MSE || (s.aux0 && s.aux_ld >= s.N), "MSE epilogue needs aux0 = X");
         JAMIE_ARG(s.epi != JAMIE_EPI_BN_EVAL || (s.aux0 && s.aux1 && s.aux2 && s.aux3), "BN_EVAL needs aux0..3");
         JAMIE_ARG(layout != JAMIE_TN || s.a_rows == nullptr, "a_rows only for NT/NN");
+        JAMIE_ARG(!s.c_bf16 && !s.b_tr && !s.a_tr, "c_bf16 / a_tr / b_tr belong to jamie_gemm_bf16");
         JAMIE_ARG(s.splitk <= 1 || s.slab_stride >= (long long)s.M * s.ldc, "slab_stride too small");
         if (s.N > max_n) max_n = s.N;
         if (s.M > max_m) max_m = s.M;

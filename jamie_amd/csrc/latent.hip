@@ -434,6 +434,17 @@ extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
 // parity for M = 3 is pinned only against the generalised CPU oracle's autograd.
 // =================================================================================================
 #define LM 4
+// diagnostic build only (-DJAMIE_LAT_STAMP, tools/bench_latent_m.py): thread 0 of workgroup 0 (forward) / of the last workgroup
+// (backward) writes s_memrealtime (100 MHz) deltas into partials[19 * JAMIE_MAX_PARTIALS + k]; nothing reads them
+#ifdef JAMIE_LAT_STAMP
+#define LSTAMP(a, k) do { if (threadIdx.x == 0) (a).partials[19 * JAMIE_MAX_PARTIALS + (k)] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull); } while (0)
+#else
+#define LSTAMP(a, k) do {} while (0)
+#endif
+#define LF_ROWS 32          // cells per workgroup of the fused kernels below
+#define LF_NT 1024          // threads per workgroup: 16 waves, so that every SIMD has four waves to hide latencies behind
+                            // (four waves of four elements each ran this launch in 36 us: one wave per SIMD pays every
+                            // dependent VALU / LDS / memory latency in full)
 enum { SM_MU2 = 0, SM_TROW = 4, SM_AL = 8, SM_F = 12, SM_DSIG = 13, SM_SLOTS = 17 };
 
 struct LatMDev {
@@ -447,147 +458,447 @@ struct LatMDev {
     float* dml[LM]; float* dsigma;
     const float* rec_partials; int n_rec_partials; float* losses;
     int rng_stream;
+    // fused tail: decoder layer 0 (g1_i = comb W_i^T + b_i), bf16 copies, head-bias gradients
+    float* g1[LM]; const float* dec0_W[LM]; const float* dec0_b[LM]; int d[LM];
+    float* comb_alias[LM];
+    unsigned short* comb_bf16[LM]; unsigned short* combT_bf16[LM];
+    unsigned short* dml_bf16[LM]; unsigned short* dmlT_bf16[LM];
+    float* dbias_head[LM]; float* colpart; int accumulate;
+    unsigned* ticket;             // zero-initialised counter of finished backward workgroups (reset by the last one)
+    int chunk_begin[LM + 1];      // column chunks of the decoder product, per modality (prefix sums)
 };
 
-__device__ __forceinline__ void put_partial_m(const LatMDev& a, int slot, float v, float* red) {
-    const float t = block_sum(v, red);
-    if (threadIdx.x == 0) a.partials[slot * JAMIE_MAX_PARTIALS + blockIdx.x] = t;
+// workgroup barrier that publishes LDS only: `__syncthreads()` also drains vmcnt(0), i.e. waits ~2 us for global stores that
+// nobody in the workgroup reads
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(256) void latent_m_fwd_kernel(LatMDev a, const uint64_t* rng) {
-    __shared__ float red[4];
-    const int B = a.B, L = a.L, M = a.M, n = B * L;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = e < n;
-    const int b = ok ? e / L : 0, l = ok ? e % L : 0;
-    float mu2[LM] = {0.f, 0.f, 0.f, 0.f}, trow[LM] = {0.f, 0.f, 0.f, 0.f}, zz[LM] = {0.f, 0.f, 0.f, 0.f};
-    float num = 0.f, S = 0.f;
+// N block-wide sums at once: wave sums on DPP (common.h), ONE pair of barriers for all N, and the cross-wave sums by N
+// threads (thread k adds slot k over the waves, in wave order); the totals are left in red[0 .. N-1] for whoever needs them
+// after the call's final barrier.  `red` holds (blockDim.x / 64) * N + N floats.
+template <int N>
+__device__ __forceinline__ void block_sum_n(float (&v)[N], float* red) {
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(v[k]);
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[N + w * N + k] = v[k];
+    }
+    lds_barrier();
+    if (threadIdx.x < N) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += red[N + i * N + threadIdx.x];
+        red[threadIdx.x] = t;
+    }
+    lds_barrier();
+}
+// ---- forward: ONE launch from the heads' split-K slabs to the decoder's first pre-activation ----
+// Workgroup (rb, chunk): the 32 cells rb*32 .. of the batch and one chunk of COLS output columns of one modality's decoder
+// layer 0.  Phase A (every workgroup, redundantly per chunk: 32 x L elements per modality, a few KB from L2): mu | logvar =
+// sum of the slabs + bias, eps (given, or Philox keyed by the element: the same numbers in every workgroup), z, comb; the
+// workgroups of chunk 0 store them, the bf16 copies and the loss partial sums of their 32 cells.  Phase B: g1[32, COLS] =
+// comb[32, L] W[COLS, L]^T + b in exact fp32 on the vector ALU (K = L <= 128: 0.2 GFLOP per step in all, not MFMA work):
+// comb and the W chunk sit in LDS (W rows padded by one float: conflict-free), a thread owns one column and RPT rows.
+// Replaces four launches of the two-modality path (reparameterise, combine, bf16 casts, the [B, L] x [L, d] GEMM).
+template <int LMAX, int COLS>
+__global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const uint64_t* rng) {
+    constexpr int RPT = LF_ROWS * COLS / LF_NT;        // rows per thread in phase B
+    constexpr int EPT = LF_ROWS * LMAX / LF_NT;        // elements per thread and modality in phase A (upper bound)
+    constexpr int WV = COLS * LMAX / 4 / LF_NT;        // float4 of the W chunk per thread (upper bound)
+    __shared__ float Ws[COLS][LMAX + 1];
+    __shared__ __attribute__((aligned(16))) float Cs[LF_ROWS][LMAX];
+    __shared__ float red[(LF_NT / 64 + 1) * (3 * LM + 1)];
+    const int B = a.B, L = a.L, M = a.M, tid = threadIdx.x;
+    const int n_rb = (B + LF_ROWS - 1) / LF_ROWS;
+    const int rb = blockIdx.x % n_rb, chunk = blockIdx.x / n_rb;
+    const int r0 = rb * LF_ROWS;
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < LM; ++i)
+        if (i < M && chunk >= a.chunk_begin[i]) mi = i;
+    const int c0 = (chunk - a.chunk_begin[mi]) * COLS;
+    const bool owner = chunk == 0;
+    const bool dec = a.g1[mi] != nullptr;
+    if (blockIdx.x == 0) LSTAMP(a, 0);
+    // the W chunk's loads go out first: their latency hides under phase A
+    const int L4 = L >> 2;
+    float4 wreg[WV];
+    if (dec) {
+#pragma unroll
+        for (int t = 0; t < WV; ++t) {
+            const int f = tid + LF_NT * t, c = f / L4, k4 = f % L4;
+            wreg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < COLS * L4 && c0 + c < a.d[mi])
+                wreg[t] = *reinterpret_cast<const float4*>(a.dec0_W[mi] + (long long)(c0 + c) * L + 4 * k4);
+        }
+    }
+    // ---- phase A ----  (all loads and the arithmetic first, results in registers; the stores follow in a second loop:
+    // a store between two elements' loads would serialise their latencies, the pointers may alias for all the compiler knows)
+    float p_mu2[LM] = {0.f, 0.f, 0.f, 0.f}, p_trow[LM] = {0.f, 0.f, 0.f, 0.f}, p_al[LM] = {0.f, 0.f, 0.f, 0.f}, p_f = 0.f;
+    float S = 0.f, sgm[LM];
 #pragma unroll
     for (int i = 0; i < LM; ++i) {
-        if (i >= M || !ok) continue;
-        float mu = a.head_bias[i][l], lv = a.head_bias[i][L + l];
-        for (int s = 0; s < a.ml_nslab; ++s) {
-            const float* p = a.ml[i] + s * a.ml_slab_stride + (long long)b * 2 * L;
-            mu += p[l];
-            lv += p[L + l];
-        }
-        float ep;
-        if (a.eps_in[i]) {
-            ep = a.eps_in[i][e];
-        } else {
-            Philox4 r = jamie_rand4(rng, (uint32_t)(a.rng_stream + i), (uint64_t)e);
-            float n1;
-            jamie_box_muller(r.v[0], r.v[1], ep, n1);
-        }
-        const float z = mu + ep * (expf(0.5f * lv) + 1e-7f);
-        a.mu[i][e] = mu; a.lv[i][e] = lv; a.eps[i][e] = ep; a.z[i][e] = z;
-        zz[i] = z;
-        mu2[i] = mu * mu;
-        if (i == M - 1 && b < M) trow[b] = 1.f + lv - expf(lv);
-        const float sg = a.sigma[i];
-        num += sg * z;
-        S += sg;
+        sgm[i] = i < M ? a.sigma[i] : 0.f;
+        S += sgm[i];
     }
-    const float comb = ok ? num / S : 0.f;
-    if (ok) a.comb[e] = comb;
+    float v_mu[EPT][LM], v_lv[EPT][LM], v_ep[EPT][LM], v_z[EPT][LM], v_comb[EPT];
+    // the slab loop is the OUTER loop: one round trip per slab for all of a thread's elements (inside the element loop
+    // its runtime trip count serialised 3 x EPT x M dependent round trips: 36 us for this launch)
 #pragma unroll
-    for (int i = 0; i < LM; ++i) {
-        if (i >= M) continue;            // uniform
-        put_partial_m(a, SM_MU2 + i, mu2[i], red);
-        put_partial_m(a, SM_TROW + i, trow[i], red);
-        put_partial_m(a, SM_AL + i, ok ? (zz[i] - comb) * (zz[i] - comb) : 0.f, red);
+    for (int j = 0; j < EPT; ++j) {
+        const int el = tid + LF_NT * j;
+        const int row = el / L, l = el % L, b = r0 + row;
+        const bool ok = el < LF_ROWS * L && b < B;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            v_mu[j][i] = (i < M && ok) ? a.head_bias[i][l] : 0.f;
+            v_lv[j][i] = (i < M && ok) ? a.head_bias[i][L + l] : 0.f;
+        }
     }
-    put_partial_m(a, SM_F, comb * comb, red);
+    for (int s0 = 0; s0 < a.ml_nslab; s0 += 4) {          // four slabs' loads in flight per round trip, added in slab order
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int el = tid + LF_NT * j;
+            const int row = el / L, l = el % L, b = r0 + row;
+            const bool ok = el < LF_ROWS * L && b < B;
+#pragma unroll
+            for (int i = 0; i < LM; ++i) {
+                if (i >= M || !ok) continue;
+                float tm[4], tl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* p = a.ml[i] + (s0 + u) * a.ml_slab_stride + (long long)b * 2 * L;
+                    tm[u] = s0 + u < a.ml_nslab ? p[l] : 0.f;
+                    tl[u] = s0 + u < a.ml_nslab ? p[L + l] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v_mu[j][i] += tm[u]; v_lv[j][i] += tl[u]; }
+            }
+        }
+    }
+    if (blockIdx.x == 0) LSTAMP(a, 4);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int el = tid + LF_NT * j;
+        const int row = el / L, l = el % L, b = r0 + row;
+        const bool ok = el < LF_ROWS * L && b < B;
+        const int e = ok ? b * L + l : 0;
+        float num = 0.f;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            v_ep[j][i] = v_z[j][i] = 0.f;
+            if (i >= M || !ok) continue;
+            const float mu = v_mu[j][i], lv = v_lv[j][i];
+            float ep;
+            if (a.eps_in[i]) {
+                ep = a.eps_in[i][e];
+            } else {
+                Philox4 r = jamie_rand4(rng, (uint32_t)(a.rng_stream + i), (uint64_t)e);
+                float n1;
+                jamie_box_muller(r.v[0], r.v[1], ep, n1);
+            }
+            const float z = mu + ep * (expf(0.5f * lv) + 1e-7f);
+            v_mu[j][i] = mu; v_lv[j][i] = lv; v_ep[j][i] = ep; v_z[j][i] = z;
+            num += sgm[i] * z;
+        }
+        v_comb[j] = ok ? num / S : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int el = tid + LF_NT * j;
+        if (el >= LF_ROWS * L) continue;
+        const int row = el / L, l = el % L, b = r0 + row;
+        const float comb = v_comb[j];
+        Cs[row][l] = comb;
+        if (b >= B || !owner) continue;
+        const int e = b * L + l;
+        a.comb[e] = comb;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            if (i >= M) continue;
+            a.mu[i][e] = v_mu[j][i]; a.lv[i][e] = v_lv[j][i]; a.eps[i][e] = v_ep[j][i]; a.z[i][e] = v_z[j][i];
+            p_mu2[i] += v_mu[j][i] * v_mu[j][i];
+            if (i == M - 1 && b < M) p_trow[b] += 1.f + v_lv[j][i] - expf(v_lv[j][i]);
+            if (a.comb_alias[i]) a.comb_alias[i][e] = comb;
+            if (a.comb_bf16[i]) a.comb_bf16[i][e] = to_bf16(comb);
+            if (a.combT_bf16[i]) a.combT_bf16[i][(long long)l * B + b] = to_bf16(comb);
+            p_al[i] += (v_z[j][i] - comb) * (v_z[j][i] - comb);
+        }
+        p_f += comb * comb;
+    }
+    if (blockIdx.x == 0) LSTAMP(a, 1);
+    if (owner) {           // (uniform per workgroup)
+        float pv[3 * LM + 1];
+#pragma unroll
+        for (int i = 0; i < LM; ++i) { pv[i] = p_mu2[i]; pv[LM + i] = p_trow[i]; pv[2 * LM + i] = p_al[i]; }
+        pv[3 * LM] = p_f;
+        block_sum_n<3 * LM + 1>(pv, red);
+        // slots SM_MU2 + i = i, SM_TROW + i = LM + i, SM_AL + i = 2 LM + i, SM_F = 3 LM
+        if (tid < 3 * LM + 1) a.partials[tid * JAMIE_MAX_PARTIALS + rb] = red[tid];
+        lds_barrier();
+    }
+    if (blockIdx.x == 0) LSTAMP(a, 2);
+    if (!dec) return;
+    // ---- phase B ----
+#pragma unroll
+    for (int t = 0; t < WV; ++t) {
+        const int f = tid + LF_NT * t, c = f / L4, k4 = f % L4;
+        if (f < COLS * L4) {
+            Ws[c][4 * k4] = wreg[t].x; Ws[c][4 * k4 + 1] = wreg[t].y; Ws[c][4 * k4 + 2] = wreg[t].z; Ws[c][4 * k4 + 3] = wreg[t].w;
+        }
+    }
+    lds_barrier();
+    const int c = tid % COLS, rbase = (tid / COLS) * RPT;
+    float acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
+    for (int k4 = 0; k4 < L4; ++k4) {
+        const float w0 = Ws[c][4 * k4], w1 = Ws[c][4 * k4 + 1], w2 = Ws[c][4 * k4 + 2], w3 = Ws[c][4 * k4 + 3];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const float4 cv = *reinterpret_cast<const float4*>(&Cs[rbase + r][4 * k4]);      // broadcast read
+            acc[r] = fmaf(cv.x, w0, acc[r]);
+            acc[r] = fmaf(cv.y, w1, acc[r]);
+            acc[r] = fmaf(cv.z, w2, acc[r]);
+            acc[r] = fmaf(cv.w, w3, acc[r]);
+        }
+    }
+    if (blockIdx.x == 0) LSTAMP(a, 3);
+    if (c0 + c < a.d[mi]) {
+        const float bias = a.dec0_b[mi][c0 + c];
+        float* out = a.g1[mi] + c0 + c;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int b = r0 + rbase + r;
+            if (b < B) out[(long long)b * a.d[mi]] = acc[r] + bias;
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void latent_m_bwd_kernel(LatMDev a) {
-    __shared__ float red[4];
-    const int B = a.B, L = a.L, M = a.M, n = B * L;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = e < n;
+template <int LMAX>
+__device__ __forceinline__ void latent_m_finalise(const LatMDev& a, float* red) {
+    const int B = a.B, L = a.L, M = a.M, n = B * L, NT = blockDim.x, tid = threadIdx.x;
+    const int nblk = (B + LF_ROWS - 1) / LF_ROWS;
+    const float invBL = 1.f / (float)n;
+    // inputs written by other CUs (cold in this CU's caches): every load is issued before the first use, so this costs
+    // about one memory round trip instead of one per dependent step
+    const float kl_scale = a.hyper[0], w_rec = a.hyper[1], w_al = a.hyper[2], w_f = a.hyper[3];
+    const float best = a.losses[5];
+    float v[SM_SLOTS + 1];
+#pragma unroll
+    for (int sl = 0; sl < SM_SLOTS; ++sl)           // 17 independent loads
+        v[sl] = tid < nblk ? a.partials[sl * JAMIE_MAX_PARTIALS + tid] : 0.f;
+    v[SM_SLOTS] = tid < a.n_rec_partials ? a.rec_partials[tid] : 0.f;
+    // head-bias gradients = column sums of d(mu | logvar): the workgroups' partial sums, added in workgroup order; the
+    // first 16 partial sums of this thread's column are loaded together
+    const bool col_ok = a.colpart && tid < M * 2 * L && a.dbias_head[(tid / (2 * L)) & 3] != nullptr;
+    const int ci = col_ok ? tid / (2 * L) : 0, cc = col_ok ? tid % (2 * L) : 0;
+    float t[16], prev = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = (col_ok && u < nblk) ? a.colpart[((long long)u * LM + ci) * 2 * LMAX + cc] : 0.f;
+    if (col_ok && a.accumulate) prev = a.dbias_head[ci][cc];
+    // (rare shapes: more partial sums than the first batch)
+    for (int i = tid + NT; i < nblk; i += NT)
+#pragma unroll
+        for (int sl = 0; sl < SM_SLOTS; ++sl) v[sl] += a.partials[sl * JAMIE_MAX_PARTIALS + i];
+    for (int i = tid + NT; i < a.n_rec_partials; i += NT) v[SM_SLOTS] += a.rec_partials[i];
+    LSTAMP(a, 11);
+    if (col_ok) {
+        float acc = prev;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += t[u];
+        for (int rb = 16; rb < nblk; ++rb) acc += a.colpart[((long long)rb * LM + ci) * 2 * LMAX + cc];
+        a.dbias_head[ci][cc] = acc;
+    }
+    if (a.colpart) {            // more columns than threads: the remaining ones, the plain way
+        for (int idx = tid + NT; idx < M * 2 * L; idx += NT) {
+            const int i = idx / (2 * L), cidx = idx % (2 * L);
+            if (!a.dbias_head[i]) continue;
+            float acc = a.accumulate ? a.dbias_head[i][cidx] : 0.f;
+            for (int rb = 0; rb < nblk; ++rb) acc += a.colpart[((long long)rb * LM + i) * 2 * LMAX + cidx];
+            a.dbias_head[i][cidx] = acc;
+        }
+    }
+    LSTAMP(a, 12);
+    block_sum_n<SM_SLOTS + 1>(v, red);
+    LSTAMP(a, 13);
+    if (tid == 0) {
+        const float rec = red[SM_SLOTS];
+        float kl = 0.f, al = 0.f;
+        for (int i = 0; i < M; ++i) {
+            kl += -0.5f * (red[SM_TROW + i] / (float)L - red[SM_MU2 + i] * invBL);
+            al += red[SM_AL + i];
+            a.dsigma[i] = red[SM_DSIG + i];
+        }
+        const float l_kl = kl_scale * kl, l_rec = w_rec * rec, l_al = w_al * al * invBL, l_f = w_f * red[SM_F] * invBL;
+        const float total = l_kl + l_rec + l_al + l_f;
+        a.losses[0] = l_kl; a.losses[1] = l_rec; a.losses[2] = l_al; a.losses[3] = l_f;
+        a.losses[4] = total;
+        a.losses[5] = fminf(best, total);
+    }
+}
+
+// ---- backward: d(mu | logvar) (+ bf16 copies), per-workgroup partial sums of d(sigma) and of the head-bias gradients ----
+template <int LMAX>
+__global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a) {
+    constexpr int EPT = LF_ROWS * LMAX / LF_NT;
+    __shared__ float red[(LF_NT / 64 + 1) * (SM_SLOTS + 1)];
+    __shared__ float T[LF_ROWS][2 * LMAX + 1];            // one modality's d(mu | logvar) of this workgroup's cells
+    const int B = a.B, L = a.L, M = a.M, n = B * L, tid = threadIdx.x;
+    const int rb = blockIdx.x, r0 = rb * LF_ROWS;
     const float invBL = 1.f / (float)n;
     const float kl_scale = a.hyper[0], w_al = a.hyper[2], w_f = a.hyper[3];
     float ds[LM] = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-        const int b = e / L, l = e % L;
+    if (blockIdx.x == 0) LSTAMP(a, 8);
+    float S = 0.f, sgm[LM];
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        sgm[i] = i < M ? a.sigma[i] : 0.f;
+        S += sgm[i];
+    }
+    // loads and arithmetic first (see the forward kernel), results in registers; the slab loop of the upstream gradient
+    // d comb (every modality's decoder contributes; split-K slabs) is the outer loop: one round trip per slab
+    float v_dmu[EPT][LM], v_dlv[EPT][LM], v_up[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v_up[j] = 0.f;
+    for (int s0 = 0; s0 < a.dcomb_nslab; s0 += 4) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int el = tid + LF_NT * j;
+            const int row = el / L, l = el % L, b = r0 + row;
+            if (el >= LF_ROWS * L || b >= B) continue;
+            float tu[LM][4];
+#pragma unroll
+            for (int i = 0; i < LM; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    tu[i][u] = (i < M && s0 + u < a.dcomb_nslab) ? a.dcomb[i][(long long)b * L + l + (s0 + u) * a.dcomb_slab_stride] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < LM; ++i) v_up[j] += tu[i][u];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int el = tid + LF_NT * j;
+        const int row = el / L, l = el % L, b = r0 + row;
+        const bool ok = el < LF_ROWS * L && b < B;
+        const int e = ok ? b * L + l : 0;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) v_dmu[j][i] = v_dlv[j][i] = 0.f;
+        if (!ok) continue;
         const float comb = a.comb[e];
-        float S = 0.f, G = w_f * 2.f * comb * invBL;         // F loss acts on combined[0]
+        float G = w_f * 2.f * comb * invBL + v_up[j];         // F loss acts on combined[0]; + the decoders' d comb
         float ga[LM], zz[LM];
 #pragma unroll
         for (int i = 0; i < LM; ++i) {
             if (i >= M) continue;
-            S += a.sigma[i];
             zz[i] = a.z[i][e];
             ga[i] = w_al * 2.f * (zz[i] - comb) * invBL;      // d CosSim / d z_i ;  -ga[i] is d / d comb_i
             G -= ga[i];
-            for (int s = 0; s < a.dcomb_nslab; ++s) G += a.dcomb[i][e + s * a.dcomb_slab_stride];
         }
 #pragma unroll
         for (int i = 0; i < LM; ++i) {
             if (i >= M) continue;
-            const float dz = a.sigma[i] / S * G + ga[i];
+            const float dz = sgm[i] / S * G + ga[i];
             const float lv = a.lv[i][e];
             const float dmu = dz + kl_scale * a.mu[i][e] * invBL;
             float dlv = dz * a.eps[i][e] * 0.5f * expf(0.5f * lv);
             if (i == M - 1 && b < M) dlv += kl_scale * (-0.5f) * (1.f - expf(lv)) / (float)L;
-            a.dml[i][(long long)b * 2 * L + l] = dmu;
-            a.dml[i][(long long)b * 2 * L + L + l] = dlv;
-            ds[i] = G * (zz[i] - comb) / S;
+            v_dmu[j][i] = dmu; v_dlv[j][i] = dlv;
+            ds[i] += G * (zz[i] - comb) / S;
         }
     }
+    // stores, and per modality the column sums over the workgroup's 32 cells through an LDS tile (rows added in order)
 #pragma unroll
     for (int i = 0; i < LM; ++i) {
-        if (i >= M) continue;
-        put_partial_m(a, SM_DSIG + i, ds[i], red);
+        if (i >= M) continue;          // uniform
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int el = tid + LF_NT * j;
+            if (el >= LF_ROWS * L) continue;
+            const int row = el / L, l = el % L, b = r0 + row;
+            T[row][l] = v_dmu[j][i]; T[row][L + l] = v_dlv[j][i];       // (rows beyond B hold zeros)
+            if (b >= B) continue;
+            a.dml[i][(long long)b * 2 * L + l] = v_dmu[j][i];
+            a.dml[i][(long long)b * 2 * L + L + l] = v_dlv[j][i];
+            if (a.dml_bf16[i]) {
+                a.dml_bf16[i][(long long)b * 2 * L + l] = to_bf16(v_dmu[j][i]);
+                a.dml_bf16[i][(long long)b * 2 * L + L + l] = to_bf16(v_dlv[j][i]);
+            }
+            if (a.dmlT_bf16[i]) {
+                a.dmlT_bf16[i][(long long)l * B + b] = to_bf16(v_dmu[j][i]);
+                a.dmlT_bf16[i][(long long)(L + l) * B + b] = to_bf16(v_dlv[j][i]);
+            }
+        }
+        lds_barrier();
+        if (a.colpart && tid < 2 * L) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int row = 0; row < LF_ROWS; ++row) v += T[row][tid];
+            a.colpart[((long long)rb * LM + i) * 2 * LMAX + tid] = v;
+        }
+        lds_barrier();
     }
-    // the last block to finish cannot be known without a counter; block 0 of a SECOND tiny launch finalises
+    LSTAMP(a, 9);
+    block_sum_n<LM>(ds, red);
+    if (tid < M) a.partials[(SM_DSIG + tid) * JAMIE_MAX_PARTIALS + rb] = red[tid];
+    // ---- the workgroup that finishes LAST finalises (losses, d sigma, head-bias gradients): a ticket counter instead of a
+    // second launch.  Hand-off as MI355X_MICROARCH.md prescribes: every storing wave drains its stores, workgroup barrier,
+    // one lane releases at agent scope and takes the ticket; the last one acquires at agent scope before anyone reads.
+    __shared__ int is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = ticket == gridDim.x - 1;
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *a.ticket = 0u;                        // for the next launch (visible at the kernel boundary)
+        }
+    }
+    __syncthreads();
+    if (is_last) { LSTAMP(a, 10); latent_m_finalise<LMAX>(a, red); LSTAMP(a, 14); }
 }
 
-__global__ __launch_bounds__(256) void latent_m_final_kernel(LatMDev a) {
-    __shared__ float red[4];
-    const int B = a.B, L = a.L, M = a.M, n = B * L;
-    const int nblk = (n + 255) / 256;
-    const float invBL = 1.f / (float)n;
-    float tot[SM_SLOTS];
-#pragma unroll
-    for (int sl = 0; sl < SM_SLOTS; ++sl) {
-        float v = 0.f;
-        for (int i = threadIdx.x; i < nblk; i += 256) v += a.partials[sl * JAMIE_MAX_PARTIALS + i];
-        tot[sl] = block_sum(v, red);
-    }
-    float rec = 0.f;
-    for (int i = threadIdx.x; i < a.n_rec_partials; i += 256) rec += a.rec_partials[i];
-    rec = block_sum(rec, red);
-    if (threadIdx.x == 0) {
-        const float kl_scale = a.hyper[0], w_rec = a.hyper[1], w_al = a.hyper[2], w_f = a.hyper[3];
-        float kl = 0.f, al = 0.f;
-        for (int i = 0; i < M; ++i) {
-            kl += -0.5f * (tot[SM_TROW + i] / (float)L - tot[SM_MU2 + i] * invBL);
-            al += tot[SM_AL + i];
-            a.dsigma[i] = tot[SM_DSIG + i];
-        }
-        const float l_kl = kl_scale * kl, l_rec = w_rec * rec, l_al = w_al * al * invBL, l_f = w_f * tot[SM_F] * invBL;
-        const float total = l_kl + l_rec + l_al + l_f;
-        a.losses[0] = l_kl; a.losses[1] = l_rec; a.losses[2] = l_al; a.losses[3] = l_f;
-        a.losses[4] = total;
-        a.losses[5] = fminf(a.losses[5], total);
-    }
-}
+static int latm_cols(int L) { return L <= 32 ? 256 : (L <= 64 ? 128 : 64); }
 
 static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
     JAMIE_ARG(a != nullptr, "null descriptor");
     JAMIE_ARG(a->M >= 2 && a->M <= LM, "2 <= M <= 4");
-    JAMIE_ARG(a->B >= a->M && a->L >= 1, "B >= M (KL uses rows 0..M-1), L >= 1");
-    JAMIE_ARG((long long)a->B * a->L <= 256LL * JAMIE_MAX_PARTIALS, "B*L too large for the partial buffer");
+    JAMIE_ARG(a->B >= a->M && a->L >= 4 && a->L % 4 == 0 && a->L <= 128, "B >= M (KL uses rows 0..M-1), L a multiple of 4, <= 128");
+    JAMIE_ARG((a->B + LF_ROWS - 1) / LF_ROWS <= JAMIE_MAX_PARTIALS, "B too large for the partial buffer");
     JAMIE_ARG(a->sigma && a->hyper && a->partials && a->comb, "null pointer");
     memset(&d, 0, sizeof(d));
     d.B = a->B; d.L = a->L; d.M = a->M;
+    const int cols = latm_cols(a->L);
+    int chunks = 0;
     for (int i = 0; i < a->M; ++i) {
         JAMIE_ARG(a->mu[i] && a->lv[i] && a->z[i] && a->eps[i], "null state buffer");
         d.ml[i] = a->ml[i]; d.head_bias[i] = a->head_bias[i]; d.eps_in[i] = a->eps_in[i];
         d.mu[i] = a->mu[i]; d.lv[i] = a->lv[i]; d.z[i] = a->z[i]; d.eps[i] = a->eps[i];
         d.dcomb[i] = a->dcomb[i]; d.dml[i] = a->dml[i];
+        d.g1[i] = a->g1[i]; d.dec0_W[i] = a->dec0_W[i]; d.dec0_b[i] = a->dec0_b[i]; d.d[i] = a->d[i];
+        JAMIE_ARG(!a->g1[i] || (a->dec0_W[i] && a->dec0_b[i] && a->d[i] > 0 && ((uintptr_t)a->dec0_W[i] % 16) == 0),
+                  "decoder layer 0: W (16-byte aligned), b, d");
+        d.comb_alias[i] = a->comb_alias[i] == a->comb ? nullptr : a->comb_alias[i];
+        d.dml_bf16[i] = (unsigned short*)a->dml_bf16[i]; d.dmlT_bf16[i] = (unsigned short*)a->dmlT_bf16[i];
+        d.comb_bf16[i] = (unsigned short*)a->comb_bf16[i]; d.combT_bf16[i] = (unsigned short*)a->combT_bf16[i];
+        d.dbias_head[i] = a->dbias_head[i];
+        d.chunk_begin[i] = chunks;
+        chunks += a->g1[i] ? (a->d[i] + cols - 1) / cols : (i == 0 ? 1 : 0);
     }
+    for (int i = a->M; i <= LM; ++i) d.chunk_begin[i] = chunks;
+    if (chunks == 0) d.chunk_begin[LM] = chunks = 1;
+    d.colpart = a->colpart; d.accumulate = a->accumulate; d.ticket = a->ticket;
     d.ml_nslab = a->ml_nslab; d.ml_slab_stride = a->ml_slab_stride;
     d.sigma = a->sigma; d.hyper = a->hyper; d.comb = a->comb; d.partials = a->partials;
     d.dcomb_nslab = a->dcomb_nslab; d.dcomb_slab_stride = a->dcomb_slab_stride;
@@ -607,8 +918,13 @@ extern "C" int jamie_latent_m_fwd(const jamie_latent_m* a, const uint64_t* rng, 
     }
     JAMIE_ARG(a->ml_nslab >= 1 && (a->ml_nslab == 1 || a->ml_slab_stride >= (long long)a->B * 2 * a->L), "ml slabs");
     JAMIE_ARG(!need_rng || rng, "rng state required when eps is not given");
-    const int nblk = (a->B * a->L + 255) / 256;
-    hipLaunchKernelGGL(latent_m_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d, rng);
+    // chunk 0 must exist and belong to a workgroup that stores the latents: with no decoder product at all there is one
+    const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS;
+    const int nblk = n_rb * d.chunk_begin[LM];
+    hipStream_t st = (hipStream_t)stream;
+    if (a->L <= 32) hipLaunchKernelGGL((latent_m_fwd_kernel<32, 256>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);
+    else if (a->L <= 64) hipLaunchKernelGGL((latent_m_fwd_kernel<64, 128>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);
+    else hipLaunchKernelGGL((latent_m_fwd_kernel<128, 64>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);
     return jamie_launch_status("jamie_latent_m_fwd");
 }
 
@@ -618,10 +934,23 @@ extern "C" int jamie_latent_m_bwd(const jamie_latent_m* a, void* stream) {
     if (rc) return rc;
     for (int i = 0; i < a->M; ++i) JAMIE_ARG(a->dcomb[i] && a->dml[i], "dcomb / dml");
     JAMIE_ARG(a->dsigma && a->losses && a->dcomb_nslab >= 1, "null output");
+    JAMIE_ARG(a->ticket != nullptr, "ticket: a zero-initialised device uint32 is required");
     JAMIE_ARG(a->dcomb_nslab == 1 || a->dcomb_slab_stride >= (long long)a->B * a->L, "dcomb_slab_stride too small");
     JAMIE_ARG(a->n_rec_partials == 0 || a->rec_partials, "rec_partials");
-    const int nblk = (a->B * a->L + 255) / 256;
-    hipLaunchKernelGGL(latent_m_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d);
-    hipLaunchKernelGGL(latent_m_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d);
+    const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->L <= 32) {
+        hipLaunchKernelGGL((latent_m_bwd_kernel<32>), dim3(n_rb), dim3(LF_NT), 0, st, d);
+    } else if (a->L <= 64) {
+        hipLaunchKernelGGL((latent_m_bwd_kernel<64>), dim3(n_rb), dim3(LF_NT), 0, st, d);
+    } else {
+        hipLaunchKernelGGL((latent_m_bwd_kernel<128>), dim3(n_rb), dim3(LF_NT), 0, st, d);
+    }
     return jamie_launch_status("jamie_latent_m_bwd");
+}
+
+/* workspace for the head-bias partial sums: floats */
+extern "C" long long jamie_latent_m_colpart_size(int B, int L) {
+    const int lmax = L <= 32 ? 32 : (L <= 64 ? 64 : 128);
+    return (long long)((B + LF_ROWS - 1) / LF_ROWS) * LM * 2 * lmax;
 }

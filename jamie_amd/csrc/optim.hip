@@ -146,20 +146,24 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
 // elements per workgroup; also advances the step counter, as jamie_grad_sqnorm does.
 #define JAMIE_SQ_CHUNK 4096
 struct SqRanges { long long off[128]; int len[128]; };
-__global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, SqRanges r, float* partials,
-                                                                 uint64_t* state) {
+__global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, unsigned short* __restrict__ g16,
+                                                                 SqRanges r, float* partials, uint64_t* state) {
     __shared__ float red[4];
     const float* p = g + r.off[blockIdx.x];
+    unsigned short* q = g16 ? g16 + r.off[blockIdx.x] : nullptr;          // bf16 copy of the range (same offsets)
     const int n = r.len[blockIdx.x], n4 = n >> 2;
     float acc = 0.f;
+    auto bf = [](float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); };
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
         for (int i = threadIdx.x; i < n4; i += 256) {
             const float4 v = reinterpret_cast<const float4*>(p)[i];
             acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (q) *reinterpret_cast<uint2*>(q + 4 * i) = make_uint2((unsigned)bf(v.x) | ((unsigned)bf(v.y) << 16),
+                                                                      (unsigned)bf(v.z) | ((unsigned)bf(v.w) << 16));
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += p[i] * p[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) { acc += p[i] * p[i]; if (q) q[i] = bf(p[i]); }
     } else {
-        for (int i = threadIdx.x; i < n; i += 256) acc += p[i] * p[i];
+        for (int i = threadIdx.x; i < n; i += 256) { acc += p[i] * p[i]; if (q) q[i] = bf(p[i]); }
     }
     const float t = block_sum(acc, red);
     if (threadIdx.x == 0) {
@@ -168,13 +172,14 @@ __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __
     }
 }
 
-extern "C" int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets, const long long* lengths, int count,
-                                        float* partials, int n_partials, uint64_t* state, void* stream) {
+static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offsets, const long long* lengths, int count,
+                              float* partials, int n_partials, uint64_t* state, void* stream) {
     JAMIE_ARG(g && offsets && lengths && partials && count >= 1, "null pointer / empty");
     SqRanges r;
     int nb = 0;
     for (int i = 0; i < count; ++i) {
         JAMIE_ARG(offsets[i] >= 0 && lengths[i] >= 0, "negative range");
+        JAMIE_ARG(!g16 || offsets[i] % 4 == 0, "bf16 copies need range offsets that are multiples of 4");
         for (long long o = 0; o < lengths[i]; o += JAMIE_SQ_CHUNK) {
             JAMIE_ARG(nb < 128, "more than 128 chunks of 4096 elements");
             r.off[nb] = offsets[i] + o;
@@ -183,8 +188,21 @@ extern "C" int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets
         }
     }
     JAMIE_ARG(nb >= 1 && n_partials == nb, "n_partials must equal jamie_sqnorm_range_blocks()");
-    hipLaunchKernelGGL(grad_sqnorm_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, r, partials, state);
+    JAMIE_ARG(!g16 || ((uintptr_t)g16 % 8) == 0, "g_bf16 must be 8-byte aligned");
+    hipLaunchKernelGGL(grad_sqnorm_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (unsigned short*)g16, r, partials,
+                       state);
     return jamie_launch_status("jamie_grad_sqnorm_ranges");
+}
+
+extern "C" int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets, const long long* lengths, int count,
+                                        float* partials, int n_partials, uint64_t* state, void* stream) {
+    return sqnorm_ranges_impl(g, nullptr, offsets, lengths, count, partials, n_partials, state, stream);
+}
+
+extern "C" int jamie_grad_sqnorm_ranges_g16(const float* g, void* g_bf16, const long long* offsets, const long long* lengths,
+                                            int count, float* partials, int n_partials, uint64_t* state, void* stream) {
+    JAMIE_ARG(g_bf16 != nullptr, "null bf16 gradient buffer");
+    return sqnorm_ranges_impl(g, g_bf16, offsets, lengths, count, partials, n_partials, state, stream);
 }
 
 extern "C" int jamie_sqnorm_range_blocks(const long long* lengths, int count) {

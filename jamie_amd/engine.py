@@ -6,6 +6,7 @@ GEMM/BN/act x2 -> output GEMM with fused MSE -> backward of all of it -> clip + 
 All buffers are allocated once per batch size; no step allocates, synchronises or reads back.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -99,7 +100,7 @@ def kl_anneal(epoch, min_epochs, epoch_DNN):
 
 class TrainEngine:
     def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
-                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=False):
+                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=False, grad_bf16=False):
         """compute_dtype 'f32': exact-fp32 MFMA GEMMs (the parity configuration).  'bf16': bf16 MFMA GEMMs with
         fp32 accumulation, fp32 master weights / optimiser / BatchNorm / losses (BASELINE config 2); needs every
         feature count, the latent size and the batch size to be multiples of 8."""
@@ -149,6 +150,8 @@ class TrainEngine:
         self.losses = torch.zeros(8, **f32)
         self.reset_best()
         self.lat_partials = torch.zeros(20 * nv.load().jamie_max_partials(), **f32)
+        self.lat_ticket = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.lat_colpart = torch.zeros(int(nv.load().jamie_latent_m_colpart_size(B, L)) if (L % 4 == 0 and L <= 128) else 1, **f32)
         # ---- per-modality workspace ----
         self.ws = []
         # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
@@ -277,6 +280,17 @@ class TrainEngine:
                 self.fused_norm = True
                 self.n_dw_partials = off
                 self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm), **f32)
+        # ---- weight gradients in bf16 (bf16 compute mode, one GPU, fused norm): the large dW launches round their fp32
+        # accumulators once on the way out into `grad16` (same flat layout as `grad`), the small ranges (biases, BatchNorm
+        # affine parameters, sigma, the skinny matrices) are copied there by the range-norm kernel, and clip + Adam reads
+        # 2 instead of 4 bytes of gradient per parameter (26 instead of 28 bytes per parameter in all; the dW launches
+        # store 80 instead of 161 MB per step).  The norm partials are sums of squares of the fp32 values.  Not with
+        # accumulating gradients (batch_step=False): set_grad_bf16(False) before the first backward pass of such a run.
+        self.grad_bf16 = bool(grad_bf16) and self.fused_norm
+        self._g16_now = self._g16_last = self._g16_pending = False
+        if self.grad_bf16:
+            self.grad16 = torch.zeros(n, device=self.dev, dtype=torch.bfloat16)
+            self.g16 = model.layout.views(self.grad16)
         bm_t, bn_t = (nv.gemm_bf16_tile(B, max(self.dims)) if self.bf16 else
                       nv.gemm_tile(nv.NT, B, max(self.dims), 2 * max(self.dims)))   # tile of the grouped launch
         self.rec_tiles = [math.ceil(B / bm_t) * math.ceil(d / bn_t) for d in self.dims]
@@ -555,9 +569,10 @@ class TrainEngine:
         dW = self.g[f'm{i}.{lin}.W']
         nout, nin = dW.shape
         if self._dw_tr(lin):      # dy [B, out], a [B, in] row-major as produced: no transposed copies
-            return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], dW, nout, nin, self.B, nout, nin, nin,
-                                   accumulate=self.accumulate, partial=self._dw_partial(i, lin), a_tr=True, b_tr=True,
-                                   store_nt=True)
+            g16 = self._g16_now and f'm{i}.{lin}' in self.dw_partial
+            return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], self.g16[f'm{i}.{lin}.W'] if g16 else dW, nout, nin,
+                                   self.B, nout, nin, nin, accumulate=self.accumulate, partial=self._dw_partial(i, lin),
+                                   a_tr=True, b_tr=True, store_nt=True, c_bf16=g16)
         # (dy^T) (a^T)^T on the [features, B] copies, K (= batch) contiguous
         return nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
                                accumulate=self.accumulate, partial=self._dw_partial(i, lin), store_nt=True)
@@ -593,7 +608,9 @@ class TrainEngine:
         nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
-        """M > 2: fully paired cells only (identity correspondence, F = 0, euclidean alignment)."""
+        """Identity correspondence, F = 0, euclidean alignment (every BASELINE config; any 2 <= M <= 4): the fused latent
+        kernels (jamie_latent_m_*): forward = heads' slabs -> mu / logvar / z / comb / loss partials AND decoder layer 0
+        in one launch; backward = d(mu | logvar) + head-bias gradients + losses in two."""
         if corr is not None or Fblk is not None or self.cosine:
             raise NotImplementedError('more than two modalities: identity correspondence, F = 0, euclidean only')
         B, L = self.B, self.L
@@ -606,7 +623,18 @@ class TrainEngine:
             for k in ('mu', 'lv', 'z', 'eps', 'dml'):
                 getattr(d, k)[i] = nv.ptr(w[k])
             d.dcomb[i] = nv.ptr(w['dcomb'])
+            d.comb_alias[i] = nv.ptr(w['comb'])
+            d.g1[i] = nv.ptr(w['g1'])
+            d.dec0_W[i], d.dec0_b[i] = nv.ptr(self.m.p[f'm{i}.dec0.W']), nv.ptr(self.m.p[f'm{i}.dec0.b'])
+            d.d[i] = self.dims[i]
+            d.dbias_head[i] = nv.ptr(self.g[f'm{i}.head.b'])
+            if self.bf16:
+                d.dml_bf16[i] = nv.ptr(w['dml_bf'])
+                d.dmlT_bf16[i] = nv.ptr(w['dml_T']) if 'dml' in self.need_T else None
+                d.comb_bf16[i] = nv.ptr(w['comb_bf'])
+                d.combT_bf16[i] = nv.ptr(w['comb_T']) if 'comb' in self.need_T else None
         d.comb = nv.ptr(self.ws[0]['comb'])
+        d.colpart, d.accumulate, d.ticket = nv.ptr(self.lat_colpart), int(self.accumulate), nv.ptr(self.lat_ticket)
         d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
         d.sigma, d.hyper, d.partials = nv.ptr(self.m.p['sigma']), nv.ptr(self.hyper), nv.ptr(self.lat_partials)
         d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
@@ -615,8 +643,13 @@ class TrainEngine:
         d.losses, d.rng_stream = nv.ptr(self.losses), 100
         return d
 
-    def _latent_desc(self, corr, Fblk, noise):
-        if self.M != 2:
+    def _fused_latent(self, corr, Fblk):
+        if self.M == 2 and os.environ.get('JAMIE_NO_FUSED_LATENT') == '1':      # A/B switch (tools/ab.sh): the general kernels
+            return False
+        return corr is None and Fblk is None and not self.cosine and self.L % 4 == 0 and self.L <= 128
+
+    def _latent_desc(self, corr, Fblk, noise, fused=False):
+        if self.M != 2 or fused:
             return self._latent_desc_m(corr, Fblk, noise)
         B, L = self.B, self.L
         d = nv.Latent()
@@ -671,9 +704,27 @@ class TrainEngine:
         return [x if x.shape[1] == d else torch.nn.functional.pad(x, (0, d - x.shape[1])).contiguous()
                 for x, d in zip(data, self.dims)]
 
+    def set_grad_bf16(self, on):
+        """Switch the bf16 weight-gradient buffer (default on in bf16 compute mode on one GPU) off / on; off for runs that
+        accumulate gradients over batches (batch_step=False)."""
+        self.grad_bf16 = bool(on) and self.fused_norm and hasattr(self, 'grad16')
+
     def grad_view(self, name):
-        """The gradient of parameter tensor `name` without the padding."""
+        """The gradient of parameter tensor `name` (fp32, without padding) as the last backward pass left it: the large
+        weight matrices live in the bf16 buffer when that pass wrote them there."""
+        if self._g16_last and name.endswith('.W') and name[:-2] in self.dw_partial:
+            return self.m.layout.unpad(name, self.g16[name].float())
         return self.m.layout.unpad(name, self.g[name])
+
+    def grad_flat(self):
+        """The whole flat gradient of the last backward pass as one fp32 tensor (tests / diagnostics)."""
+        out = self.grad.clone()
+        if self._g16_last:
+            for key in self.dw_partial:
+                o, shp = self.m.layout.entries[key + '.W']
+                n = shp[0] * shp[1]
+                out[o:o + n] = self.grad16[o:o + n].float()
+        return out
 
     def set_batch(self, X):
         """Use the given [B, d_i] fp32 matrices as the batch (tests; the training loop uses `load_batch`)."""
@@ -731,10 +782,12 @@ class TrainEngine:
         self._bn_fwd('bn1', 'h2', 'a2', 11, noise, 'enc_masks', 1)
         self._cast('a2')
         self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)      # bias added in the latent kernel
-        lat = self._latent_desc(corr, Fblk, noise)
+        fused = fused_losses and self._fused_latent(corr, Fblk)
+        lat = self._latent_desc(corr, Fblk, noise, fused)
         nv.latent_fwd(lat, self.state)
-        self._cast('comb')
-        self._fwd_gemm('comb', 'dec0', 'g1', 'dec0')
+        if not fused:            # (the fused kernel has written g1 = comb W^T + b and the bf16 copies of comb itself)
+            self._cast('comb')
+            self._fwd_gemm('comb', 'dec0', 'g1', 'dec0')
         self._bn_fwd('bn2', 'g1', 'e1', 12, noise, 'dec_masks', 0)
         self._cast('e1')
         self._fwd_gemm('e1', 'dec1', 'g2', 'dec1')
@@ -782,6 +835,11 @@ class TrainEngine:
             self.refresh_weights_bf16(transposes_only=True)
             self._wT_stale = False
         self._fuse_now = self.fused_norm and allreduce is None      # a reduced gradient needs its norm taken afterwards
+        self._g16_now = self.grad_bf16 and self._fuse_now and not self.accumulate
+        if self.accumulate and self._g16_pending:
+            raise nv.JamieHipError('gradients accumulate onto a backward pass that wrote bf16 weight gradients: call '
+                                   'set_grad_bf16(False) before the first backward pass of an accumulating run')
+        self._g16_last = self._g16_pending = self._g16_now
         nv.colsum_group([(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
         self._region(allreduce, 'dec2')
@@ -796,8 +854,9 @@ class TrainEngine:
         nv.latent_bwd(lat)                                                      # dml, dsigma, losses
         if acc:                                                                 # batch_step=False: d(sigma) accumulates
             self.g['sigma'].add_(self._dsig_tmp)
-        self._cast('dml')
-        nv.colsum_group([(self.ws[i]['dml'], self.g[f'm{i}.head.b']) for i in range(len(self.dims))], acc)
+        if not (isinstance(lat, nv.LatentM) and lat.colpart):                   # (fused kernels: bf16 dml + head-bias gradients done)
+            self._cast('dml')
+            nv.colsum_group([(self.ws[i]['dml'], self.g[f'm{i}.head.b']) for i in range(len(self.dims))], acc)
         self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
         self._region(allreduce, 'head')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
@@ -822,11 +881,14 @@ class TrainEngine:
         elif self._norm_ready:         # the dW launches of this backward pass wrote their tiles' sums of squares
             n_live = self.n_dw_partials + self.sq_ranges.blocks
             norm = self.norm_partials[:n_live]
-            nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state)
+            nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state,
+                                  self.grad16 if self._g16_now else None)
+            if self._g16_now:
+                grad = self.grad16
         else:                        # (also: reduced gradient, external backward) one pass over the whole buffer
             norm = self.norm_partials[:self.n_norm]
             nv.grad_sqnorm(self.grad, norm, self.state)
-        self._norm_ready = False
+        self._norm_ready = self._g16_pending = False
         if after_norm is not None:       # e.g. the next batch's sampler + gather on a side stream, under clip + Adam
             after_norm()
         if not self.pipeline:
@@ -946,8 +1008,9 @@ class TrainEngine:
         self._timing_step += 1
 
     def adam_bytes_per_param(self):
-        """Algorithmic HBM bytes per parameter of one clip + Adam launch: read p, g, m, v; write p, m, v (fp32)."""
-        return 28.0
+        """Algorithmic HBM bytes per parameter of one clip + Adam launch: read p, g, m, v; write p, m, v (fp32; the
+        gradient is 2 bytes when the dW launches wrote it as bf16)."""
+        return 26.0 if self.grad_bf16 else 28.0
 
     def read_losses(self):
         """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""

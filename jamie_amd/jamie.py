@@ -357,6 +357,8 @@ class JAMIE:
                           dist_method=self.dist_method, seed=int(self.manual_seed) + 7919 * rank,
                           world_size=world, compute_dtype=self.compute_dtype)
         eng.accumulate = False
+        if not self.batch_step:
+            eng.set_grad_bf16(False)        # gradients accumulate over the batches of an epoch (jamie.py:734-749): fp32 buffer
         self.engine = eng
         data = eng.pad_cells(data)
         rep = min(self.col) < B and self.dataset_num == 2                    # jamie.py:553 (sic); M > 2: never

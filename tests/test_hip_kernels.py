@@ -399,6 +399,106 @@ def test_latent_fwd_bwd(nv, B, L, general, useF, cosine, nslab):
     _latent_case(nv, B, L, general, useF, cosine, nslab, B * 3 + L)
 
 
+@pytest.mark.parametrize('M,B,L,dims,nslab,bf,acc', [
+    (2, 512, 32, (2000, 1000), 3, True, False), (2, 50, 8, (72, 45), 1, False, False), (3, 130, 64, (300, 200, 136), 2, True, True),
+    (4, 64, 16, (40, 33, 24, 16), 1, False, False), (2, 96, 128, (70, 52), 2, False, False)])
+def test_latent_m_fused_kernels(nv, M, B, L, dims, nslab, bf, acc):
+    """The fused latent kernels of the identity-correspondence step (jamie_latent_m_fwd / _bwd; reference model.py:225-259
+    with corr = I, model.py:190 decoder layer 0, jamie.py:618-668 losses) against a float64 autograd restatement:
+    forward = mu / logvar / z / comb from the heads' split-K slabs, the decoder's first pre-activation g1 = comb W^T + b for
+    every modality (ragged column chunks, ragged last row block) and the losses; backward = d(mu | logvar), d sigma and
+    the head-bias gradients (column sums; accumulated when asked), with the bf16 copies the bf16 GEMMs read."""
+    f32 = dict(device='cuda', dtype=torch.float32)
+    g = torch.Generator().manual_seed(M * 1000 + B + L)
+    ml = [torch.randn(nslab, B, 2 * L, generator=g) * .5 for _ in range(M)]
+    hb = [torch.randn(2 * L, generator=g) * .1 for _ in range(M)]
+    eps = [torch.randn(B, L, generator=g) for _ in range(M)]
+    sigma = torch.rand(M, generator=g) + .2
+    W = [torch.randn(d, L, generator=g) / L ** .5 for d in dims]
+    bd = [torch.randn(d, generator=g) * .1 for d in dims]
+    ndc = 2
+    dcomb = [torch.randn(ndc, B, L, generator=g) * 1e-3 for _ in range(M)]
+    hyper = torch.zeros(16)
+    hyper[0:4] = torch.tensor([0.016, 1.5, 32.0, 0.7])
+    recp = torch.rand(5, generator=g)
+    prev_db = [torch.randn(2 * L, generator=g) for _ in range(M)]
+    # ---- float64 reference ----
+    mlp = [(m.double().sum(0) + h.double()).requires_grad_(True) for m, h in zip(ml, hb)]
+    sg = sigma.double().requires_grad_(True)
+    mus, lvs, zs = [], [], []
+    for i in range(M):
+        mu, lv = mlp[i][:, :L], mlp[i][:, L:]
+        mus.append(mu); lvs.append(lv)
+        zs.append(mu + eps[i].double() * (torch.exp(lv / 2) + 1e-7))
+    comb = sum(sg[i] * zs[i] for i in range(M)) / sg.sum()
+    lvl = lvs[M - 1]
+    kl = sum(-.5 * ((1 + lvl[i] - lvl[i].exp()).mean() - (mus[i] ** 2).mean()) for i in range(M))
+    l_kl = hyper[0].double() * kl
+    l_al = hyper[2].double() * sum(((zs[i] - comb) ** 2).mean() for i in range(M))
+    l_f = hyper[3].double() * (comb ** 2).mean()
+    l_rec = hyper[1].double() * recp.double().sum()
+    total = l_kl + l_al + l_f + sum((dcomb[i].double().sum(0) * comb).sum() for i in range(M))
+    grads = torch.autograd.grad(total, mlp + [sg])
+    g1_ref = [comb.detach() @ W[i].double().t() + bd[i].double() for i in range(M)]
+    # ---- device ----
+    d = nv.LatentM()
+    d.B, d.L, d.M = B, L, M
+    keep = {'sigma': dev(sigma), 'hyper': dev(hyper), 'rec': dev(recp), 'losses': torch.zeros(8, **f32),
+            'partials': torch.zeros(20 * nv.load().jamie_max_partials(), **f32), 'dsigma': torch.zeros(M, **f32),
+            'comb': torch.zeros(B, L, **f32),
+            'colpart': torch.zeros(int(nv.load().jamie_latent_m_colpart_size(B, L)), **f32)}
+    keep['losses'][5] = float('inf')
+    for i in range(M):
+        keep[f'ml{i}'], keep[f'hb{i}'], keep[f'eps_in{i}'] = dev(ml[i]), dev(hb[i]), dev(eps[i])
+        keep[f'W{i}'], keep[f'b{i}'], keep[f'dcomb{i}'] = dev(W[i]), dev(bd[i]), dev(dcomb[i])
+        keep[f'g1{i}'] = torch.full((B, dims[i]), float('nan'), **f32)
+        keep[f'dml{i}'] = torch.zeros(B, 2 * L, **f32)
+        keep[f'db{i}'] = dev(prev_db[i]) if acc else torch.zeros(2 * L, **f32)
+        keep[f'alias{i}'] = torch.zeros(B, L, **f32)
+        for k in ('mu', 'lv', 'z', 'eps'):
+            keep[f'{k}{i}'] = torch.zeros(B, L, **f32)
+            getattr(d, k)[i] = nv.ptr(keep[f'{k}{i}'])
+        d.ml[i], d.head_bias[i], d.eps_in[i] = nv.ptr(keep[f'ml{i}']), nv.ptr(keep[f'hb{i}']), nv.ptr(keep[f'eps_in{i}'])
+        d.g1[i], d.dec0_W[i], d.dec0_b[i], d.d[i] = nv.ptr(keep[f'g1{i}']), nv.ptr(keep[f'W{i}']), nv.ptr(keep[f'b{i}']), dims[i]
+        d.dcomb[i], d.dml[i], d.dbias_head[i] = nv.ptr(keep[f'dcomb{i}']), nv.ptr(keep[f'dml{i}']), nv.ptr(keep[f'db{i}'])
+        d.comb_alias[i] = nv.ptr(keep[f'alias{i}'])
+        if bf:
+            keep[f'cb{i}'] = torch.zeros(B, L, device='cuda', dtype=torch.bfloat16)
+            keep[f'cT{i}'] = torch.zeros(L, B, device='cuda', dtype=torch.bfloat16)
+            keep[f'db16{i}'] = torch.zeros(B, 2 * L, device='cuda', dtype=torch.bfloat16)
+            keep[f'dT16{i}'] = torch.zeros(2 * L, B, device='cuda', dtype=torch.bfloat16)
+            d.comb_bf16[i], d.combT_bf16[i] = nv.ptr(keep[f'cb{i}']), nv.ptr(keep[f'cT{i}'])
+            d.dml_bf16[i], d.dmlT_bf16[i] = nv.ptr(keep[f'db16{i}']), nv.ptr(keep[f'dT16{i}'])
+    d.ml_nslab, d.ml_slab_stride = nslab, B * 2 * L
+    d.sigma, d.hyper, d.partials, d.comb = nv.ptr(keep['sigma']), nv.ptr(keep['hyper']), nv.ptr(keep['partials']), nv.ptr(keep['comb'])
+    d.dcomb_nslab, d.dcomb_slab_stride = ndc, B * L
+    d.dsigma, d.rec_partials, d.n_rec_partials, d.losses = nv.ptr(keep['dsigma']), nv.ptr(keep['rec']), 5, nv.ptr(keep['losses'])
+    keep['ticket'] = torch.zeros(4, dtype=torch.int32, device='cuda')
+    d.colpart, d.accumulate, d.rng_stream, d.ticket = nv.ptr(keep['colpart']), int(acc), 100, nv.ptr(keep['ticket'])
+    nv.latent_fwd(d, None)
+    nv.latent_bwd(d)
+    for i in range(M):
+        close(keep[f'mu{i}'], mus[i], 1e-5, 1e-6, f'mu{i}')
+        close(keep[f'lv{i}'], lvs[i], 1e-5, 1e-6, f'lv{i}')
+        close(keep[f'z{i}'], zs[i], 1e-5, 2e-6, f'z{i}')
+        close(keep[f'alias{i}'], comb, 1e-5, 2e-6, f'comb alias {i}')
+        close(keep[f'g1{i}'], g1_ref[i], 1e-5, 5e-6, f'g1 {i}')
+        scale = float(grads[i].abs().max())
+        close(keep[f'dml{i}'], grads[i], 2e-4, 2e-6 * scale, f'dml{i}')
+        want_db = grads[i].sum(0) + (prev_db[i].double() if acc else 0)
+        close(keep[f'db{i}'], want_db, 2e-4, 1e-5 * float(want_db.abs().max()), f'head bias grad {i}')
+        if bf:
+            assert torch.equal(keep[f'cb{i}'], keep['comb'].to(torch.bfloat16)) and torch.equal(keep[f'cT{i}'], keep['comb'].t().to(torch.bfloat16))
+            assert torch.equal(keep[f'db16{i}'], keep[f'dml{i}'].to(torch.bfloat16))
+            assert torch.equal(keep[f'dT16{i}'], keep[f'dml{i}'].t().to(torch.bfloat16))
+    close(keep['comb'], comb, 1e-5, 2e-6, 'comb')
+    close(keep['dsigma'], grads[M], 2e-4, 1e-6 * float(grads[M].abs().max()) + 1e-9, 'dsigma')
+    assert int(keep['ticket'][0].item()) == 0            # reset by the last workgroup
+    ls = keep['losses'].cpu().double()
+    close(ls[:4], torch.stack([l_kl, l_rec, l_al, l_f]).detach(), 2e-5, 1e-7, 'losses')
+    assert abs(float(ls[4]) - float((l_kl + l_rec + l_al + l_f).detach())) < 2e-5 * abs(float(ls[4])) and ls[5] == ls[4]
+
+
 def test_latent_rng_eps_is_standard_normal(nv):
     """Without explicit eps the kernel draws N(0,1): check moments and that z = mu + eps*std holds."""
     B, L = 1024, 32
