@@ -179,11 +179,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('JAMIE_LIB') or LIB_PATH          # JAMIE_LIB: an A/B build of the same sources (tools/ab.sh)
+    if not os.path.exists(path):
         raise JamieHipError(
-            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'{path} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950).  jamie_amd has no CPU fallback.')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res

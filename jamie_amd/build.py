@@ -26,6 +26,26 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else -1.0
 
 
+def build_variant(tag, flags, verbose=False):
+    """An A/B build of the same sources with extra hipcc flags (e.g. -DJAMIE_OLD_REDUCE): `libjamie_hip_<tag>.so` next to
+    the product library, selected at run time with JAMIE_LIB=<path> (tools/ab.sh)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    odir = os.path.join(CSRC, '_obj_' + tag)
+    os.makedirs(odir, exist_ok=True)
+    srcs = sources()
+    objs = [os.path.join(odir, os.path.basename(s)[:-4] + '.o') for s in srcs]
+
+    def cc(so):
+        subprocess.run([hipcc] + FLAGS + list(flags) + ['-c', so[0], '-o', so[1]], check=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(cc, zip(srcs, objs)))
+    out = os.path.join(_HERE, f'libjamie_hip_{tag}.so')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, check=True)
+    if verbose:
+        print('built', out)
+    return out
+
+
 def build_library(force=False, verbose=False, jobs=None):
     srcs = sources()
     headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(_HERE, '..', 'include', '*.h'))

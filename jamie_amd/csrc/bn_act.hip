@@ -709,8 +709,10 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
         }
         dyv[j] = make_float4(dh[0], dh[1], dh[2], dh[3]);
     }
-    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, cq, rp, cok);
+    // the bias-gradient column sums come BEFORE the bf16 stores: col_reduce4's barriers are `__syncthreads()`, which drain
+    // vmcnt(0) -- behind the stores they made every wave wait for its stores to be acknowledged
     const float4 dbias = col_reduce4(s3, sh, tid);
+    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, cq, rp, cok);
     if (cok && rp == 0) {
         const float dg[4] = {dgamma.x, dgamma.y, dgamma.z, dgamma.w}, db[4] = {dbeta.x, dbeta.y, dbeta.z, dbeta.w};
         const float dl[4] = {dbias.x, dbias.y, dbias.z, dbias.w};

@@ -95,12 +95,6 @@ __device__ __forceinline__ void jamie_box_muller(uint32_t a, uint32_t b, float& 
 // ------------------------------------------------------------------------------------------------
 // reductions (wave = 64)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // wave-wide sum on the VALU's DPP lane permutations (no LDS traffic; `__shfl_xor` is a ds_bpermute per stage: with 16 waves
 // reducing 13-18 values each, the shuffles alone took 7 us of a 20 us launch -- tools/stamp_latent.sh).  Quad butterfly
 // (quad_perm), then row_half_mirror and row_mirror leave every lane of a 16-lane row with the row's sum; the four row sums
@@ -118,13 +112,32 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-// block-wide sum; `red` is >= (blockDim.x/64) floats of LDS; result valid in every thread
+// workgroup barrier that publishes LDS only: `__syncthreads()` also drains vmcnt(0), i.e. waits for global stores (and
+// loads) that the barrier does not need
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+#ifdef JAMIE_OLD_REDUCE      // A/B build (tools/ab.sh): the round-1 reductions (ds_bpermute butterflies, fencing barriers)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#define JAMIE_RED_BARRIER() __syncthreads()
+#else
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+#define JAMIE_RED_BARRIER() lds_barrier()
+#endif
+
+// block-wide sum; `red` is >= (blockDim.x/64) floats of LDS; result valid in every thread.  Its barriers order LDS only.
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    __syncthreads();
+    JAMIE_RED_BARRIER();
     if ((threadIdx.x & 63) == 0) red[w] = v;
-    __syncthreads();
+    JAMIE_RED_BARRIER();
     float t = 0.f;
     for (int i = 0; i < nw; ++i) t += red[i];
     return t;

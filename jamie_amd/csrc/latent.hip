@@ -468,13 +468,6 @@ struct LatMDev {
     int chunk_begin[LM + 1];      // column chunks of the decoder product, per modality (prefix sums)
 };
 
-// workgroup barrier that publishes LDS only: `__syncthreads()` also drains vmcnt(0), i.e. waits ~2 us for global stores that
-// nobody in the workgroup reads
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
 // N block-wide sums at once: wave sums on DPP (common.h), ONE pair of barriers for all N, and the cross-wave sums by N
 // threads (thread k adds slot k over the waves, in wave order); the totals are left in red[0 .. N-1] for whoever needs them
 // after the call's final barrier.  `red` holds (blockDim.x / 64) * N + N floats.

@@ -25,13 +25,15 @@ H_LR, H_B1, H_B2, H_EPS, H_MAXNORM, H_GSCALE = 8, 9, 10, 11, 12, 13
 
 def choose_splitk(M, N, K, bm=64, bn=64):
     """Split K so that a problem offers >= ~2 workgroups of 64x64 per CU (512 in all); each slice keeps at
-    least 512 of K (256 for the skinny heads / latent products).  Slabs are summed by the consuming kernel.
+    least 512 of K (160 for the skinny heads / latent products).  Slabs are summed by the consuming kernel.
     Measured (tools/bench_gemm.py): [512x2000x4000] 65 -> 89 TFLOP/s with 2 slices."""
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
     if tiles >= 384:
         return 1
     s = max(1, math.ceil(512 / tiles))
-    return int(max(1, min(s, K // (512 if N > 64 else 256))))
+    # (skinny heads / latent products: slices of >= 160; at config 2 six slabs instead of three took 3-5 us off the step,
+    #  profiles/r02_ab_skinny_slabs.log: the launch is a latency chain of k-steps, not bandwidth)
+    return int(max(1, min(s, K // (512 if N > 64 else 160))))
 
 
 # ---- bf16 GEMM launch plans (tile configuration + per-problem split-K), from tools/bench_gemm_bf16.py ----
@@ -157,6 +159,8 @@ class TrainEngine:
         # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
         sk_head = min(choose_splitk(B, 2 * L, d) for d in self.dims)
         sk_dcomb = min(choose_splitk(B, L, d) for d in self.dims)
+        if os.environ.get('JAMIE_SK_SKINNY'):          # tuning knob (tools/ab.sh): slab count of the skinny head / latent products
+            sk_head = sk_dcomb = int(os.environ['JAMIE_SK_SKINNY'])
         # bf16: tile configuration of every large launch + per-modality slab counts (plan_bf16_*)
         self.gcfg, plan_sk = {}, {}
         if self.bf16:
