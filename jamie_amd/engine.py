@@ -61,6 +61,12 @@ def plan_bf16_rows(B, shapes):
     """shapes = [(N_i, K_i)] of one forward / dX launch -> (cfg, [splitk_i]); cfg -1 = the library default."""
     if not _big_enough(B, shapes):
         return -1, [choose_splitk(B, N, K) for (N, K) in shapes]
+    if os.environ.get('JAMIE_BF16_ROWS'):         # tuning knob (tools/ab.sh): "cfg:s0,s1[;cfg:s0,s1 for the N < K launches]"
+        parts = os.environ['JAMIE_BF16_ROWS'].split(';')
+        part = parts[0] if (all(N >= K for (N, K) in shapes) or len(parts) == 1) else parts[1]
+        cfg, sks = part.split(':')
+        sks = [int(v) for v in sks.split(',')]
+        return int(cfg), [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
     cfg = BF16_CFG_ROWS_WIDE if (B >= 256 and all(N >= K for (N, K) in shapes)) else BF16_CFG_ROWS
     bm, bn = BF16_TILE[cfg]
     tk = sum(math.ceil(B / bm) * math.ceil(N / bn) * K for (N, K) in shapes)
