@@ -270,6 +270,13 @@ int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, c
  * buffer (same offsets as the flat fp32 gradient) and read from there -- no fp32 copy-back pass, 2 instead of 4 bytes of
  * gradient per parameter in both kernels. */
 int jamie_grad_sqnorm_bf16(const void* g_bf16, long long n, float* partials, int n_partials, uint64_t* state, void* stream);
+/* jamie_clip_adam (g fp32) / jamie_clip_adam_g16 (g_is_bf16) with ONE extra workgroup that draws the NEXT step's batch:
+ * idx[B] = jamie_sample_indices(B, N, offset, replace, state, rng_stream) with the step number the norm kernel has just
+ * advanced -- the same indices a stand-alone sampler launch at the start of the next step would draw (np.random.choice of
+ * jamie/jamie.py:556), without that launch on the step's critical path. */
+int jamie_clip_adam_sample(float* p, const void* g, int g_is_bf16, float* m, float* v, long long n, const float* partials,
+                           int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, int32_t* idx, int B,
+                           long long N, long long offset, int replace, int rng_stream, void* stream);
 int jamie_clip_adam_g16(float* p, const void* g_bf16, float* m, float* v, long long n, const float* partials,
                         int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream);
 

@@ -136,6 +136,9 @@ EXPORTS = {
     'jamie_grad_sqnorm_bf16': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_clip_adam_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'jamie_clip_adam_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong,
+                                         C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
     'jamie_grad_sqnorm_ranges': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p]),
     'jamie_grad_sqnorm_ranges_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -421,8 +424,15 @@ def grad_sqnorm(g, partials, state):
     _call(name, ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream())
 
 
-def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None):
-    """`g`: the fp32 gradient, or (a bf16 tensor) the reduced gradient left in its bf16 message buffer."""
+def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None, sample=None):
+    """`g`: the fp32 gradient, or (a bf16 tensor) the reduced gradient left in its bf16 message buffer.
+    `sample` = (idx, N, offset, replace, rng_stream): the launch's extra workgroup draws the next step's batch into idx."""
+    if sample is not None:
+        idx, N, offset, replace, rng_stream = sample
+        _call('jamie_clip_adam_sample', ptr(p), ptr(g), int(g.dtype == torch.bfloat16), ptr(m), ptr(v), p.numel(), ptr(partials),
+              partials.numel(), ptr(hyper), ptr(state), ptr(p_bf16), ptr(idx), idx.numel(), int(N), int(offset), int(replace),
+              int(rng_stream), _stream())
+        return
     name = 'jamie_clip_adam_g16' if g.dtype == torch.bfloat16 else 'jamie_clip_adam'
     _call(name, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),
           ptr(hyper), ptr(state), ptr(p_bf16), _stream())

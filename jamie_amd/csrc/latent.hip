@@ -514,8 +514,11 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
     for (int i = 1; i < LM; ++i)
         if (i < M && chunk >= a.chunk_begin[i]) mi = i;
     const int c0 = (chunk - a.chunk_begin[mi]) * COLS;
+    // chunk 0 is the OWNER of the 32 cells: it stores the latents, their bf16 copies and the loss partial sums and computes no
+    // decoder columns (those workgroups would otherwise be the last to finish: stores + 13 block sums + the product);
+    // chunks 1.. are the decoder products
     const bool owner = chunk == 0;
-    const bool dec = a.g1[mi] != nullptr;
+    const bool dec = !owner && a.g1[mi] != nullptr;
     if (blockIdx.x == 0) LSTAMP(a, 0);
     // the W chunk's loads go out first: their latency hides under phase A
     const int L4 = L >> 2;
@@ -886,11 +889,11 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
         d.dml_bf16[i] = (unsigned short*)a->dml_bf16[i]; d.dmlT_bf16[i] = (unsigned short*)a->dmlT_bf16[i];
         d.comb_bf16[i] = (unsigned short*)a->comb_bf16[i]; d.combT_bf16[i] = (unsigned short*)a->combT_bf16[i];
         d.dbias_head[i] = a->dbias_head[i];
-        d.chunk_begin[i] = chunks;
-        chunks += a->g1[i] ? (a->d[i] + cols - 1) / cols : (i == 0 ? 1 : 0);
+        d.chunk_begin[i] = chunks == 0 ? 1 : chunks;          // chunk 0: the owner workgroups (no decoder columns)
+        if (chunks == 0) chunks = 1;
+        chunks += a->g1[i] ? (a->d[i] + cols - 1) / cols : 0;
     }
     for (int i = a->M; i <= LM; ++i) d.chunk_begin[i] = chunks;
-    if (chunks == 0) d.chunk_begin[LM] = chunks = 1;
     d.colpart = a->colpart; d.accumulate = a->accumulate; d.ticket = a->ticket;
     d.ml_nslab = a->ml_nslab; d.ml_slab_stride = a->ml_slab_stride;
     d.sigma = a->sigma; d.hyper = a->hyper; d.comb = a->comb; d.partials = a->partials;

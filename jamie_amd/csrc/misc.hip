@@ -1,5 +1,6 @@
 // Batch assembly and small utility kernels, gfx950 (reference jamie.py:552-604).
 #include "common.h"
+#include "sampler.h"
 
 thread_local char g_jamie_err[512] = {0};
 
@@ -38,95 +39,11 @@ extern "C" int jamie_gather_rows(const float* src, long long n_rows, int d, cons
     return jamie_launch_status("jamie_gather_rows");
 }
 
-// ---- device-side np.random.choice(N, B, replace): one workgroup, deterministic given (seed, step) ----
-// Without replacement, two exact methods (both symmetric under relabelling of values, so the result is a
-// uniform B-subset in uniformly random order):
-//   N <= 4096 : every candidate gets a random 32-bit key; a bitonic sort in LDS orders the candidates and
-//               the first B are taken (ties broken by index).
-//   N  > 4096 : rounds of "every unresolved slot draws; a value belongs to the claim with the lowest
-//               (round, slot) priority, so claims of earlier rounds are never displaced; losers redraw".
-//               B <= 2048 < N/2, so a draw succeeds with probability > 1/2 and 64 rounds leave a failure
-//               probability below 2^-64 per slot.  Every wave leaves the loop after at most 64 rounds.
-#define SMP_HASH 4096
+// ---- device-side np.random.choice(N, B, replace): sampler.h (one workgroup, deterministic given (seed, step)) ----
 __global__ __launch_bounds__(1024) void sample_kernel(int32_t* idx, int B, long long N, long long offset, int replace,
                                                       const uint64_t* rng, int rng_stream) {
-    __shared__ long long key[SMP_HASH];
-    __shared__ int owner[SMP_HASH];
-    __shared__ int pending;
-    const int tid = threadIdx.x;
-    if (replace) {
-        for (int slot = tid; slot < B; slot += 1024) {
-            Philox4 r = jamie_rand4(rng, (uint32_t)rng_stream, (uint64_t)slot << 8);
-            const uint64_t u = ((uint64_t)r.v[0] << 32) | r.v[1];
-            idx[slot] = (int32_t)((long long)(u % (uint64_t)N) + offset);
-        }
-        return;
-    }
-    if (N <= SMP_HASH) {
-        // sort-based exact subset: key = (random32 << 32) | candidate, padding = +inf
-        for (int i = tid; i < SMP_HASH; i += 1024) {
-            if (i < N) {
-                Philox4 r = jamie_rand4(rng, (uint32_t)rng_stream, (uint64_t)i << 8);
-                key[i] = (long long)(((uint64_t)(r.v[0] >> 1) << 32) | (uint32_t)i);
-            } else {
-                key[i] = 0x7fffffffffffffffLL;
-            }
-        }
-        __syncthreads();
-        for (int k = 2; k <= SMP_HASH; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < SMP_HASH; i += 1024) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const long long a = key[i], b = key[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { key[i] = b; key[ixj] = a; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        for (int slot = tid; slot < B; slot += 1024) idx[slot] = (int32_t)((key[slot] & 0xffffffffLL) + offset);
-        return;
-    }
-    for (int i = tid; i < SMP_HASH; i += 1024) { key[i] = -1; owner[i] = 0x7fffffff; }
-    __syncthreads();
-    for (int base = 0; base < B; base += 1024) {   // chunks of 1024 slots share the table
-        const int slot = base + tid;
-        bool need = slot < B;
-        long long val = 0;
-        for (unsigned round = 0; round < 64; ++round) {
-            if (tid == 0) pending = 0;
-            __syncthreads();
-            int pos = -1;
-            const int prio = (int)((((unsigned)(base >> 10) * 64u + round) << 11) | (unsigned)slot);
-            if (need) {
-                Philox4 r = jamie_rand4(rng, (uint32_t)rng_stream, ((uint64_t)slot << 8) | round);
-                const uint64_t u = ((uint64_t)r.v[0] << 32) | r.v[1];
-                val = (long long)(u % (uint64_t)N);
-                // open addressing keyed by value
-                unsigned hsh = (unsigned)((uint64_t)val * 0x9E3779B97F4A7C15ull >> 52) & (SMP_HASH - 1);
-                for (int probe = 0; probe < SMP_HASH; ++probe) {
-                    const long long prev = (long long)atomicCAS((unsigned long long*)&key[hsh],
-                                                                (unsigned long long)-1LL, (unsigned long long)val);
-                    if (prev == -1 || prev == val) { pos = (int)hsh; break; }
-                    hsh = (hsh + 1) & (SMP_HASH - 1);
-                }
-                if (pos >= 0) atomicMin(&owner[pos], prio);
-            }
-            __syncthreads();
-            if (need) {
-                if (pos >= 0 && owner[pos] == prio) need = false;
-                else atomicAdd(&pending, 1);
-            }
-            __syncthreads();
-            const int pend = pending;
-            __syncthreads();
-            if (pend == 0) break;
-        }
-        if (slot < B) idx[slot] = (int32_t)(val + offset);
-        __syncthreads();
-    }
+    __shared__ SampleLds lds;
+    jamie_sample_block(lds, idx, B, N, offset, replace, rng, rng_stream);
 }
 
 extern "C" int jamie_sample_indices(int32_t* idx, int B, long long N, long long offset, int replace,

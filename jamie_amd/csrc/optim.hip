@@ -8,6 +8,7 @@
 //                       updates p, m, v                           (reads 16n, writes 12n bytes)
 // 16 B per lane loads/stores, grid-stride over <= 2048 blocks (cdna_hip_programming.md Guideline 11).
 #include "common.h"
+#include "sampler.h"
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n,
                                                           float* partials, uint64_t* state) {
@@ -57,13 +58,25 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
     }
 }
 
-template <int U, int T>
+struct SampleArgs { int32_t* idx; int B; long long N; long long offset; int replace; int rng_stream; };
+
+template <int U, int T, bool SMP>
 __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* partials, int n_partials,
                                                         const float* hyper, const uint64_t* state,
                                                         unsigned short* __restrict__ p_bf16,
-                                                        const unsigned short* __restrict__ g_bf16) {
+                                                        const unsigned short* __restrict__ g_bf16, SampleArgs smp) {
+    // one EXTRA workgroup (the last one) draws the next step's batch indices when `smp.idx` is set: the sampler is a
+    // one-workgroup job whose own launch cost 5 us of every step; here it runs beside 256 streaming workgroups for free.
+    // state[1] already holds the next step's number (the norm kernel advanced it).
+    if constexpr (SMP) {
+        __shared__ SampleLds smp_lds;
+        if (blockIdx.x == gridDim.x - 1) {
+            jamie_sample_block(smp_lds, smp.idx, smp.B, smp.N, smp.offset, smp.replace, state, smp.rng_stream);
+            return;
+        }
+    }
     __shared__ float red[T / 64];
     float s = 0.f;
     for (int i = threadIdx.x; i < n_partials; i += T) s += partials[i];
@@ -89,7 +102,8 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    for (long long i0 = (long long)blockIdx.x * (T * U) + threadIdx.x; i0 < n4; i0 += (long long)gridDim.x * (T * U)) {
+    const long long nwg = SMP ? gridDim.x - 1 : gridDim.x;          // streaming workgroups
+    for (long long i0 = (long long)blockIdx.x * (T * U) + threadIdx.x; i0 < n4; i0 += nwg * (T * U)) {
         // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
         float4 pp[U], mm[U], vv[U], gg[U];
 #pragma unroll
@@ -229,7 +243,8 @@ extern "C" int jamie_grad_sqnorm(const float* g, long long n, float* partials, i
 }
 
 static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m, float* v, long long n, const float* partials,
-                          int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
+                          int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, const SampleArgs* smp,
+                          void* stream) {
     JAMIE_ARG(p && (g || g_bf16) && m && v && partials && hyper && state && n > 0, "null pointer / empty");
     JAMIE_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                   ((uintptr_t)v % 16) == 0 && ((uintptr_t)g_bf16 % 8) == 0, "buffers must be 16-byte aligned (bf16 gradient: 8)");
@@ -240,21 +255,42 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
     // one workgroup per CU (fewer, longer streams keep more DRAM pages open: 2048 workgroups x 1 float4 4.8 TB/s), eight
     // waves each with one float4 per array in flight: 5.8 TB/s where four waves x two float4 reached 5.0-5.2 on the slower
     // boxes of the pool and 5.7 on the faster ones (tools/bench_adam.py; in the step 231 -> 209 us on a slow box)
-    hipLaunchKernelGGL((clip_adam_kernel<1, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n, partials,
-                       n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16);
+    if (smp && smp->idx) {
+        JAMIE_ARG(smp->B > 0 && smp->N > 0 && (smp->replace || (smp->B <= smp->N && smp->B <= SMP_HASH / 2)),
+                  "sampler: B <= N and B <= 2048 without replacement");
+        JAMIE_ARG(smp->N + smp->offset <= 0x7fffffffLL, "sampler: indices must fit int32");
+        hipLaunchKernelGGL((clip_adam_kernel<1, 512, true>), dim3(grid + 1), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
+                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, *smp);
+    } else {
+        SampleArgs none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL((clip_adam_kernel<1, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
+                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, none);
+    }
     return jamie_launch_status("jamie_clip_adam");
 }
 
 extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                                int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
     JAMIE_ARG(g != nullptr, "null gradient");
-    return clip_adam_impl(p, g, nullptr, m, v, n, partials, n_partials, hyper, state, p_bf16, stream);
+    return clip_adam_impl(p, g, nullptr, m, v, n, partials, n_partials, hyper, state, p_bf16, nullptr, stream);
 }
 
 extern "C" int jamie_clip_adam_g16(float* p, const void* g_bf16, float* m, float* v, long long n, const float* partials,
                                    int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
     JAMIE_ARG(g_bf16 != nullptr, "null gradient");
-    return clip_adam_impl(p, nullptr, g_bf16, m, v, n, partials, n_partials, hyper, state, p_bf16, stream);
+    return clip_adam_impl(p, nullptr, g_bf16, m, v, n, partials, n_partials, hyper, state, p_bf16, nullptr, stream);
+}
+
+extern "C" int jamie_clip_adam_sample(float* p, const void* g, int g_is_bf16, float* m, float* v, long long n,
+                                      const float* partials, int n_partials, const float* hyper, const uint64_t* state,
+                                      void* p_bf16, int32_t* idx, int B, long long N, long long offset, int replace,
+                                      int rng_stream, void* stream) {
+    JAMIE_ARG(g != nullptr && idx != nullptr, "null gradient / index buffer");
+    SampleArgs smp;
+    smp.idx = idx; smp.B = B; smp.N = N; smp.offset = offset; smp.replace = replace; smp.rng_stream = rng_stream;
+    return clip_adam_impl(p, g_is_bf16 ? nullptr : (const float*)g, g_is_bf16 ? g : nullptr, m, v, n, partials, n_partials, hyper,
+                          state, p_bf16, &smp, stream);
 }
 
 extern "C" int jamie_grad_sqnorm_bf16(const void* g_bf16, long long n, float* partials, int n_partials, uint64_t* state,

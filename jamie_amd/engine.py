@@ -880,7 +880,7 @@ class TrainEngine:
         self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
 
-    def optimizer_step(self, g16=None, after_norm=None):
+    def optimizer_step(self, g16=None, after_norm=None, sample=None):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step).
         `g16`: the reduced gradient as a flat bf16 tensor with the layout of `self.grad` (data-parallel exchange with
         bf16 messages); default: `self.grad`."""
@@ -902,9 +902,10 @@ class TrainEngine:
         if after_norm is not None:       # e.g. the next batch's sampler + gather on a side stream, under clip + Adam
             after_norm()
         if not self.pipeline:
+            # `sample`: the launch's extra workgroup draws the NEXT step's batch indices (make_plan)
             self._launch('adam', lambda: nv.clip_adam(self.m.flat, grad, self.exp_avg, self.exp_avg_sq,
                                                        norm, self.hyper, self.state,
-                                                       self.wbf_flat if self.bf16 else None))
+                                                       self.wbf_flat if self.bf16 else None, sample))
             if self.bf16 and self.side_transposes:
                 # the K-contiguous W^T copies are only read by the NEXT backward pass: they are made on a side stream
                 # under the next forward pass (36 us of HBM-bound copying off the critical path)
@@ -943,7 +944,7 @@ class TrainEngine:
             nv.set_stream(None)
         self._opt_pending = True
 
-    def step(self, corr=None, Fblk=None, noise=None, allreduce=None, after_norm=None):
+    def step(self, corr=None, Fblk=None, noise=None, allreduce=None, after_norm=None, sample=None):
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
         `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
         self.forward_backward(corr, Fblk, noise, allreduce)
@@ -960,7 +961,7 @@ class TrainEngine:
             fn()
             if in_place:
                 g16 = allreduce.comm
-        self.optimizer_step(g16, after_norm)
+        self.optimizer_step(g16, after_norm, sample)
 
     # ---- recorded launch plan: one foreign call per launch, no descriptor rebuilding (host cost ~3 us/launch) ----
     def make_plan(self, data, idx, n_rows, replace=False, allreduce=None, prefetch=False):
@@ -970,17 +971,23 @@ class TrainEngine:
         kernel (which advances the step counter the sampler draws from), i.e. under clip + Adam, instead of in front of
         the next forward pass: the same index stream and the same bits.  Measured: -1 % (clip + Adam loses more to the
         interference than the 16 us are worth, like every other overlap tried on this step), so it is off by default."""
-        def next_batch():
-            nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
+        def next_batch(sample=True):
+            if sample:
+                nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
             self.load_batch(data, [idx] * self.M, with_wT=not prefetch)
             if replace:
                 nv.corr_from_indices(idx, idx, self.corr)
         corr = self.corr if replace else None
         if not prefetch:
+            # the sampler of the NEXT batch rides in this step's clip + Adam launch (one extra workgroup: the same index
+            # stream, no launch of its own); the first batch is drawn here, before the recording
+            fused = not self.pipeline and (replace or idx.numel() <= 2048) and os.environ.get('JAMIE_NO_FUSED_SAMPLER') != '1'
+            if fused:
+                nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
             nv.begin_record()
             try:
-                next_batch()
-                self.step(corr, None, None, allreduce)
+                next_batch(sample=not fused)
+                self.step(corr, None, None, allreduce, sample=(idx, n_rows, 0, replace, 200) if fused else None)
             finally:
                 plan = nv.end_record()
             return plan
