@@ -232,8 +232,11 @@ typedef struct {
     void* comb_bf16[4] /* [B, L] */; void* combT_bf16[4] /* [L, B] */;
     void* dml_bf16[4] /* [B, 2L] */; void* dmlT_bf16[4] /* [2L, B] */;
     float* dbias_head[4]; float* colpart; int accumulate;
-    unsigned* ticket;   /* REQUIRED for the backward launch: one zero-initialised device uint32 (count of finished workgroups;
-                         * the last one finalises the losses, d sigma and the head-bias gradients and resets it) */
+    unsigned* ticket;   /* REQUIRED for the backward launch unless defer_final: one zero-initialised device uint32 (count of
+                         * finished workgroups; the last one finalises the losses, d sigma and the head-bias gradients and
+                         * resets it) */
+    int defer_final;    /* 1: jamie_latent_m_bwd leaves the partial sums as they are; the step's range-norm launch finalises
+                         * them in an extra workgroup (jamie_grad_sqnorm_ranges_fin), off the backward pass's critical path */
 } jamie_latent_m;
 /* forward: ONE launch from the heads' split-K slabs to mu / logvar / z / comb, the loss partial sums and (fused tail) the
  * decoder's first pre-activation; backward: ONE launch (gradients + partial sums; its last workgroup finalises the losses, d sigma
@@ -262,6 +265,12 @@ int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets /*host*/, 
  * (jamie_gemm_problem.c_bf16) the whole gradient then exists in ONE bf16 buffer for jamie_clip_adam_g16. */
 int jamie_grad_sqnorm_ranges_g16(const float* g, void* g_bf16, const long long* offsets /*host*/, const long long* lengths /*host*/,
                                  int count, float* partials, int n_partials, uint64_t* state, void* stream);
+/* jamie_grad_sqnorm_ranges (g_bf16 NULL) / _g16 plus ONE extra workgroup that finalises a deferred latent backward pass
+ * (`fin->defer_final`): losses, d sigma, head-bias gradients (written into g, and g_bf16), and their sum of squares into
+ * partials[n_partials - 1].  The ranges must NOT cover sigma and the head biases; n_partials = range blocks + 1. */
+int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* offsets /*host*/, const long long* lengths /*host*/,
+                                 int count, float* partials, int n_partials, uint64_t* state,
+                                 const jamie_latent_m* fin /*host*/, void* stream);
 int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,

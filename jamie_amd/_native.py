@@ -101,7 +101,8 @@ class LatentM(C.Structure):
                 ('g1', C.c_void_p * 4), ('dec0_W', C.c_void_p * 4), ('dec0_b', C.c_void_p * 4), ('d', C.c_int * 4),
                 ('comb_alias', C.c_void_p * 4), ('comb_bf16', C.c_void_p * 4), ('combT_bf16', C.c_void_p * 4),
                 ('dml_bf16', C.c_void_p * 4), ('dmlT_bf16', C.c_void_p * 4),
-                ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p)]
+                ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p),
+                ('defer_final', C.c_int)]
 
 
 class PdState(C.Structure):
@@ -143,6 +144,8 @@ EXPORTS = {
                                            C.c_void_p]),
     'jamie_grad_sqnorm_ranges_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p]),
+    'jamie_grad_sqnorm_ranges_fin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
     'jamie_sqnorm_range_blocks': (C.c_int, [C.c_void_p, C.c_int]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -522,8 +525,13 @@ class SqRanges:
         self.blocks = load().jamie_sqnorm_range_blocks(self.len, self.count)
 
 
-def grad_sqnorm_ranges(g, ranges, partials, state, g16=None):
-    """`g16` (flat bf16, same layout as g): also receives the bf16 copy of every range."""
+def grad_sqnorm_ranges(g, ranges, partials, state, g16=None, fin=None):
+    """`g16` (flat bf16, same layout as g): also receives the bf16 copy of every range.  `fin` (a LatentM with defer_final):
+    one extra workgroup finalises the latent backward pass; `partials` has one more slot for what it writes."""
+    if fin is not None:
+        _call('jamie_grad_sqnorm_ranges_fin', ptr(g), ptr(g16), ranges.off, ranges.len, ranges.count, ptr(partials),
+              partials.numel(), ptr(state), C.pointer(fin), _stream())
+        return
     if g16 is not None:
         _call('jamie_grad_sqnorm_ranges_g16', ptr(g), ptr(g16), ranges.off, ranges.len, ranges.count, ptr(partials),
               partials.numel(), ptr(state), _stream())

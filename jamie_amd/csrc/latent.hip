@@ -9,6 +9,7 @@
 // partial sums and added up in a fixed order by block 0 of the last kernel (deterministic, no atomics).
 // The B x B products (C z, C^T z, F comb, ...) are ~8 MFLOP each: plain VALU loops, not MFMA.
 #include "common.h"
+#include "latent_final.h"
 
 #define LAT_SLOTS 16
 enum { S_MU2_0 = 0, S_MU2_1, S_TROW0, S_TROW1, S_AL0, S_AL1, S_F, S_DSIG0, S_DSIG1 };
@@ -433,7 +434,6 @@ extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
 // For M = 2 it coincides with the two-modality kernels above at corr = I (tested).  No oracle in the reference:
 // parity for M = 3 is pinned only against the generalised CPU oracle's autograd.
 // =================================================================================================
-#define LM 4
 // diagnostic build only (-DJAMIE_LAT_STAMP, tools/bench_latent_m.py): thread 0 of workgroup 0 (forward) / of the last workgroup
 // (backward) writes s_memrealtime (100 MHz) deltas into partials[19 * JAMIE_MAX_PARTIALS + k]; nothing reads them
 #ifdef JAMIE_LAT_STAMP
@@ -441,11 +441,9 @@ extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
 #else
 #define LSTAMP(a, k) do {} while (0)
 #endif
-#define LF_ROWS 32          // cells per workgroup of the fused kernels below
 #define LF_NT 1024          // threads per workgroup: 16 waves, so that every SIMD has four waves to hide latencies behind
                             // (four waves of four elements each ran this launch in 36 us: one wave per SIMD pays every
                             // dependent VALU / LDS / memory latency in full)
-enum { SM_MU2 = 0, SM_TROW = 4, SM_AL = 8, SM_F = 12, SM_DSIG = 13, SM_SLOTS = 17 };
 
 struct LatMDev {
     int B, L, M;
@@ -465,30 +463,11 @@ struct LatMDev {
     unsigned short* dml_bf16[LM]; unsigned short* dmlT_bf16[LM];
     float* dbias_head[LM]; float* colpart; int accumulate;
     unsigned* ticket;             // zero-initialised counter of finished backward workgroups (reset by the last one)
+    int defer_final;              // the caller finalises later (jamie_grad_sqnorm_ranges_fin): no ticket, no finalisation here
+    LatFinal fin;
     int chunk_begin[LM + 1];      // column chunks of the decoder product, per modality (prefix sums)
 };
 
-// N block-wide sums at once: wave sums on DPP (common.h), ONE pair of barriers for all N, and the cross-wave sums by N
-// threads (thread k adds slot k over the waves, in wave order); the totals are left in red[0 .. N-1] for whoever needs them
-// after the call's final barrier.  `red` holds (blockDim.x / 64) * N + N floats.
-template <int N>
-__device__ __forceinline__ void block_sum_n(float (&v)[N], float* red) {
-    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(v[k]);
-    lds_barrier();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) red[N + w * N + k] = v[k];
-    }
-    lds_barrier();
-    if (threadIdx.x < N) {
-        float t = 0.f;
-        for (int i = 0; i < nw; ++i) t += red[N + i * N + threadIdx.x];
-        red[threadIdx.x] = t;
-    }
-    lds_barrier();
-}
 // ---- forward: ONE launch from the heads' split-K slabs to the decoder's first pre-activation ----
 // Workgroup (rb, chunk): the 32 cells rb*32 .. of the batch and one chunk of COLS output columns of one modality's decoder
 // layer 0.  Phase A (every workgroup, redundantly per chunk: 32 x L elements per modality, a few KB from L2): mu | logvar =
@@ -675,74 +654,11 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
     }
 }
 
-template <int LMAX>
-__device__ __forceinline__ void latent_m_finalise(const LatMDev& a, float* red) {
-    const int B = a.B, L = a.L, M = a.M, n = B * L, NT = blockDim.x, tid = threadIdx.x;
-    const int nblk = (B + LF_ROWS - 1) / LF_ROWS;
-    const float invBL = 1.f / (float)n;
-    // inputs written by other CUs (cold in this CU's caches): every load is issued before the first use, so this costs
-    // about one memory round trip instead of one per dependent step
-    const float kl_scale = a.hyper[0], w_rec = a.hyper[1], w_al = a.hyper[2], w_f = a.hyper[3];
-    const float best = a.losses[5];
-    float v[SM_SLOTS + 1];
-#pragma unroll
-    for (int sl = 0; sl < SM_SLOTS; ++sl)           // 17 independent loads
-        v[sl] = tid < nblk ? a.partials[sl * JAMIE_MAX_PARTIALS + tid] : 0.f;
-    v[SM_SLOTS] = tid < a.n_rec_partials ? a.rec_partials[tid] : 0.f;
-    // head-bias gradients = column sums of d(mu | logvar): the workgroups' partial sums, added in workgroup order; the
-    // first 16 partial sums of this thread's column are loaded together
-    const bool col_ok = a.colpart && tid < M * 2 * L && a.dbias_head[(tid / (2 * L)) & 3] != nullptr;
-    const int ci = col_ok ? tid / (2 * L) : 0, cc = col_ok ? tid % (2 * L) : 0;
-    float t[16], prev = 0.f;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = (col_ok && u < nblk) ? a.colpart[((long long)u * LM + ci) * 2 * LMAX + cc] : 0.f;
-    if (col_ok && a.accumulate) prev = a.dbias_head[ci][cc];
-    // (rare shapes: more partial sums than the first batch)
-    for (int i = tid + NT; i < nblk; i += NT)
-#pragma unroll
-        for (int sl = 0; sl < SM_SLOTS; ++sl) v[sl] += a.partials[sl * JAMIE_MAX_PARTIALS + i];
-    for (int i = tid + NT; i < a.n_rec_partials; i += NT) v[SM_SLOTS] += a.rec_partials[i];
-    LSTAMP(a, 11);
-    if (col_ok) {
-        float acc = prev;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc += t[u];
-        for (int rb = 16; rb < nblk; ++rb) acc += a.colpart[((long long)rb * LM + ci) * 2 * LMAX + cc];
-        a.dbias_head[ci][cc] = acc;
-    }
-    if (a.colpart) {            // more columns than threads: the remaining ones, the plain way
-        for (int idx = tid + NT; idx < M * 2 * L; idx += NT) {
-            const int i = idx / (2 * L), cidx = idx % (2 * L);
-            if (!a.dbias_head[i]) continue;
-            float acc = a.accumulate ? a.dbias_head[i][cidx] : 0.f;
-            for (int rb = 0; rb < nblk; ++rb) acc += a.colpart[((long long)rb * LM + i) * 2 * LMAX + cidx];
-            a.dbias_head[i][cidx] = acc;
-        }
-    }
-    LSTAMP(a, 12);
-    block_sum_n<SM_SLOTS + 1>(v, red);
-    LSTAMP(a, 13);
-    if (tid == 0) {
-        const float rec = red[SM_SLOTS];
-        float kl = 0.f, al = 0.f;
-        for (int i = 0; i < M; ++i) {
-            kl += -0.5f * (red[SM_TROW + i] / (float)L - red[SM_MU2 + i] * invBL);
-            al += red[SM_AL + i];
-            a.dsigma[i] = red[SM_DSIG + i];
-        }
-        const float l_kl = kl_scale * kl, l_rec = w_rec * rec, l_al = w_al * al * invBL, l_f = w_f * red[SM_F] * invBL;
-        const float total = l_kl + l_rec + l_al + l_f;
-        a.losses[0] = l_kl; a.losses[1] = l_rec; a.losses[2] = l_al; a.losses[3] = l_f;
-        a.losses[4] = total;
-        a.losses[5] = fminf(best, total);
-    }
-}
-
 // ---- backward: d(mu | logvar) (+ bf16 copies), per-workgroup partial sums of d(sigma) and of the head-bias gradients ----
 template <int LMAX>
 __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a) {
     constexpr int EPT = LF_ROWS * LMAX / LF_NT;
-    __shared__ float red[(LF_NT / 64 + 1) * (SM_SLOTS + 1)];
+    __shared__ float red[(LF_NT / 64 + 1) * (SM_SLOTS + 2)];
     __shared__ float T[LF_ROWS][2 * LMAX + 1];            // one modality's d(mu | logvar) of this workgroup's cells
     const int B = a.B, L = a.L, M = a.M, n = B * L, tid = threadIdx.x;
     const int rb = blockIdx.x, r0 = rb * LF_ROWS;
@@ -847,6 +763,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a) {
     // ---- the workgroup that finishes LAST finalises (losses, d sigma, head-bias gradients): a ticket counter instead of a
     // second launch.  Hand-off as MI355X_MICROARCH.md prescribes: every storing wave drains its stores, workgroup barrier,
     // one lane releases at agent scope and takes the ticket; the last one acquires at agent scope before anyone reads.
+    if (a.defer_final) return;          // (uniform) the range-norm launch of this step finalises (jamie_grad_sqnorm_ranges_fin)
     __shared__ int is_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -862,7 +779,16 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a) {
         }
     }
     __syncthreads();
-    if (is_last) { LSTAMP(a, 10); latent_m_finalise<LMAX>(a, red); LSTAMP(a, 14); }
+    if (is_last) { LSTAMP(a, 10); latent_m_finalise(a.fin, red); LSTAMP(a, 14); }
+}
+
+void jamie_latent_m_fill_final(const jamie_latent_m* a, LatFinal* f) {
+    memset(f, 0, sizeof(*f));
+    f->B = a->B; f->L = a->L; f->M = a->M; f->lmax = a->L <= 32 ? 32 : (a->L <= 64 ? 64 : 128);
+    f->accumulate = a->accumulate; f->n_rec_partials = a->n_rec_partials;
+    f->partials = a->partials; f->rec_partials = a->rec_partials; f->hyper = a->hyper; f->colpart = a->colpart;
+    f->losses = a->losses; f->dsigma = a->dsigma;
+    for (int i = 0; i < a->M && i < LM; ++i) f->dbias_head[i] = a->dbias_head[i];
 }
 
 static int latm_cols(int L) { return L <= 32 ? 256 : (L <= 64 ? 128 : 64); }
@@ -900,6 +826,8 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
     d.dcomb_nslab = a->dcomb_nslab; d.dcomb_slab_stride = a->dcomb_slab_stride;
     d.dsigma = a->dsigma; d.rec_partials = a->rec_partials; d.n_rec_partials = a->n_rec_partials;
     d.losses = a->losses; d.rng_stream = a->rng_stream;
+    d.defer_final = a->defer_final;
+    jamie_latent_m_fill_final(a, &d.fin);
     return 0;
 }
 
@@ -930,7 +858,7 @@ extern "C" int jamie_latent_m_bwd(const jamie_latent_m* a, void* stream) {
     if (rc) return rc;
     for (int i = 0; i < a->M; ++i) JAMIE_ARG(a->dcomb[i] && a->dml[i], "dcomb / dml");
     JAMIE_ARG(a->dsigma && a->losses && a->dcomb_nslab >= 1, "null output");
-    JAMIE_ARG(a->ticket != nullptr, "ticket: a zero-initialised device uint32 is required");
+    JAMIE_ARG(a->ticket != nullptr || a->defer_final, "ticket: a zero-initialised device uint32 is required");
     JAMIE_ARG(a->dcomb_nslab == 1 || a->dcomb_slab_stride >= (long long)a->B * a->L, "dcomb_slab_stride too small");
     JAMIE_ARG(a->n_rec_partials == 0 || a->rec_partials, "rec_partials");
     const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS;

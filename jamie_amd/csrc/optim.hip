@@ -9,6 +9,7 @@
 // 16 B per lane loads/stores, grid-stride over <= 2048 blocks (cdna_hip_programming.md Guideline 11).
 #include "common.h"
 #include "sampler.h"
+#include "latent_final.h"
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n,
                                                           float* partials, uint64_t* state) {
@@ -160,8 +161,19 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
 // elements per workgroup; also advances the step counter, as jamie_grad_sqnorm does.
 #define JAMIE_SQ_CHUNK 4096
 struct SqRanges { long long off[128]; int len[128]; };
+template <bool FIN>
 __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, unsigned short* __restrict__ g16,
-                                                                 SqRanges r, float* partials, uint64_t* state) {
+                                                                 SqRanges r, float* partials, uint64_t* state, LatFinal fin,
+                                                                 int n_range_blocks) {
+    if constexpr (FIN) {
+        // the extra workgroup: the deferred finalisation of the latent backward pass (losses, d sigma, head-bias gradients)
+        // and the sum of squares of what it wrote -- those ranges are not in `r`
+        __shared__ float fred[(256 / 64 + 1) * (SM_SLOTS + 2)];
+        if ((int)blockIdx.x == n_range_blocks) {
+            latent_m_finalise(fin, fred, &partials[n_range_blocks], g, g16);
+            return;
+        }
+    }
     __shared__ float red[4];
     const float* p = g + r.off[blockIdx.x];
     unsigned short* q = g16 ? g16 + r.off[blockIdx.x] : nullptr;          // bf16 copy of the range (same offsets)
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __
 }
 
 static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offsets, const long long* lengths, int count,
-                              float* partials, int n_partials, uint64_t* state, void* stream) {
+                              float* partials, int n_partials, uint64_t* state, void* stream, const jamie_latent_m* lat = nullptr) {
     JAMIE_ARG(g && offsets && lengths && partials && count >= 1, "null pointer / empty");
     SqRanges r;
     int nb = 0;
@@ -201,10 +213,21 @@ static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offset
             ++nb;
         }
     }
-    JAMIE_ARG(nb >= 1 && n_partials == nb, "n_partials must equal jamie_sqnorm_range_blocks()");
+    JAMIE_ARG(nb >= 1 && n_partials == nb + (lat ? 1 : 0), "n_partials must equal jamie_sqnorm_range_blocks() (+ 1 with a finaliser)");
     JAMIE_ARG(!g16 || ((uintptr_t)g16 % 8) == 0, "g_bf16 must be 8-byte aligned");
-    hipLaunchKernelGGL(grad_sqnorm_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (unsigned short*)g16, r, partials,
-                       state);
+    LatFinal fin;
+    memset(&fin, 0, sizeof(fin));
+    if (lat) {
+        JAMIE_ARG(lat->defer_final && lat->partials && lat->hyper && lat->losses && lat->dsigma && !lat->accumulate,
+                  "finaliser: a deferred, non-accumulating jamie_latent_m");
+        JAMIE_ARG(lat->M * 2 * lat->L <= 256 * 64, "finaliser: too many head-bias columns");
+        jamie_latent_m_fill_final(lat, &fin);
+        hipLaunchKernelGGL((grad_sqnorm_ranges_kernel<true>), dim3(nb + 1), dim3(256), 0, (hipStream_t)stream, g, (unsigned short*)g16,
+                           r, partials, state, fin, nb);
+    } else {
+        hipLaunchKernelGGL((grad_sqnorm_ranges_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (unsigned short*)g16,
+                           r, partials, state, fin, nb);
+    }
     return jamie_launch_status("jamie_grad_sqnorm_ranges");
 }
 
@@ -217,6 +240,13 @@ extern "C" int jamie_grad_sqnorm_ranges_g16(const float* g, void* g_bf16, const 
                                             int count, float* partials, int n_partials, uint64_t* state, void* stream) {
     JAMIE_ARG(g_bf16 != nullptr, "null bf16 gradient buffer");
     return sqnorm_ranges_impl(g, g_bf16, offsets, lengths, count, partials, n_partials, state, stream);
+}
+
+extern "C" int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* offsets, const long long* lengths,
+                                            int count, float* partials, int n_partials, uint64_t* state,
+                                            const jamie_latent_m* fin, void* stream) {
+    JAMIE_ARG(fin != nullptr, "null latent descriptor");
+    return sqnorm_ranges_impl(g, g_bf16, offsets, lengths, count, partials, n_partials, state, stream, fin);
 }
 
 extern "C" int jamie_sqnorm_range_blocks(const long long* lengths, int count) {

@@ -266,6 +266,7 @@ class TrainEngine:
         # every dW tile's epilogue writes its sum of squares into `norm_partials`; a small kernel adds the ranges the
         # GEMMs do not produce (biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices)
         self.fused_norm, self._fuse_now, self._norm_ready = False, False, False
+        self._lat_deferred = None
         big = {'dec2': 'd_e2', 'dec1': 'd_e1', 'enc1': 'd_a1', 'enc0': 'dw'}
         if self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values()):
             bm_d, bn_d = BF16_TILE[self.gcfg['dw']]
@@ -286,10 +287,26 @@ class TrainEngine:
             if n > pos:
                 rest.append((pos, n - pos))
             self.sq_ranges = nv.SqRanges(rest)
+            # the same without d sigma and the head-bias gradients: a step with the fused latent kernels defers their
+            # finalisation to the range-norm launch's extra workgroup, which also adds their squares (optimizer_step)
+            cut = [model.layout.entries['sigma']] + [model.layout.entries[f'm{i}.head.b'] for i in range(self.M)]
+            cut = sorted((o, o + int(np.prod(shp))) for o, shp in cut)
+            rest2 = []
+            for lo, ln in rest:
+                hi = lo + ln
+                for c0, c1 in cut:
+                    if c0 >= hi or c1 <= lo:
+                        continue
+                    if c0 > lo:
+                        rest2.append((lo, c0 - lo))
+                    lo = max(lo, c1)
+                if hi > lo:
+                    rest2.append((lo, hi - lo))
+            self.sq_ranges_nofin = nv.SqRanges(rest2)
             if off + self.sq_ranges.blocks <= nv.load().jamie_max_partials() and self.sq_ranges.blocks <= 128:
                 self.fused_norm = True
                 self.n_dw_partials = off
-                self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm), **f32)
+                self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm) + 2, **f32)
         # ---- weight gradients in bf16 (bf16 compute mode, one GPU, fused norm): the large dW launches round their fp32
         # accumulators once on the way out into `grad16` (same flat layout as `grad`), the small ranges (biases, BatchNorm
         # affine parameters, sigma, the skinny matrices) are copied there by the range-norm kernel, and clip + Adam reads
@@ -889,16 +906,23 @@ class TrainEngine:
             norm = self.norm_partials[:self.n_norm]
             nv.grad_sqnorm(grad, norm, self.state)
         elif self._norm_ready:         # the dW launches of this backward pass wrote their tiles' sums of squares
-            n_live = self.n_dw_partials + self.sq_ranges.blocks
-            norm = self.norm_partials[:n_live]
-            nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state,
-                                  self.grad16 if self._g16_now else None)
+            if self._lat_deferred is not None:      # + the extra workgroup that finalises the latent backward pass
+                n_live = self.n_dw_partials + self.sq_ranges_nofin.blocks + 1
+                norm = self.norm_partials[:n_live]
+                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges_nofin, norm[self.n_dw_partials:], self.state,
+                                      self.grad16 if self._g16_now else None, self._lat_deferred)
+            else:
+                n_live = self.n_dw_partials + self.sq_ranges.blocks
+                norm = self.norm_partials[:n_live]
+                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state,
+                                      self.grad16 if self._g16_now else None)
             if self._g16_now:
                 grad = self.grad16
         else:                        # (also: reduced gradient, external backward) one pass over the whole buffer
             norm = self.norm_partials[:self.n_norm]
             nv.grad_sqnorm(self.grad, norm, self.state)
         self._norm_ready = self._g16_pending = False
+        self._lat_deferred = None
         if after_norm is not None:       # e.g. the next batch's sampler + gather on a side stream, under clip + Adam
             after_norm()
         if not self.pipeline:
@@ -947,7 +971,15 @@ class TrainEngine:
     def step(self, corr=None, Fblk=None, noise=None, allreduce=None, after_norm=None, sample=None):
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
         `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
-        self.forward_backward(corr, Fblk, noise, allreduce)
+        # the fused latent backward kernel leaves its finalisation (losses, d sigma, head-bias gradients) to the range-norm
+        # launch that follows in this very step when that launch exists (bf16 mode, one GPU, fused gradient norm)
+        defer = (self.fused_norm and allreduce is None and not self.accumulate and self._fused_latent(corr, Fblk)
+                 and os.environ.get('JAMIE_NO_DEFER_FINAL') != '1')
+        lat = self._forward(corr, Fblk, noise, True)
+        if defer and isinstance(lat, nv.LatentM):
+            lat.defer_final = 1
+            self._lat_deferred = lat
+        self._backward(lat, noise, allreduce)
         g16 = None
         if allreduce is not None:
             # bf16 messages: the reduced gradient stays in the exchange's bf16 buffer; norm and Adam read it there
