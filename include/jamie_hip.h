@@ -128,6 +128,9 @@ typedef struct {
 } jamie_mse_problem;
 int jamie_mse_cast(const jamie_mse_problem* problems /*host*/, int count /* <= JAMIE_MAX_GROUP */, void* stream);
 
+/* one column-sum problem: out[n] (+)= sum_m sum_slabs X[m, n] (jamie_colsum_group; extra workgroups of jamie_bn_act_bwd_cs and
+ * jamie_grad_sqnorm_ranges_fin) */
+typedef struct { const float* X; float* out; int M, N, ld, nslab; long long slab_stride; int accumulate; } jamie_colsum_problem;
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d(train) + LeakyReLU + Dropout, forward and backward, one column strip per workgroup.
  * Replaces native_batch_norm / leaky_relu / bernoulli_ + mul (model.py:152-154,162-164,193-195,198-200)
@@ -161,6 +164,11 @@ typedef struct {
 
 int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* problems /*host*/, int count, float p_drop,
                      float slope, const uint64_t* rng, void* stream);
+/* The same launch with EXTRA workgroups that compute column sums (`colsums`: out[n] = sum_m X[m, n]; e.g. the decoder's
+ * output-bias gradient, the column sums of d x_hat, jamie.py:734): a job of 47 short workgroups that would otherwise be a launch
+ * of its own at the head of the backward pass runs beside this launch's long ones. */
+int jamie_bn_act_bwd_cs(const jamie_bnact_bwd_problem* problems /*host*/, int count, float p_drop, float slope,
+                        const uint64_t* rng, const jamie_colsum_problem* colsums /*host*/, int n_colsums, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Latent block: reparameterisation (model.py:225-243), sigma-weighted combine (model.py:245-259),
@@ -265,12 +273,16 @@ int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets /*host*/, 
  * (jamie_gemm_problem.c_bf16) the whole gradient then exists in ONE bf16 buffer for jamie_clip_adam_g16. */
 int jamie_grad_sqnorm_ranges_g16(const float* g, void* g_bf16, const long long* offsets /*host*/, const long long* lengths /*host*/,
                                  int count, float* partials, int n_partials, uint64_t* state, void* stream);
-/* jamie_grad_sqnorm_ranges (g_bf16 NULL) / _g16 plus ONE extra workgroup that finalises a deferred latent backward pass
- * (`fin->defer_final`): losses, d sigma, head-bias gradients (written into g, and g_bf16), and their sum of squares into
- * partials[n_partials - 1].  The ranges must NOT cover sigma and the head biases; n_partials = range blocks + 1. */
+/* jamie_grad_sqnorm_ranges (g_bf16 NULL) / _g16 plus extra workgroups for work that would otherwise be launches of its own on
+ * the step's critical path: ONE that finalises a deferred latent backward pass (`fin->defer_final`): losses, d sigma, head-bias
+ * gradients (written into g, and g_bf16) and their sum of squares into partials[range blocks]; and, optionally, column sums
+ * (`colsums`, e.g. the decoder's output-bias gradient = column sums of d x_hat, jamie.py:734), each workgroup of 64 columns
+ * writing its sums into g (and g_bf16) and their squares into the next partial.  The ranges must NOT cover what the extra
+ * workgroups write; n_partials = range blocks + 1 + sum(ceil(N_i / 64)). */
 int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* offsets /*host*/, const long long* lengths /*host*/,
                                  int count, float* partials, int n_partials, uint64_t* state,
-                                 const jamie_latent_m* fin /*host*/, void* stream);
+                                 const jamie_latent_m* fin /*host*/, const jamie_colsum_problem* colsums /*host or NULL*/,
+                                 int n_colsums, void* stream);
 int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,
@@ -325,7 +337,6 @@ int jamie_axpby(float* out, float a, const float* x, float b, const float* y, lo
 /* out[n] (+)= sum_m X[m,n]  (bias gradients of the non-BN Linear layers) */
 int jamie_colsum(const float* X, int M, int N, int ld, int nslab, long long slab_stride, float* out,
                  int accumulate, void* stream);
-typedef struct { const float* X; float* out; int M, N, ld, nslab; long long slab_stride; int accumulate; } jamie_colsum_problem;
 /* the same for up to JAMIE_MAX_GROUP matrices in one launch (the modalities) */
 int jamie_colsum_group(const jamie_colsum_problem* problems /*host*/, int count, void* stream);
 

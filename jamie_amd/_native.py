@@ -127,6 +127,8 @@ EXPORTS = {
                                    C.c_float, C.c_void_p, C.c_void_p]),
     'jamie_bn_act_bwd': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p,
                                    C.c_void_p]),
+    'jamie_bn_act_bwd_cs': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
     'jamie_latent_fwd': (C.c_int, [C.POINTER(Latent), C.c_void_p, C.c_void_p]),
     'jamie_latent_bwd': (C.c_int, [C.POINTER(Latent), C.c_void_p]),
     'jamie_latent_m_fwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
@@ -145,7 +147,7 @@ EXPORTS = {
     'jamie_grad_sqnorm_ranges_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p]),
     'jamie_grad_sqnorm_ranges_fin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                               C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
+                                               C.c_void_p, C.POINTER(LatentM), C.c_void_p, C.c_int, C.c_void_p]),
     'jamie_sqnorm_range_blocks': (C.c_int, [C.c_void_p, C.c_int]),
     'jamie_clip_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -405,8 +407,12 @@ def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01):
     _call('jamie_bn_act_fwd', arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), _stream())
 
 
-def bn_act_bwd(problems, p_drop, rng, slope=0.01):
+def bn_act_bwd(problems, p_drop, rng, slope=0.01, colsums=None):
+    """`colsums` (from colsum_problems): column sums computed by extra workgroups of the same launch."""
     arr = (BnBwdProblem * len(problems))(*problems)
+    if colsums is not None:
+        _call('jamie_bn_act_bwd_cs', arr, len(problems), p_drop, slope, ptr(rng), colsums[0], colsums[1], _stream())
+        return
     _call('jamie_bn_act_bwd', arr, len(problems), p_drop, slope, ptr(rng), _stream())
 
 
@@ -525,12 +531,26 @@ class SqRanges:
         self.blocks = load().jamie_sqnorm_range_blocks(self.len, self.count)
 
 
-def grad_sqnorm_ranges(g, ranges, partials, state, g16=None, fin=None):
+def colsum_problems(items, accumulate=False):
+    """[(X [M, N] contiguous fp32, out [N])] -> (ctypes array, count, partial slots: ceil(N / 64) each)."""
+    probs = []
+    for X, out in items:
+        p = ColsumProblem()
+        p.X, p.out, p.M, p.N, p.ld, p.nslab, p.slab_stride, p.accumulate = ptr(X), ptr(out), X.shape[0], X.shape[1], X.shape[1], 1, 0, int(accumulate)
+        probs.append(p)
+    arr = (ColsumProblem * len(probs))(*probs)
+    arr._keep = items
+    return arr, len(probs), sum((X.shape[1] + 63) // 64 for X, _ in items)
+
+
+def grad_sqnorm_ranges(g, ranges, partials, state, g16=None, fin=None, colsums=None):
     """`g16` (flat bf16, same layout as g): also receives the bf16 copy of every range.  `fin` (a LatentM with defer_final):
-    one extra workgroup finalises the latent backward pass; `partials` has one more slot for what it writes."""
+    one extra workgroup finalises the latent backward pass; `colsums` (from colsum_problems): further extra workgroups write
+    column sums into g; `partials` has one more slot per extra workgroup."""
     if fin is not None:
+        arr, cnt = (colsums[0], colsums[1]) if colsums is not None else (None, 0)
         _call('jamie_grad_sqnorm_ranges_fin', ptr(g), ptr(g16), ranges.off, ranges.len, ranges.count, ptr(partials),
-              partials.numel(), ptr(state), C.pointer(fin), _stream())
+              partials.numel(), ptr(state), C.pointer(fin), arr, cnt, _stream())
         return
     if g16 is not None:
         _call('jamie_grad_sqnorm_ranges_g16', ptr(g), ptr(g16), ranges.off, ranges.len, ranges.count, ptr(partials),

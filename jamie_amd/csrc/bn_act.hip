@@ -14,6 +14,7 @@
 // stream) with one call per 4 elements, and are regenerated identically in the backward kernel; tests
 // pass explicit masks.
 #include "common.h"
+#include "colsum.h"
 
 // diagnostic ablations of the float4 forward kernel (timing only): 1 = no global loads, 2 = no global stores,
 // 3 = neither (launch + reductions only)
@@ -602,8 +603,18 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     if ((P.out_bf || P.outT_bf) && (!(JAMIE_BN_ABL & 2) || v[0].x == 123.456f)) strip_out_bf16x4(v, P.out_bf, P.outT_bf, tl, B, N, col0, cq, rp, cok);
 }
 
+// `cs` / `cs_begin`: workgroups cs_begin .. are EXTRA ones that compute column sums (jamie_bn_act_bwd_cs: the decoder's
+// output-bias gradient = column sums of d x_hat rides in the first BatchNorm-backward launch of the step instead of being a
+// launch of its own at the head of the backward pass; 47 short workgroups beside 375 long ones)
 template <int R>
-__global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng) {
+__global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng,
+                                                          ColsumGroup cs, int cs_begin) {
+    if ((int)blockIdx.x >= cs_begin) {
+        __shared__ float4 csh[32][17];
+        float* o;
+        colsum_block(cs, (int)blockIdx.x - cs_begin, csh, &o);
+        return;
+    }
     __shared__ float sh[BN4_NW][BN_CW];
     __shared__ float sh2[BN4_NW][2 * BN_CW];
     __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * (128 * R + 2)];
@@ -779,8 +790,22 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     return jamie_launch_status("jamie_bn_act_fwd");
 }
 
+static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
+                           const jamie_colsum_problem* csp, int cs_count, void* stream);
+
 extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope,
                                 const uint64_t* rng, void* stream) {
+    return bn_act_bwd_impl(pr, count, p_drop, slope, rng, nullptr, 0, stream);
+}
+
+extern "C" int jamie_bn_act_bwd_cs(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope,
+                                   const uint64_t* rng, const jamie_colsum_problem* colsums, int n_colsums, void* stream) {
+    JAMIE_ARG(colsums && n_colsums >= 1 && n_colsums <= JAMIE_MAX_GROUP, "1 <= column-sum problems <= JAMIE_MAX_GROUP");
+    return bn_act_bwd_impl(pr, count, p_drop, slope, rng, colsums, n_colsums, stream);
+}
+
+static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
+                           const jamie_colsum_problem* csp, int cs_count, void* stream) {
     JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
     JAMIE_ARG(p_drop >= 0.f && p_drop < 1.f, "0 <= p < 1");
     BnBwdGroup g;
@@ -816,13 +841,29 @@ extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, fl
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
+    ColsumGroup cs;
+    memset(&cs, 0, sizeof(cs));
+    int cs_blocks = 0;
+    for (int i = 0; i < cs_count; ++i) {
+        const jamie_colsum_problem& q = csp[i];
+        JAMIE_ARG(q.X && q.out && q.M > 0 && q.N > 0 && q.ld >= q.N && q.nslab >= 1, "column-sum problem");
+        ColsumDev& d = cs.p[i];
+        d.X = q.X; d.out = q.out; d.slab_stride = q.slab_stride; d.M = q.M; d.N = q.N; d.ld = q.ld; d.nslab = q.nslab;
+        d.accumulate = q.accumulate; d.blk_begin = cs_blocks;
+        cs_blocks += (q.N + 63) / 64;
+    }
+    cs.count = cs_count;
+    const bool wide4 = wide && maxB <= 8 * BN4_RP;
+    const int extra = wide4 ? cs_blocks : 0;            // the float4 kernels take the column sums as extra workgroups
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks), dim3(512), 0, st, g, p_drop, slope, rng);
-    else if (wide && maxB <= 8 * BN4_RP)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks), dim3(512), 0, st, g, p_drop, slope, rng);
+        hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks + extra), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks);
+    else if (wide4)
+        hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks + extra), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
     else
         hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
-    return jamie_launch_status("jamie_bn_act_bwd");
+    int rc = jamie_launch_status("jamie_bn_act_bwd");
+    if (rc == 0 && cs_count > 0 && !wide4) rc = jamie_colsum_group(csp, cs_count, stream);     // (dword kernels: a launch of its own)
+    return rc;
 }

@@ -1,6 +1,7 @@
 // Batch assembly and small utility kernels, gfx950 (reference jamie.py:552-604).
 #include "common.h"
 #include "sampler.h"
+#include "colsum.h"
 
 thread_local char g_jamie_err[512] = {0};
 
@@ -161,62 +162,11 @@ extern "C" int jamie_dense_block(const float* M, long long ld, const int32_t* id
     return jamie_launch_status("jamie_dense_block");
 }
 
-// ---- out[n] (+)= sum_m sum_slabs X[m,n]: 16 columns x 16 row phases per workgroup; up to 4 matrices per launch ----
-struct ColsumDev { const float* X; float* out; long long slab_stride; int M, N, ld, nslab, accumulate, blk_begin; };
-struct ColsumGroup { ColsumDev p[JAMIE_MAX_GROUP]; int count; };
-
-// 64 columns per workgroup: 16 lanes x float4 across the columns (256 contiguous bytes per row), 16 row groups; a thread
-// keeps 8 rows in flight.  (The first version read one dword per lane, 16 columns per workgroup: 11.5 us for the
-// [512, 2000 + 1000] bias gradients of a step.)  Rows are added in a fixed order: deterministic.
+// ---- out[n] (+)= sum_m sum_slabs X[m,n]  (colsum.h); up to 4 matrices per launch ----
 __global__ __launch_bounds__(256) void colsum_kernel(ColsumGroup g) {
-    __shared__ float4 sh[16][17];
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
-        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
-    const ColsumDev& P = g.p[pi];
-    const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int col = ((int)blockIdx.x - P.blk_begin) * 64 + c4 * 4;
-    const bool vec = ((P.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.X) & 15) == 0) && ((P.slab_stride & 3) == 0);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < P.N) {
-        for (int s = 0; s < P.nslab; ++s) {
-            const float* X = P.X + s * P.slab_stride + col;
-            if (vec && col + 3 < P.N) {
-                int m = rg;
-                for (; m + 112 < P.M; m += 128) {
-                    float4 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(X + (long long)(m + 16 * u) * P.ld);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-                }
-                for (; m < P.M; m += 16) {
-                    const float4 v = *reinterpret_cast<const float4*>(X + (long long)m * P.ld);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                }
-            } else {
-                for (int m = rg; m < P.M; m += 16) {
-                    const float* r = X + (long long)m * P.ld;
-                    acc.x += r[0];
-                    if (col + 1 < P.N) acc.y += r[1];
-                    if (col + 2 < P.N) acc.z += r[2];
-                    if (col + 3 < P.N) acc.w += r[3];
-                }
-            }
-        }
-    }
-    sh[rg][c4] = acc;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = threadIdx.x, oc = ((int)blockIdx.x - P.blk_begin) * 64 + c;
-        if (oc < P.N) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) t += reinterpret_cast<const float*>(&sh[i][c >> 2])[c & 3];
-            P.out[oc] = P.accumulate ? P.out[oc] + t : t;
-        }
-    }
+    __shared__ float4 sh[32][17];
+    float* o;
+    colsum_block(g, (int)blockIdx.x, sh, &o);
 }
 
 extern "C" int jamie_colsum_group(const jamie_colsum_problem* pr, int count, void* stream) {

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "sampler.h"
 #include "latent_final.h"
+#include "colsum.h"
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n,
                                                           float* partials, uint64_t* state) {
@@ -164,8 +165,20 @@ struct SqRanges { long long off[128]; int len[128]; };
 template <bool FIN>
 __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, unsigned short* __restrict__ g16,
                                                                  SqRanges r, float* partials, uint64_t* state, LatFinal fin,
-                                                                 int n_range_blocks) {
+                                                                 int n_range_blocks, ColsumGroup cs, int cs_begin) {
     if constexpr (FIN) {
+        // further extra workgroups: column sums (the decoder's output-bias gradient = column sums of d x_hat), written into
+        // the gradient (and its bf16 copy) together with their squares -- not in `r` either
+        if ((int)blockIdx.x >= cs_begin) {
+            __shared__ float4 csh[32][17];
+            __shared__ float cred[4];
+            float* o;
+            const float t = colsum_block(cs, (int)blockIdx.x - cs_begin, csh, &o);
+            if (o && g16) g16[o - g] = __builtin_bit_cast(unsigned short, (__bf16)t);
+            const float q = block_sum(t * t, cred);
+            if (threadIdx.x == 0) partials[blockIdx.x] = q;
+            return;
+        }
         // the extra workgroup: the deferred finalisation of the latent backward pass (losses, d sigma, head-bias gradients)
         // and the sum of squares of what it wrote -- those ranges are not in `r`
         __shared__ float fred[(256 / 64 + 1) * (SM_SLOTS + 2)];
@@ -199,7 +212,8 @@ __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __
 }
 
 static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offsets, const long long* lengths, int count,
-                              float* partials, int n_partials, uint64_t* state, void* stream, const jamie_latent_m* lat = nullptr) {
+                              float* partials, int n_partials, uint64_t* state, void* stream, const jamie_latent_m* lat = nullptr,
+                              const jamie_colsum_problem* csp = nullptr, int cs_count = 0) {
     JAMIE_ARG(g && offsets && lengths && partials && count >= 1, "null pointer / empty");
     SqRanges r;
     int nb = 0;
@@ -213,7 +227,24 @@ static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offset
             ++nb;
         }
     }
-    JAMIE_ARG(nb >= 1 && n_partials == nb + (lat ? 1 : 0), "n_partials must equal jamie_sqnorm_range_blocks() (+ 1 with a finaliser)");
+    ColsumGroup cs;
+    memset(&cs, 0, sizeof(cs));
+    int cs_blocks = 0;
+    if (lat && csp) {
+        JAMIE_ARG(cs_count >= 1 && cs_count <= JAMIE_MAX_GROUP, "1 <= column-sum problems <= JAMIE_MAX_GROUP");
+        cs.count = cs_count;
+        for (int i = 0; i < cs_count; ++i) {
+            const jamie_colsum_problem& q = csp[i];
+            JAMIE_ARG(q.X && q.out && q.M > 0 && q.N > 0 && q.ld >= q.N && q.nslab >= 1 && !q.accumulate, "column-sum problem");
+            ColsumDev& d = cs.p[i];
+            d.X = q.X; d.out = q.out; d.slab_stride = q.slab_stride; d.M = q.M; d.N = q.N; d.ld = q.ld; d.nslab = q.nslab;
+            d.accumulate = 0; d.blk_begin = cs_blocks;
+            cs_blocks += (q.N + 63) / 64;
+        }
+    }
+    JAMIE_ARG(nb >= 1 && n_partials == nb + (lat ? 1 : 0) + cs_blocks,
+              "n_partials must equal jamie_sqnorm_range_blocks() (+ 1 with a finaliser, + ceil(N / 64) per column-sum problem)");
+    JAMIE_ARG(n_partials <= JAMIE_MAX_PARTIALS, "too many partial sums");
     JAMIE_ARG(!g16 || ((uintptr_t)g16 % 8) == 0, "g_bf16 must be 8-byte aligned");
     LatFinal fin;
     memset(&fin, 0, sizeof(fin));
@@ -222,11 +253,11 @@ static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offset
                   "finaliser: a deferred, non-accumulating jamie_latent_m");
         JAMIE_ARG(lat->M * 2 * lat->L <= 256 * 64, "finaliser: too many head-bias columns");
         jamie_latent_m_fill_final(lat, &fin);
-        hipLaunchKernelGGL((grad_sqnorm_ranges_kernel<true>), dim3(nb + 1), dim3(256), 0, (hipStream_t)stream, g, (unsigned short*)g16,
-                           r, partials, state, fin, nb);
+        hipLaunchKernelGGL((grad_sqnorm_ranges_kernel<true>), dim3(nb + 1 + cs_blocks), dim3(256), 0, (hipStream_t)stream, g,
+                           (unsigned short*)g16, r, partials, state, fin, nb, cs, nb + 1);
     } else {
         hipLaunchKernelGGL((grad_sqnorm_ranges_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (unsigned short*)g16,
-                           r, partials, state, fin, nb);
+                           r, partials, state, fin, nb, cs, nb);
     }
     return jamie_launch_status("jamie_grad_sqnorm_ranges");
 }
@@ -244,9 +275,10 @@ extern "C" int jamie_grad_sqnorm_ranges_g16(const float* g, void* g_bf16, const 
 
 extern "C" int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* offsets, const long long* lengths,
                                             int count, float* partials, int n_partials, uint64_t* state,
-                                            const jamie_latent_m* fin, void* stream) {
+                                            const jamie_latent_m* fin, const jamie_colsum_problem* colsums, int n_colsums,
+                                            void* stream) {
     JAMIE_ARG(fin != nullptr, "null latent descriptor");
-    return sqnorm_ranges_impl(g, g_bf16, offsets, lengths, count, partials, n_partials, state, stream, fin);
+    return sqnorm_ranges_impl(g, g_bf16, offsets, lengths, count, partials, n_partials, state, stream, fin, colsums, n_colsums);
 }
 
 extern "C" int jamie_sqnorm_range_blocks(const long long* lengths, int count) {

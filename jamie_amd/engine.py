@@ -306,7 +306,7 @@ class TrainEngine:
             if off + self.sq_ranges.blocks <= nv.load().jamie_max_partials() and self.sq_ranges.blocks <= 128:
                 self.fused_norm = True
                 self.n_dw_partials = off
-                self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm) + 2, **f32)
+                self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm) + 2 + sum((d + 63) // 64 for d in self.dims), **f32)
         # ---- weight gradients in bf16 (bf16 compute mode, one GPU, fused norm): the large dW launches round their fp32
         # accumulators once on the way out into `grad16` (same flat layout as `grad`), the small ranges (biases, BatchNorm
         # affine parameters, sigma, the skinny matrices) are copied there by the range-norm kernel, and clip + Adam reads
@@ -503,7 +503,7 @@ class TrainEngine:
             probs.append(pr)
         nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE)
 
-    def _bn_bwd(self, layer, da_key, h_key, lin, stream_base, noise, kind, j):
+    def _bn_bwd(self, layer, da_key, h_key, lin, stream_base, noise, kind, j, colsums=None):
         probs = []
         for i, d in enumerate(self.dims):
             w, P = self.ws[i], self.m.p
@@ -520,7 +520,7 @@ class TrainEngine:
                 pr.dh_bf16, pr.skip_f32 = nv.ptr(w[da_key + '_bf']), 1
                 pr.dhT_bf16 = nv.ptr(w[da_key + '_T']) if da_key in self.need_T else None
             probs.append(pr)
-        nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE)
+        nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE, colsums)
 
     def _fwd_gemm(self, a_key, lin, out_key, sk_key, with_bias=True):
         """out[B, out_f] (slabs) = a[B, in_f] W^T (+ b)."""
@@ -867,10 +867,17 @@ class TrainEngine:
             raise nv.JamieHipError('gradients accumulate onto a backward pass that wrote bf16 weight gradients: call '
                                    'set_grad_bf16(False) before the first backward pass of an accumulating run')
         self._g16_last = self._g16_pending = self._g16_now
-        nv.colsum_group([(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))], acc)
+        # the decoder's output-bias gradient (column sums of d x_hat) rides in the first BatchNorm-backward launch as extra
+        # workgroups (47 short ones beside 375 long ones) instead of being a launch of its own at the head of the backward
+        # pass; with an overlapped gradient exchange the region must be complete before it is announced: own launch
+        ride = allreduce is None and os.environ.get('JAMIE_NO_CS_RIDE') != '1'
+        cs_items = [(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))]
+        if not ride:
+            nv.colsum_group(cs_items, acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
         self._region(allreduce, 'dec2')
-        self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1)   # de2[0] <- dg2p
+        self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1,
+                     colsums=nv.colsum_problems(cs_items, acc) if ride else None)   # de2[0] <- dg2p
         self._cast('de2')
         self._bwd_gemms('de2', 'dec1', 'e1', 'de1', 'd_e1')
         self._region(allreduce, 'dec1')
@@ -973,7 +980,8 @@ class TrainEngine:
         `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
         # the fused latent backward kernel leaves its finalisation (losses, d sigma, head-bias gradients) to the range-norm
         # launch that follows in this very step when that launch exists (bf16 mode, one GPU, fused gradient norm)
-        defer = (self.fused_norm and allreduce is None and not self.accumulate and self._fused_latent(corr, Fblk)
+        defer = (self.fused_norm and self.sq_ranges_nofin.blocks <= 128 and allreduce is None and not self.accumulate
+                 and self._fused_latent(corr, Fblk)
                  and os.environ.get('JAMIE_NO_DEFER_FINAL') != '1')
         lat = self._forward(corr, Fblk, noise, True)
         if defer and isinstance(lat, nv.LatentM):
