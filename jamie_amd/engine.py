@@ -266,7 +266,7 @@ class TrainEngine:
         # every dW tile's epilogue writes its sum of squares into `norm_partials`; a small kernel adds the ranges the
         # GEMMs do not produce (biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices)
         self.fused_norm, self._fuse_now, self._norm_ready = False, False, False
-        self._lat_deferred = None
+        self._lat_deferred, self._ranges_done = None, False
         big = {'dec2': 'd_e2', 'dec1': 'd_e1', 'enc1': 'd_a1', 'enc0': 'dw'}
         if self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values()):
             bm_d, bn_d = BF16_TILE[self.gcfg['dw']]
@@ -899,10 +899,29 @@ class TrainEngine:
         self._region(allreduce, 'enc1')
         self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
         self._cast('da1')
+        # (the range-norm launch on a second stream beside this last dW product: +11 us per step for the two cross-stream
+        #  events, profiles/r02_ab_range_norm_side_stream_rejected.log)
         self._dw_gemm('da1', 'x', 'enc0')
         self._region(allreduce, 'enc0')
         self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
+
+    def _range_norm(self, launch=True):
+        """Sum of squares of the gradient ranges no dW launch covers (+ the deferred latent finalisation in an extra
+        workgroup); returns the live slice of `norm_partials` the optimiser sums."""
+        if self._lat_deferred is not None:
+            n_live = self.n_dw_partials + self.sq_ranges_nofin.blocks + 1
+            norm = self.norm_partials[:n_live]
+            if launch:
+                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges_nofin, norm[self.n_dw_partials:], self.state,
+                                      self.grad16 if self._g16_now else None, self._lat_deferred)
+        else:
+            n_live = self.n_dw_partials + self.sq_ranges.blocks
+            norm = self.norm_partials[:n_live]
+            if launch:
+                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state,
+                                      self.grad16 if self._g16_now else None)
+        return norm
 
     def optimizer_step(self, g16=None, after_norm=None, sample=None):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step).
@@ -913,22 +932,13 @@ class TrainEngine:
             norm = self.norm_partials[:self.n_norm]
             nv.grad_sqnorm(grad, norm, self.state)
         elif self._norm_ready:         # the dW launches of this backward pass wrote their tiles' sums of squares
-            if self._lat_deferred is not None:      # + the extra workgroup that finalises the latent backward pass
-                n_live = self.n_dw_partials + self.sq_ranges_nofin.blocks + 1
-                norm = self.norm_partials[:n_live]
-                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges_nofin, norm[self.n_dw_partials:], self.state,
-                                      self.grad16 if self._g16_now else None, self._lat_deferred)
-            else:
-                n_live = self.n_dw_partials + self.sq_ranges.blocks
-                norm = self.norm_partials[:n_live]
-                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state,
-                                      self.grad16 if self._g16_now else None)
+            norm = self._range_norm(launch=not self._ranges_done)
             if self._g16_now:
                 grad = self.grad16
         else:                        # (also: reduced gradient, external backward) one pass over the whole buffer
             norm = self.norm_partials[:self.n_norm]
             nv.grad_sqnorm(self.grad, norm, self.state)
-        self._norm_ready = self._g16_pending = False
+        self._norm_ready = self._g16_pending = self._ranges_done = False
         self._lat_deferred = None
         if after_norm is not None:       # e.g. the next batch's sampler + gather on a side stream, under clip + Adam
             after_norm()
