@@ -242,7 +242,7 @@ def main():
                          'that the roofline kernel is timed alone)')
     ap.add_argument('--transposed-weight-copies', action='store_true',
                     help='bf16 A/B: dX products on transposed bf16 weight copies (the earlier scheme) instead of reading W as stored')
-    ap.add_argument('--skinny-tr', action='store_true', help='bf16 experiment: head / latent backward launches through the 128x128 k-row-major kernel')
+    ap.add_argument('--no-skinny-tr', action='store_true', help='bf16 A/B: head / latent backward launches through the 64x64 kernel on transposed copies (round 1)')
     ap.add_argument('--prefetch', action='store_true', help='A/B: sample + gather the next batch on a side stream under clip + Adam (measured -1 %)')
     ap.add_argument('--side-transposes', action='store_true',
                     help='bf16: transposed weight copies on a side stream under the next forward pass')
@@ -281,7 +281,7 @@ def main():
     if world > 1:
         jd.broadcast_flat(model.flat)
     eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype,
-                      dx_from_weights=not args.transposed_weight_copies, skinny_tr=args.skinny_tr)
+                      dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr)
     data = eng.pad_cells(data_real)
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
     allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm) if world > 1 else None

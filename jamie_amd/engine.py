@@ -108,7 +108,7 @@ def kl_anneal(epoch, min_epochs, epoch_DNN):
 
 class TrainEngine:
     def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
-                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=False, grad_bf16=False):
+                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=True, grad_bf16=False):
         """compute_dtype 'f32': exact-fp32 MFMA GEMMs (the parity configuration).  'bf16': bf16 MFMA GEMMs with
         fp32 accumulation, fp32 master weights / optimiser / BatchNorm / losses (BASELINE config 2); needs every
         feature count, the latent size and the batch size to be multiples of 8."""
@@ -180,8 +180,9 @@ class TrainEngine:
                                   ('d_a1', [(2 * d, d) for d in self.dims], True)):
                 self.gcfg[key], plan_sk[key] = (plan_bf16_bwd if (bwd and grouped) else plan_bf16_rows)(B, shp)
             self.gcfg['dw'] = BF16_CFG_DW if _big_enough(B, [(d, d) for d in self.dims]) else -1
-            # experiment: the skinny head / latent backward launches through the 128 x 128 k-row-major kernel as well
-            # (no transposed copies at all)
+            # the skinny head / latent backward launches go through the 128 x 128 k-row-major kernel as well: the same speed as
+            # the 64 x 64 kernel on transposed copies (profiles/r02_ab_skinny_tr.log), and with no transposed weight copy left
+            # the next batch's gather can ride in the optimiser launch (make_plan)
             self.skinny_tr = bool(skinny_tr) and self.gcfg['dw'] == BF16_CFG_DW and L % 8 == 0 and 2 * self.M <= nv.MAX_GROUP
             if self.skinny_tr:
                 self.gcfg['d_comb'] = self.gcfg['d_a2'] = BF16_CFG_DW

@@ -433,8 +433,10 @@ def test_bf16_compute_mode_tracks_fp32_oracle(jam, B, dims, L, p):
         assert_mostly_close(got, st['grads'][ref].numpy(), rtol=0, atol=0, max_bad_frac=1.0, rel_l2=1e-1, msg=ref)
     eng.optimizer_step()
     assert torch.equal(eng.wbf['m0.enc0.W'].float(), model.p['m0.enc0.W'].to(torch.bfloat16).float())
-    # the big layers' dX products read W as stored (b_tr): only the skinny head / latent layers keep a transposed copy
-    assert ('m1.dec1' not in eng.wT) == (min(dims) >= 256) and len(eng.wT) > 0
+    # the big layers' dX products read W as stored (b_tr); so do the skinny head / latent layers when every layer is large
+    # enough for the 128 x 128 k-row-major kernel (skinny_tr): then NO transposed weight copy exists
+    assert ('m1.dec1' not in eng.wT) == (min(dims) >= 256)
+    assert (len(eng.wT) == 0) == bool(eng.skinny_tr)
     eng.flush()            # the transposed copies are refreshed with the next batch launch, or on flush()
     for k, wt in eng.wT.items():
         assert torch.equal(wt.float(), model.p[k + '.W'].t().to(torch.bfloat16).float()), k
