@@ -246,11 +246,17 @@ typedef struct {
     int defer_final;    /* 1: jamie_latent_m_bwd leaves the partial sums as they are; the step's range-norm launch finalises
                          * them in an extra workgroup (jamie_grad_sqnorm_ranges_fin), off the backward pass's critical path */
 } jamie_latent_m;
+/* What a riding sampler draws: idx[B] = jamie_sample_indices(B, N, offset, replace, {seed, step + step_add}, rng_stream)
+ * (np.random.choice of jamie/jamie.py:556).  step_add = 1 in a launch that runs before the norm kernel has advanced the step. */
+typedef struct { int32_t* idx; int B; long long N; long long offset; int replace; int rng_stream; int step_add; } jamie_sample_args;
 /* forward: ONE launch from the heads' split-K slabs to mu / logvar / z / comb, the loss partial sums and (fused tail) the
  * decoder's first pre-activation; backward: ONE launch (gradients + partial sums; its last workgroup finalises the losses, d sigma
  * and the head-bias gradients) */
 int jamie_latent_m_fwd(const jamie_latent_m* a /*host*/, const uint64_t* rng, void* stream);
 int jamie_latent_m_bwd(const jamie_latent_m* a /*host*/, void* stream);
+/* jamie_latent_m_bwd with ONE extra workgroup that draws the NEXT step's batch indices (sample->step_add = 1: the norm kernel
+ * has not advanced the step yet): early enough for the batch gather to ride in the optimiser launch (jamie_clip_adam_ride) */
+int jamie_latent_m_bwd_ex(const jamie_latent_m* a /*host*/, const jamie_sample_args* sample /*host*/, const uint64_t* state, void* stream);
 long long jamie_latent_m_colpart_size(int B, int L);
 
 /* ---------------------------------------------------------------------------------------------
@@ -291,13 +297,15 @@ int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, c
  * buffer (same offsets as the flat fp32 gradient) and read from there -- no fp32 copy-back pass, 2 instead of 4 bytes of
  * gradient per parameter in both kernels. */
 int jamie_grad_sqnorm_bf16(const void* g_bf16, long long n, float* partials, int n_partials, uint64_t* state, void* stream);
-/* jamie_clip_adam (g fp32) / jamie_clip_adam_g16 (g_is_bf16) with ONE extra workgroup that draws the NEXT step's batch:
- * idx[B] = jamie_sample_indices(B, N, offset, replace, state, rng_stream) with the step number the norm kernel has just
- * advanced -- the same indices a stand-alone sampler launch at the start of the next step would draw (np.random.choice of
- * jamie/jamie.py:556), without that launch on the step's critical path. */
-int jamie_clip_adam_sample(float* p, const void* g, int g_is_bf16, float* m, float* v, long long n, const float* partials,
-                           int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, int32_t* idx, int B,
-                           long long N, long long offset, int replace, int rng_stream, void* stream);
+/* jamie_clip_adam (g fp32) / jamie_clip_adam_g16 (g_is_bf16) with EXTRA workgroups that do work of the NEXT step, which would
+ * otherwise be launches of its own on the critical path, beside the 256 streaming workgroups of this ~190 us launch: either the
+ * next batch's sampler (`sample`; state[1] already holds the next step's number: step_add = 0) or the next batch's row gather +
+ * bf16 cast (`casts`: jamie_cast_transpose problems; the batch buffers are free once the step's last dW product has run) --
+ * not both: the gather reads the sampler's output. */
+int jamie_clip_adam_ride(float* p, const void* g, int g_is_bf16, float* m, float* v, long long n, const float* partials,
+                         int n_partials, const float* hyper, const uint64_t* state, void* p_bf16,
+                         const jamie_sample_args* sample /*host or NULL*/, const jamie_cast_problem* casts /*host or NULL*/,
+                         int n_casts, void* stream);
 int jamie_clip_adam_g16(float* p, const void* g_bf16, float* m, float* v, long long n, const float* partials,
                         int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream);
 

@@ -105,6 +105,11 @@ class LatentM(C.Structure):
                 ('defer_final', C.c_int)]
 
 
+class SampleArgs(C.Structure):
+    _fields_ = [('idx', C.c_void_p), ('B', C.c_int), ('N', C.c_longlong), ('offset', C.c_longlong), ('replace', C.c_int),
+                ('rng_stream', C.c_int), ('step_add', C.c_int)]
+
+
 class PdState(C.Structure):
     _fields_ = [('F', C.c_void_p), ('G1', C.c_void_p), ('G2', C.c_void_p), ('m1', C.c_void_p), ('m2', C.c_void_p),
                 ('Mu', C.c_void_p), ('Lambda', C.c_void_p), ('S', C.c_void_p), ('rowsum', C.c_void_p),
@@ -133,15 +138,16 @@ EXPORTS = {
     'jamie_latent_bwd': (C.c_int, [C.POINTER(Latent), C.c_void_p]),
     'jamie_latent_m_fwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
     'jamie_latent_m_bwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p]),
+    'jamie_latent_m_bwd_ex': (C.c_int, [C.POINTER(LatentM), C.POINTER(SampleArgs), C.c_void_p, C.c_void_p]),
     'jamie_latent_m_colpart_size': (C.c_longlong, [C.c_int, C.c_int]),
     'jamie_optim_blocks': (C.c_int, [C.c_longlong]),
     'jamie_grad_sqnorm': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_grad_sqnorm_bf16': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_clip_adam_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'jamie_clip_adam_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
-                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong,
-                                         C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_clip_adam_ride': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SampleArgs),
+                                       C.POINTER(CastProblem), C.c_int, C.c_void_p]),
     'jamie_grad_sqnorm_ranges': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p]),
     'jamie_grad_sqnorm_ranges_g16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -420,7 +426,20 @@ def latent_fwd(desc, rng):
     _call('jamie_latent_m_fwd' if isinstance(desc, LatentM) else 'jamie_latent_fwd', C.pointer(desc), ptr(rng), _stream())
 
 
-def latent_bwd(desc):
+def sample_args(idx, N, offset, replace, rng_stream, step_add=0):
+    """What a riding sampler draws (jamie_sample_args): idx.numel() indices of [0, N) + offset into idx."""
+    a = SampleArgs()
+    a.idx, a.B, a.N, a.offset, a.replace, a.rng_stream, a.step_add = ptr(idx), idx.numel(), int(N), int(offset), int(replace), \
+        int(rng_stream), int(step_add)
+    a._keep = idx
+    return a
+
+
+def latent_bwd(desc, sample=None, state=None):
+    """`sample` (sample_args, fused M-modality path only): the launch's extra workgroup draws the NEXT step's batch."""
+    if sample is not None:
+        _call('jamie_latent_m_bwd_ex', C.pointer(desc), C.pointer(sample), ptr(state), _stream())
+        return
     _call('jamie_latent_m_bwd' if isinstance(desc, LatentM) else 'jamie_latent_bwd', C.pointer(desc), _stream())
 
 
@@ -433,14 +452,15 @@ def grad_sqnorm(g, partials, state):
     _call(name, ptr(g), g.numel(), ptr(partials), partials.numel(), ptr(state), _stream())
 
 
-def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None, sample=None):
+def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None, sample=None, casts=None):
     """`g`: the fp32 gradient, or (a bf16 tensor) the reduced gradient left in its bf16 message buffer.
-    `sample` = (idx, N, offset, replace, rng_stream): the launch's extra workgroup draws the next step's batch into idx."""
-    if sample is not None:
-        idx, N, offset, replace, rng_stream = sample
-        _call('jamie_clip_adam_sample', ptr(p), ptr(g), int(g.dtype == torch.bfloat16), ptr(m), ptr(v), p.numel(), ptr(partials),
-              partials.numel(), ptr(hyper), ptr(state), ptr(p_bf16), ptr(idx), idx.numel(), int(N), int(offset), int(replace),
-              int(rng_stream), _stream())
+    Extra workgroups of the same launch, one kind at most: `sample` (sample_args) draws the next step's batch into idx;
+    `casts` (list of cast_problem, <= 16) gathers / casts the next step's batch rows."""
+    if sample is not None or casts:
+        arr = (CastProblem * len(casts))(*casts) if casts else None
+        _call('jamie_clip_adam_ride', ptr(p), ptr(g), int(g.dtype == torch.bfloat16), ptr(m), ptr(v), p.numel(), ptr(partials),
+              partials.numel(), ptr(hyper), ptr(state), ptr(p_bf16), C.pointer(sample) if sample is not None else None,
+              arr, len(casts) if casts else 0, _stream())
         return
     name = 'jamie_clip_adam_g16' if g.dtype == torch.bfloat16 else 'jamie_clip_adam'
     _call(name, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(partials), partials.numel(),

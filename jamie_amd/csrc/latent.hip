@@ -10,6 +10,7 @@
 // The B x B products (C z, C^T z, F comb, ...) are ~8 MFLOP each: plain VALU loops, not MFMA.
 #include "common.h"
 #include "latent_final.h"
+#include "sampler.h"
 
 #define LAT_SLOTS 16
 enum { S_MU2_0 = 0, S_MU2_1, S_TROW0, S_TROW1, S_AL0, S_AL1, S_F, S_DSIG0, S_DSIG1 };
@@ -655,8 +656,17 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
 }
 
 // ---- backward: d(mu | logvar) (+ bf16 copies), per-workgroup partial sums of d(sigma) and of the head-bias gradients ----
+// `smp` (optional): ONE extra workgroup draws the NEXT step's batch (jamie_latent_m_bwd_ex): the sampler is a one-workgroup job
+// whose own launch costs 5 us of every step; here, in the middle of the backward pass, it is early enough for the batch gather
+// to ride in the optimiser launch.  The norm kernel has not advanced the step counter yet: smp.step_add = 1.
 template <int LMAX>
-__global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a) {
+__global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleArgs smp, const uint64_t* state) {
+    const int n_work = (int)gridDim.x - (smp.idx ? 1 : 0);
+    if (smp.idx && (int)blockIdx.x == n_work) {
+        __shared__ SampleLds smp_lds;
+        jamie_sample_block(smp_lds, smp.idx, smp.B, smp.N, smp.offset, smp.replace, state, smp.rng_stream, smp.step_add);
+        return;
+    }
     constexpr int EPT = LF_ROWS * LMAX / LF_NT;
     __shared__ float red[(LF_NT / 64 + 1) * (SM_SLOTS + 2)];
     __shared__ float T[LF_ROWS][2 * LMAX + 1];            // one modality's d(mu | logvar) of this workgroup's cells
@@ -771,7 +781,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = ticket == gridDim.x - 1;
+        is_last = ticket == (unsigned)(n_work - 1);
         if (is_last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -852,7 +862,7 @@ extern "C" int jamie_latent_m_fwd(const jamie_latent_m* a, const uint64_t* rng, 
     return jamie_launch_status("jamie_latent_m_fwd");
 }
 
-extern "C" int jamie_latent_m_bwd(const jamie_latent_m* a, void* stream) {
+static int latent_m_bwd_impl(const jamie_latent_m* a, const jamie_sample_args* smp, const uint64_t* state, void* stream) {
     LatMDev d;
     int rc = latm_to_dev(a, d);
     if (rc) return rc;
@@ -861,16 +871,28 @@ extern "C" int jamie_latent_m_bwd(const jamie_latent_m* a, void* stream) {
     JAMIE_ARG(a->ticket != nullptr || a->defer_final, "ticket: a zero-initialised device uint32 is required");
     JAMIE_ARG(a->dcomb_nslab == 1 || a->dcomb_slab_stride >= (long long)a->B * a->L, "dcomb_slab_stride too small");
     JAMIE_ARG(a->n_rec_partials == 0 || a->rec_partials, "rec_partials");
-    const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS;
-    hipStream_t st = (hipStream_t)stream;
-    if (a->L <= 32) {
-        hipLaunchKernelGGL((latent_m_bwd_kernel<32>), dim3(n_rb), dim3(LF_NT), 0, st, d);
-    } else if (a->L <= 64) {
-        hipLaunchKernelGGL((latent_m_bwd_kernel<64>), dim3(n_rb), dim3(LF_NT), 0, st, d);
-    } else {
-        hipLaunchKernelGGL((latent_m_bwd_kernel<128>), dim3(n_rb), dim3(LF_NT), 0, st, d);
+    SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    if (smp && smp->idx) {
+        JAMIE_ARG(state != nullptr, "sampler: rng state");
+        JAMIE_ARG(smp->B > 0 && smp->N > 0 && (smp->replace || (smp->B <= smp->N && smp->B <= SMP_HASH / 2)),
+                  "sampler: B <= N and B <= 2048 without replacement");
+        JAMIE_ARG(smp->N + smp->offset <= 0x7fffffffLL, "sampler: indices must fit int32");
+        sa.idx = smp->idx; sa.B = smp->B; sa.N = smp->N; sa.offset = smp->offset; sa.replace = smp->replace;
+        sa.rng_stream = smp->rng_stream; sa.step_add = smp->step_add;
     }
+    const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS + (sa.idx ? 1 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->L <= 32) hipLaunchKernelGGL((latent_m_bwd_kernel<32>), dim3(n_rb), dim3(LF_NT), 0, st, d, sa, state);
+    else if (a->L <= 64) hipLaunchKernelGGL((latent_m_bwd_kernel<64>), dim3(n_rb), dim3(LF_NT), 0, st, d, sa, state);
+    else hipLaunchKernelGGL((latent_m_bwd_kernel<128>), dim3(n_rb), dim3(LF_NT), 0, st, d, sa, state);
     return jamie_launch_status("jamie_latent_m_bwd");
+}
+
+extern "C" int jamie_latent_m_bwd(const jamie_latent_m* a, void* stream) { return latent_m_bwd_impl(a, nullptr, nullptr, stream); }
+
+extern "C" int jamie_latent_m_bwd_ex(const jamie_latent_m* a, const jamie_sample_args* sample, const uint64_t* state, void* stream) {
+    return latent_m_bwd_impl(a, sample, state, stream);
 }
 
 /* workspace for the head-bias partial sums: floats */

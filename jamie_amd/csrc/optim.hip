@@ -11,6 +11,7 @@
 #include "sampler.h"
 #include "latent_final.h"
 #include "colsum.h"
+#include "cast_tile.h"
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n,
                                                           float* partials, uint64_t* state) {
@@ -60,22 +61,28 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
     }
 }
 
-struct SampleArgs { int32_t* idx; int B; long long N; long long offset; int replace; int rng_stream; };
-
-template <int U, int T, bool SMP>
+// RIDE: EXTRA workgroups after the `n_stream` streaming ones do work of the NEXT step that would otherwise be launches of its
+// own on the critical path, beside 256 streaming workgroups that run for ~190 us anyway:
+//   * one workgroup (if smp.idx): the next batch's sampler (state[1] already holds the next step's number), and / or
+//   * the next batch's row gather + bf16 cast (jamie_cast_transpose's 64 x 64 tiles; the batch buffers are free once the last dW
+//     product of this step has run).  Sampler and gather never ride together here: the gather needs the sampler's output.
+template <int U, int T, bool RIDE>
 __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* partials, int n_partials,
                                                         const float* hyper, const uint64_t* state,
                                                         unsigned short* __restrict__ p_bf16,
-                                                        const unsigned short* __restrict__ g_bf16, SampleArgs smp) {
-    // one EXTRA workgroup (the last one) draws the next step's batch indices when `smp.idx` is set: the sampler is a
-    // one-workgroup job whose own launch cost 5 us of every step; here it runs beside 256 streaming workgroups for free.
-    // state[1] already holds the next step's number (the norm kernel advanced it).
-    if constexpr (SMP) {
-        __shared__ SampleLds smp_lds;
-        if (blockIdx.x == gridDim.x - 1) {
-            jamie_sample_block(smp_lds, smp.idx, smp.B, smp.N, smp.offset, smp.replace, state, smp.rng_stream);
+                                                        const unsigned short* __restrict__ g_bf16, SampleArgs smp, CastGroup casts,
+                                                        int n_stream) {
+    if constexpr (RIDE) {
+        if ((int)blockIdx.x >= n_stream) {
+            if (smp.idx) {
+                __shared__ SampleLds smp_lds;
+                jamie_sample_block(smp_lds, smp.idx, smp.B, smp.N, smp.offset, smp.replace, state, smp.rng_stream, smp.step_add);
+            } else {
+                __shared__ float ctile[64][65];
+                cast_tile_block(casts, (int)blockIdx.x - n_stream, ctile);
+            }
             return;
         }
     }
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    const long long nwg = SMP ? gridDim.x - 1 : gridDim.x;          // streaming workgroups
+    const long long nwg = RIDE ? n_stream : gridDim.x;          // streaming workgroups
     for (long long i0 = (long long)blockIdx.x * (T * U) + threadIdx.x; i0 < n4; i0 += nwg * (T * U)) {
         // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
         float4 pp[U], mm[U], vv[U], gg[U];
@@ -305,8 +312,8 @@ extern "C" int jamie_grad_sqnorm(const float* g, long long n, float* partials, i
 }
 
 static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m, float* v, long long n, const float* partials,
-                          int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, const SampleArgs* smp,
-                          void* stream) {
+                          int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, const jamie_sample_args* smp,
+                          const jamie_cast_problem* casts, int n_casts, void* stream) {
     JAMIE_ARG(p && (g || g_bf16) && m && v && partials && hyper && state && n > 0, "null pointer / empty");
     JAMIE_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                   ((uintptr_t)v % 16) == 0 && ((uintptr_t)g_bf16 % 8) == 0, "buffers must be 16-byte aligned (bf16 gradient: 8)");
@@ -317,17 +324,29 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
     // one workgroup per CU (fewer, longer streams keep more DRAM pages open: 2048 workgroups x 1 float4 4.8 TB/s), eight
     // waves each with one float4 per array in flight: 5.8 TB/s where four waves x two float4 reached 5.0-5.2 on the slower
     // boxes of the pool and 5.7 on the faster ones (tools/bench_adam.py; in the step 231 -> 209 us on a slow box)
-    if (smp && smp->idx) {
+    SampleArgs sa;
+    CastGroup cg;
+    memset(&sa, 0, sizeof(sa));
+    memset(&cg, 0, sizeof(cg));
+    const bool has_smp = smp && smp->idx, has_cast = casts && n_casts > 0;
+    JAMIE_ARG(!(has_smp && has_cast), "the sampler and the gather cannot ride in the same launch (the gather reads the sampler's output)");
+    if (has_smp) {
         JAMIE_ARG(smp->B > 0 && smp->N > 0 && (smp->replace || (smp->B <= smp->N && smp->B <= SMP_HASH / 2)),
                   "sampler: B <= N and B <= 2048 without replacement");
         JAMIE_ARG(smp->N + smp->offset <= 0x7fffffffLL, "sampler: indices must fit int32");
+        sa.idx = smp->idx; sa.B = smp->B; sa.N = smp->N; sa.offset = smp->offset; sa.replace = smp->replace;
+        sa.rng_stream = smp->rng_stream; sa.step_add = smp->step_add;
         hipLaunchKernelGGL((clip_adam_kernel<1, 512, true>), dim3(grid + 1), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
-                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, *smp);
+                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, sa, cg, grid);
+    } else if (has_cast) {
+        int blocks = 0;
+        const int rc = jamie_cast_fill_group(casts, n_casts, &cg, &blocks);
+        if (rc) return rc;
+        hipLaunchKernelGGL((clip_adam_kernel<1, 512, true>), dim3(grid + blocks), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
+                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, sa, cg, grid);
     } else {
-        SampleArgs none;
-        memset(&none, 0, sizeof(none));
         hipLaunchKernelGGL((clip_adam_kernel<1, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
-                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, none);
+                           partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, sa, cg, grid);
     }
     return jamie_launch_status("jamie_clip_adam");
 }
@@ -335,24 +354,22 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
 extern "C" int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                                int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
     JAMIE_ARG(g != nullptr, "null gradient");
-    return clip_adam_impl(p, g, nullptr, m, v, n, partials, n_partials, hyper, state, p_bf16, nullptr, stream);
+    return clip_adam_impl(p, g, nullptr, m, v, n, partials, n_partials, hyper, state, p_bf16, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int jamie_clip_adam_g16(float* p, const void* g_bf16, float* m, float* v, long long n, const float* partials,
                                    int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, void* stream) {
     JAMIE_ARG(g_bf16 != nullptr, "null gradient");
-    return clip_adam_impl(p, nullptr, g_bf16, m, v, n, partials, n_partials, hyper, state, p_bf16, nullptr, stream);
+    return clip_adam_impl(p, nullptr, g_bf16, m, v, n, partials, n_partials, hyper, state, p_bf16, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int jamie_clip_adam_sample(float* p, const void* g, int g_is_bf16, float* m, float* v, long long n,
-                                      const float* partials, int n_partials, const float* hyper, const uint64_t* state,
-                                      void* p_bf16, int32_t* idx, int B, long long N, long long offset, int replace,
-                                      int rng_stream, void* stream) {
-    JAMIE_ARG(g != nullptr && idx != nullptr, "null gradient / index buffer");
-    SampleArgs smp;
-    smp.idx = idx; smp.B = B; smp.N = N; smp.offset = offset; smp.replace = replace; smp.rng_stream = rng_stream;
+extern "C" int jamie_clip_adam_ride(float* p, const void* g, int g_is_bf16, float* m, float* v, long long n,
+                                    const float* partials, int n_partials, const float* hyper, const uint64_t* state,
+                                    void* p_bf16, const jamie_sample_args* sample, const jamie_cast_problem* casts, int n_casts,
+                                    void* stream) {
+    JAMIE_ARG(g != nullptr, "null gradient");
     return clip_adam_impl(p, g_is_bf16 ? nullptr : (const float*)g, g_is_bf16 ? g : nullptr, m, v, n, partials, n_partials, hyper,
-                          state, p_bf16, &smp, stream);
+                          state, p_bf16, sample, casts, n_casts, stream);
 }
 
 extern "C" int jamie_grad_sqnorm_bf16(const void* g_bf16, long long n, float* partials, int n_partials, uint64_t* state,

@@ -15,11 +15,15 @@
 //               probability below 2^-64 per slot.  Every wave leaves the loop after at most 64 rounds.
 #define SMP_HASH 4096
 struct SampleLds { long long key[SMP_HASH]; int owner[SMP_HASH]; int pending; };
+// what to draw; `step_add`: added to the step counter rng[1] (a launch that runs BEFORE the norm kernel has advanced the counter
+// draws the next step's batch with step_add = 1)
+struct SampleArgs { int32_t* idx; int B; long long N; long long offset; int replace; int rng_stream; int step_add; };
 
 // Without replacement and N > 4096 the slots are processed in chunks of 1024 (the stand-alone kernel's workgroup size), a
 // thread taking the slots tid, tid + NT, ... of a chunk: the index stream does not depend on the workgroup size.
 __device__ __forceinline__ void jamie_sample_block(SampleLds& L, int32_t* idx, int B, long long N, long long offset, int replace,
-                                                   const uint64_t* rng, int rng_stream) {
+                                                   const uint64_t* rng_in, int rng_stream, int step_add = 0) {
+    const uint64_t rng[2] = {rng_in[0], rng_in[1] + (uint64_t)step_add};
     long long (&key)[SMP_HASH] = L.key;
     int (&owner)[SMP_HASH] = L.owner;
     int& pending = L.pending;

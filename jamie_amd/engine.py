@@ -706,12 +706,16 @@ class TrainEngine:
         return d
 
     # ---- the step ----
+    def _batch_problems(self, data, idx):
+        """cast_transpose problems of the batch: row gather + fp32 / bf16 (/ transposed) copies."""
+        return [nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'] if 'x' in self.need_T else None,
+                                rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)]
+
     def load_batch(self, data, idx, with_wT=True):
         """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors.  `with_wT=False`: the batch is being
         loaded while the optimiser may still be writing the weights (prefetch): leave the weight transposes to _backward."""
         if self.bf16:      # gather + bf16 copy (+ transposed copy) of the batch, and the skinny weights' transposes: one launch
-            probs = [nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'] if 'x' in self.need_T else None,
-                                     rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)]
+            probs = self._batch_problems(data, idx)
             nv.cast_transpose(probs + (self._wT_problems() if with_wT else []))
             if with_wT:
                 self._wT_stale = False
@@ -855,7 +859,7 @@ class TrainEngine:
         self._cast('dxhat')
         return lat
 
-    def _backward(self, lat, noise, allreduce):
+    def _backward(self, lat, noise, allreduce, sample=None):
         B, L = self.B, self.L
         acc = self.accumulate
         self._wait_wT()
@@ -886,7 +890,10 @@ class TrainEngine:
         self._cast('de1')
         self._bwd_gemms('de1', 'dec0', 'comb', 'dcomb', 'd_comb')
         self._region(allreduce, 'dec0')
-        nv.latent_bwd(lat)                                                      # dml, dsigma, losses
+        if sample is not None:                 # + the NEXT batch's sampler as an extra workgroup (make_plan)
+            nv.latent_bwd(lat, sample, self.state)
+        else:
+            nv.latent_bwd(lat)                                                  # dml, dsigma, losses
         if acc:                                                                 # batch_step=False: d(sigma) accumulates
             self.g['sigma'].add_(self._dsig_tmp)
         if not (isinstance(lat, nv.LatentM) and lat.colpart):                   # (fused kernels: bf16 dml + head-bias gradients done)
@@ -924,7 +931,7 @@ class TrainEngine:
                                       self.grad16 if self._g16_now else None)
         return norm
 
-    def optimizer_step(self, g16=None, after_norm=None, sample=None):
+    def optimizer_step(self, g16=None, after_norm=None, sample=None, casts=None):
         """clip_grad_norm_(params, 1) + Adam.step (+ zero_grad: gradients are overwritten next step).
         `g16`: the reduced gradient as a flat bf16 tensor with the layout of `self.grad` (data-parallel exchange with
         bf16 messages); default: `self.grad`."""
@@ -944,10 +951,11 @@ class TrainEngine:
         if after_norm is not None:       # e.g. the next batch's sampler + gather on a side stream, under clip + Adam
             after_norm()
         if not self.pipeline:
-            # `sample`: the launch's extra workgroup draws the NEXT step's batch indices (make_plan)
+            # `sample` / `casts`: extra workgroups of the launch draw the NEXT step's batch indices, or (indices drawn earlier, in
+            # the latent backward launch) gather and cast the next batch itself (make_plan)
             self._launch('adam', lambda: nv.clip_adam(self.m.flat, grad, self.exp_avg, self.exp_avg_sq,
                                                        norm, self.hyper, self.state,
-                                                       self.wbf_flat if self.bf16 else None, sample))
+                                                       self.wbf_flat if self.bf16 else None, sample, casts))
             if self.bf16 and self.side_transposes:
                 # the K-contiguous W^T copies are only read by the NEXT backward pass: they are made on a side stream
                 # under the next forward pass (36 us of HBM-bound copying off the critical path)
@@ -986,9 +994,12 @@ class TrainEngine:
             nv.set_stream(None)
         self._opt_pending = True
 
-    def step(self, corr=None, Fblk=None, noise=None, allreduce=None, after_norm=None, sample=None):
+    def step(self, corr=None, Fblk=None, noise=None, allreduce=None, after_norm=None, sample=None, next_casts=None):
         """One training step.  `allreduce`: None (single GPU), a callable on the flat gradient, or an
-        `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them."""
+        `OverlappedGradAllReduce` that is fed parameter regions as the backward pass completes them.
+        `sample` (nv.sample_args): the NEXT batch's sampler rides in the clip + Adam launch; with `next_casts` (the next
+        batch's gather problems) it rides in the latent backward launch instead (sample.step_add = 1) and the gather
+        rides in clip + Adam."""
         # the fused latent backward kernel leaves its finalisation (losses, d sigma, head-bias gradients) to the range-norm
         # launch that follows in this very step when that launch exists (bf16 mode, one GPU, fused gradient norm)
         defer = (self.fused_norm and self.sq_ranges_nofin.blocks <= 128 and allreduce is None and not self.accumulate
@@ -998,7 +1009,7 @@ class TrainEngine:
         if defer and isinstance(lat, nv.LatentM):
             lat.defer_final = 1
             self._lat_deferred = lat
-        self._backward(lat, noise, allreduce)
+        self._backward(lat, noise, allreduce, sample if next_casts else None)
         g16 = None
         if allreduce is not None:
             # bf16 messages: the reduced gradient stays in the exchange's bf16 buffer; norm and Adam read it there
@@ -1012,7 +1023,7 @@ class TrainEngine:
             fn()
             if in_place:
                 g16 = allreduce.comm
-        self.optimizer_step(g16, after_norm, sample)
+        self.optimizer_step(g16, after_norm, None if next_casts else sample, next_casts)
 
     # ---- recorded launch plan: one foreign call per launch, no descriptor rebuilding (host cost ~3 us/launch) ----
     def make_plan(self, data, idx, n_rows, replace=False, allreduce=None, prefetch=False):
@@ -1033,12 +1044,25 @@ class TrainEngine:
             # the sampler of the NEXT batch rides in this step's clip + Adam launch (one extra workgroup: the same index
             # stream, no launch of its own); the first batch is drawn here, before the recording
             fused = not self.pipeline and (replace or idx.numel() <= 2048) and os.environ.get('JAMIE_NO_FUSED_SAMPLER') != '1'
+            # ... and where the latent backward launch can carry the sampler (fused M-modality kernels, identity
+            # correspondence, no weight transposes waiting for Adam's output) the next batch's GATHER rides in clip + Adam
+            # too: the batch buffers are free once the last dW product has run, and the step is then fwd + bwd + norm + Adam
+            early = (fused and self.bf16 and not self.wT and not replace and self._fused_latent(corr, None)
+                     and os.environ.get('JAMIE_NO_GATHER_RIDE') != '1')
             if fused:
                 nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
+            if early:
+                next_batch(sample=False)
+                self._plan_keep = (nv.sample_args(idx, n_rows, 0, replace, 200, step_add=1),
+                                   self._batch_problems(data, [idx] * self.M))
+            elif fused:
+                self._plan_keep = (nv.sample_args(idx, n_rows, 0, replace, 200), None)
             nv.begin_record()
             try:
-                next_batch(sample=not fused)
-                self.step(corr, None, None, allreduce, sample=(idx, n_rows, 0, replace, 200) if fused else None)
+                if not early:
+                    next_batch(sample=not fused)
+                self.step(corr, None, None, allreduce, sample=self._plan_keep[0] if fused else None,
+                          next_casts=self._plan_keep[1] if early else None)
             finally:
                 plan = nv.end_record()
             return plan
