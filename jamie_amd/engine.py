@@ -82,6 +82,7 @@ def plan_bf16_bwd(B, shapes):
 
 
 F32_CFG_ROWS = 12           # 128x128x32 tile on 16 waves of 32x32 (gemm_f32.hip; 8 waves of 64x32, cfg 4, is 5-7 % slower)
+F32_CFG_DW = 1              # fp32 dW (TN, K = batch): 64x64x32 tile (sweep: tools/sweep_f32_dw.sh)
 
 
 def plan_f32_rows(B, shapes, target=2 * N_CU):
@@ -560,7 +561,10 @@ class TrainEngine:
         if self.bf16:
             nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
         else:
-            nv.gemm(probs, nv.NN, self.fcfg.get(sk_key, -1))
+            cfg = self.fcfg.get(sk_key, -1)
+            if cfg < 0 and os.environ.get('JAMIE_F32_DX_CFG') and sk_key in ('d_e2', 'd_a1'):
+                cfg = int(os.environ['JAMIE_F32_DX_CFG'])
+            nv.gemm(probs, nv.NN, cfg)
 
     def _dw_gemm(self, dy_key, a_key, lin):
         """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer."""
@@ -577,7 +581,13 @@ class TrainEngine:
         if self.bf16:
             nv.gemm_bf16(probs, self._dw_cfg(lin))
         else:
-            nv.gemm(probs, nv.TN)
+            nv.gemm(probs, nv.TN, self._f32_dw_cfg(lin))
+
+    def _f32_dw_cfg(self, lin):
+        """fp32 dW launch (TN, K = batch): tile configuration (-1: the library's 64 x 64 default)."""
+        env = os.environ.get('JAMIE_F32_DW_CFG')
+        big = self.B >= 256 and all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 512 for i in range(self.M))
+        return (int(env) if env else F32_CFG_DW) if big else -1
 
     def _dw_cfg(self, lin):
         """Tile configuration of the dW launch of layer `lin` (-1: the library default for small / skinny problems)."""
