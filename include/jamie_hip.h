@@ -30,6 +30,7 @@ extern "C" {
 #endif
 
 #define JAMIE_MAX_GROUP 4      /* problems per grouped launch (modalities) */
+#define JAMIE_MAX_GEMM_GROUP 8 /* problems per grouped GEMM launch (modalities x {dX, dW} + a skinny layer's dW riding along) */
 
 const char* jamie_last_error(void);
 int jamie_version(void);
@@ -83,7 +84,7 @@ typedef struct {
                                  * bytes per parameter written here and read again by jamie_clip_adam_g16 */
 } jamie_gemm_problem;
 
-/* One launch computing up to JAMIE_MAX_GROUP independent problems (the modalities of one layer). */
+/* One launch computing up to JAMIE_MAX_GEMM_GROUP independent problems (the modalities of one layer; dX and dW together). */
 int jamie_gemm_f32(const jamie_gemm_problem* problems /*host*/, int count, int layout, void* stream);
 /* Same with an explicit tile configuration (tuning / benchmarks); cfg < 0 = choose by shape. */
 int jamie_gemm_f32_cfg(const jamie_gemm_problem* problems /*host*/, int count, int layout, int cfg, void* stream);
@@ -245,6 +246,10 @@ typedef struct {
                          * resets it) */
     int defer_final;    /* 1: jamie_latent_m_bwd leaves the partial sums as they are; the step's range-norm launch finalises
                          * them in an extra workgroup (jamie_grad_sqnorm_ranges_fin), off the backward pass's critical path */
+    /* optional fused tail of jamie_latent_m_bwd: da2[i] [B, d[i]] (fp32, ld = d[i]) = d(mu | logvar)_i [B, 2L] head_W[i] [2L, d[i]]
+     * -- the heads' input gradient (dx of nn.Linear(d, 2L), model.py:141-143) computed by extra workgroups of the same launch
+     * in exact fp32; d[i] a multiple of 4.  NULL: the caller runs that product as a GEMM. */
+    const float* head_W[4]; float* da2[4];
 } jamie_latent_m;
 /* What a riding sampler draws: idx[B] = jamie_sample_indices(B, N, offset, replace, {seed, step + step_add}, rng_stream)
  * (np.random.choice of jamie/jamie.py:556).  step_add = 1 in a launch that runs before the norm kernel has advanced the step. */

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('JAMIE_HIP_LIB') or os.path.join(_HERE, 'libjamie_hip.so')
 
 MAX_GROUP = 4
+MAX_GEMM_GROUP = 8          # JAMIE_MAX_GEMM_GROUP: problems per grouped GEMM launch
 NT, NN, TN = 0, 1, 2
 EPI_STORE, EPI_MSE, EPI_BN_EVAL = 0, 1, 2
 
@@ -102,7 +103,7 @@ class LatentM(C.Structure):
                 ('comb_alias', C.c_void_p * 4), ('comb_bf16', C.c_void_p * 4), ('combT_bf16', C.c_void_p * 4),
                 ('dml_bf16', C.c_void_p * 4), ('dmlT_bf16', C.c_void_p * 4),
                 ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p),
-                ('defer_final', C.c_int)]
+                ('defer_final', C.c_int), ('head_W', C.c_void_p * 4), ('da2', C.c_void_p * 4)]
 
 
 class SampleArgs(C.Structure):

@@ -40,7 +40,7 @@ struct GemmBDev {
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
-struct GemmBGroup { GemmBDev p[JAMIE_MAX_GROUP]; int count; };
+struct GemmBGroup { GemmBDev p[JAMIE_MAX_GEMM_GROUP]; int count; };
 
 #define JB_OOB 0xFFFFFFF0u
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
 #pragma unroll
-    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
         if (i < g.count) {
             const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
             const int j = (xcd - rot) & 7;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
 #pragma unroll
-    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
         if (i < g.count) {
             const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
             const int j = (xcd - rot) & 7;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
 #pragma unroll
-    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) {
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
         if (i < g.count) {
             const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
             const int j = (xcd - rot) & 7;
@@ -955,7 +955,7 @@ static const int BT[33][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}
 static int pick_cfg_b(int max_m, int max_n, int min_k) { (void)max_m; (void)max_n; return min_k >= 1000 ? 7 : 10; }
 
 extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg, void* stream) {
-    JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
+    JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GEMM_GROUP, "1 <= count <= JAMIE_MAX_GEMM_GROUP");
     int max_m = 0, max_n = 0, min_k = 1 << 30;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];

@@ -12,6 +12,8 @@
 #include "latent_final.h"
 #include "sampler.h"
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 #define LAT_SLOTS 16
 enum { S_MU2_0 = 0, S_MU2_1, S_TROW0, S_TROW1, S_AL0, S_AL1, S_F, S_DSIG0, S_DSIG1 };
 
@@ -435,10 +437,15 @@ extern "C" int jamie_latent_bwd(const jamie_latent* a, void* stream) {
 // For M = 2 it coincides with the two-modality kernels above at corr = I (tested).  No oracle in the reference:
 // parity for M = 3 is pinned only against the generalised CPU oracle's autograd.
 // =================================================================================================
-// diagnostic build only (-DJAMIE_LAT_STAMP, tools/bench_latent_m.py): thread 0 of workgroup 0 (forward) / of the last workgroup
-// (backward) writes s_memrealtime (100 MHz) deltas into partials[19 * JAMIE_MAX_PARTIALS + k]; nothing reads them
+// diagnostic build only (-DJAMIE_LAT_STAMP, tools/stamp_latent.sh): thread 0 of EVERY workgroup of the fused kernels writes
+// s_memrealtime (100 MHz) at its phase boundaries into a buffer of its own (forward: slots 0..7, backward: 8..15 of the
+// workgroup's 16); nothing else reads it and no stamp exists in the product build
 #ifdef JAMIE_LAT_STAMP
-#define LSTAMP(a, k) do { if (threadIdx.x == 0) (a).partials[19 * JAMIE_MAX_PARTIALS + (k)] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull); } while (0)
+__device__ unsigned long long jamie_lat_stamps[1024 * 16];
+#define LSTAMP(a, k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) jamie_lat_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int jamie_latent_debug_stamps(unsigned long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(jamie_lat_stamps), sizeof(unsigned long long) * 16 * n_blocks);
+}
 #else
 #define LSTAMP(a, k) do {} while (0)
 #endif
@@ -467,6 +474,9 @@ struct LatMDev {
     int defer_final;              // the caller finalises later (jamie_grad_sqnorm_ranges_fin): no ticket, no finalisation here
     LatFinal fin;
     int chunk_begin[LM + 1];      // column chunks of the decoder product, per modality (prefix sums)
+    // fused tail of the backward launch: da2_i [B, d_i] = d(mu | logvar)_i [B, 2L] head_W_i [2L, d_i] (the heads' input gradient)
+    const float* head_W[LM]; float* da2[LM];
+    int bchunk_begin[LM + 1];     // column chunks of that product (chunk 0: the owner workgroups), prefix sums
 };
 
 // ---- forward: ONE launch from the heads' split-K slabs to the decoder's first pre-activation ----
@@ -477,15 +487,18 @@ struct LatMDev {
 // comb[32, L] W[COLS, L]^T + b in exact fp32 on the vector ALU (K = L <= 128: 0.2 GFLOP per step in all, not MFMA work):
 // comb and the W chunk sit in LDS (W rows padded by one float: conflict-free), a thread owns one column and RPT rows.
 // Replaces four launches of the two-modality path (reparameterise, combine, bf16 casts, the [B, L] x [L, d] GEMM).
-template <int LMAX, int COLS>
+// MM = the number of modalities as a template constant: the per-modality register arrays of phase A are sized for LM = 4, and with
+// a run-time M the compiler keeps all four alive (spills at 1024 threads)
+template <int LMAX, int COLS, int MM>
 __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const uint64_t* rng) {
-    constexpr int RPT = LF_ROWS * COLS / LF_NT;        // rows per thread in phase B
     constexpr int EPT = LF_ROWS * LMAX / LF_NT;        // elements per thread and modality in phase A (upper bound)
     constexpr int WV = COLS * LMAX / 4 / LF_NT;        // float4 of the W chunk per thread (upper bound)
+    constexpr int TRIP = LMAX * MM <= 64 ? 8 : (LMAX * MM <= 128 ? 4 : 2);      // slabs whose loads are in flight together
     __shared__ float Ws[COLS][LMAX + 1];
-    __shared__ __attribute__((aligned(16))) float Cs[LF_ROWS][LMAX];
+    __shared__ float Cs[LF_ROWS][LMAX + 2];            // (+2: the MFMA operand read Cs[lane & 31][k + (lane >> 5)] is conflict-free)
     __shared__ float red[(LF_NT / 64 + 1) * (3 * LM + 1)];
-    const int B = a.B, L = a.L, M = a.M, tid = threadIdx.x;
+    constexpr int M = MM;
+    const int B = a.B, L = a.L, tid = threadIdx.x;
     const int n_rb = (B + LF_ROWS - 1) / LF_ROWS;
     const int rb = blockIdx.x % n_rb, chunk = blockIdx.x / n_rb;
     const int r0 = rb * LF_ROWS;
@@ -499,10 +512,12 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
     // chunks 1.. are the decoder products
     const bool owner = chunk == 0;
     const bool dec = !owner && a.g1[mi] != nullptr;
-    if (blockIdx.x == 0) LSTAMP(a, 0);
-    // the W chunk's loads go out first: their latency hides under phase A
+    LSTAMP(a, 0);
+    // the W chunk's loads (and the bias of this lane's output column) go out first: their latency hides under phase A
     const int L4 = L >> 2;
     float4 wreg[WV];
+    float bias = 0.f;
+    const int ocol = c0 + ((tid >> 6) % (COLS / 32)) * 32 + (tid & 31);      // phase B: the column of this lane's MFMA results
     if (dec) {
 #pragma unroll
         for (int t = 0; t < WV; ++t) {
@@ -511,16 +526,14 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
             if (f < COLS * L4 && c0 + c < a.d[mi])
                 wreg[t] = *reinterpret_cast<const float4*>(a.dec0_W[mi] + (long long)(c0 + c) * L + 4 * k4);
         }
+        if (ocol < a.d[mi]) bias = a.dec0_b[mi][ocol];
     }
     // ---- phase A ----  (all loads and the arithmetic first, results in registers; the stores follow in a second loop:
     // a store between two elements' loads would serialise their latencies, the pointers may alias for all the compiler knows)
     float p_mu2[LM] = {0.f, 0.f, 0.f, 0.f}, p_trow[LM] = {0.f, 0.f, 0.f, 0.f}, p_al[LM] = {0.f, 0.f, 0.f, 0.f}, p_f = 0.f;
     float S = 0.f, sgm[LM];
 #pragma unroll
-    for (int i = 0; i < LM; ++i) {
-        sgm[i] = i < M ? a.sigma[i] : 0.f;
-        S += sgm[i];
-    }
+    for (int i = 0; i < LM; ++i) sgm[i] = i < M ? a.sigma[i] : 0.f;       // (first used after the slab loop: no wait in front of it)
     float v_mu[EPT][LM], v_lv[EPT][LM], v_ep[EPT][LM], v_z[EPT][LM], v_comb[EPT];
     // the slab loop is the OUTER loop: one round trip per slab for all of a thread's elements (inside the element loop
     // its runtime trip count serialised 3 x EPT x M dependent round trips: 36 us for this launch)
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
             v_lv[j][i] = (i < M && ok) ? a.head_bias[i][L + l] : 0.f;
         }
     }
-    for (int s0 = 0; s0 < a.ml_nslab; s0 += 4) {          // four slabs' loads in flight per round trip, added in slab order
+    for (int s0 = 0; s0 < a.ml_nslab; s0 += TRIP) {       // TRIP slabs' loads in flight per round trip, added in slab order
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int el = tid + LF_NT * j;
@@ -544,19 +557,21 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
 #pragma unroll
             for (int i = 0; i < LM; ++i) {
                 if (i >= M || !ok) continue;
-                float tm[4], tl[4];
+                float tm[TRIP], tl[TRIP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TRIP; ++u) {
                     const float* p = a.ml[i] + (s0 + u) * a.ml_slab_stride + (long long)b * 2 * L;
                     tm[u] = s0 + u < a.ml_nslab ? p[l] : 0.f;
                     tl[u] = s0 + u < a.ml_nslab ? p[L + l] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { v_mu[j][i] += tm[u]; v_lv[j][i] += tl[u]; }
+                for (int u = 0; u < TRIP; ++u) { v_mu[j][i] += tm[u]; v_lv[j][i] += tl[u]; }
             }
         }
     }
-    if (blockIdx.x == 0) LSTAMP(a, 4);
+    LSTAMP(a, 1);
+#pragma unroll
+    for (int i = 0; i < LM; ++i) S += sgm[i];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int el = tid + LF_NT * j;
@@ -564,19 +579,23 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         const bool ok = el < LF_ROWS * L && b < B;
         const int e = ok ? b * L + l : 0;
         float num = 0.f;
+        // eps ~ N(0, 1): ONE Philox call and ONE Box-Muller pair per element and PAIR of modalities (its cosine branch is the
+        // even modality's draw, its sine branch the odd one's: independent normals); every workgroup of the row block draws
+        // the same numbers.  (A call per modality was half of phase A's 2 us: a wave64 instruction occupies its SIMD 4 cycles.)
+        float draw[LM];
+#pragma unroll
+        for (int i = 0; i < LM; i += 2) {
+            draw[i] = draw[i + 1] = 0.f;
+            if (i >= M || !ok || (a.eps_in[i] && (i + 1 >= M || a.eps_in[i + 1]))) continue;
+            Philox4 r = jamie_rand4(rng, (uint32_t)(a.rng_stream + (i >> 1)), (uint64_t)e);
+            jamie_box_muller(r.v[0], r.v[1], draw[i], draw[i + 1]);
+        }
 #pragma unroll
         for (int i = 0; i < LM; ++i) {
             v_ep[j][i] = v_z[j][i] = 0.f;
             if (i >= M || !ok) continue;
             const float mu = v_mu[j][i], lv = v_lv[j][i];
-            float ep;
-            if (a.eps_in[i]) {
-                ep = a.eps_in[i][e];
-            } else {
-                Philox4 r = jamie_rand4(rng, (uint32_t)(a.rng_stream + i), (uint64_t)e);
-                float n1;
-                jamie_box_muller(r.v[0], r.v[1], ep, n1);
-            }
+            const float ep = a.eps_in[i] ? a.eps_in[i][e] : draw[i];
             const float z = mu + ep * (expf(0.5f * lv) + 1e-7f);
             v_mu[j][i] = mu; v_lv[j][i] = lv; v_ep[j][i] = ep; v_z[j][i] = z;
             num += sgm[i] * z;
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         }
         p_f += comb * comb;
     }
-    if (blockIdx.x == 0) LSTAMP(a, 1);
+    LSTAMP(a, 2);
     if (owner) {           // (uniform per workgroup)
         float pv[3 * LM + 1];
 #pragma unroll
@@ -617,7 +636,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         if (tid < 3 * LM + 1) a.partials[tid * JAMIE_MAX_PARTIALS + rb] = red[tid];
         lds_barrier();
     }
-    if (blockIdx.x == 0) LSTAMP(a, 2);
+    LSTAMP(a, 3);
     if (!dec) return;
     // ---- phase B ----
 #pragma unroll
@@ -628,83 +647,138 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         }
     }
     lds_barrier();
-    const int c = tid % COLS, rbase = (tid / COLS) * RPT;
-    float acc[RPT];
+    // exact-fp32 MFMA (32x32x2): wave w < COLS / 32 owns the 32-column tile w (waves are dealt round-robin to the SIMDs; the
+    // matrix pipe's time is the same however the K = L steps are split over a SIMD's waves, so the other waves just leave).
+    // One column x RPT rows per thread on the vector ALU was bound by its LDS reads: 2.3 us for this phase.
+    {
+        constexpr int NTILE = COLS / 32;
+        const int wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+        if (wv >= NTILE) return;
+        f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
-    for (int k4 = 0; k4 < L4; ++k4) {
-        const float w0 = Ws[c][4 * k4], w1 = Ws[c][4 * k4 + 1], w2 = Ws[c][4 * k4 + 2], w3 = Ws[c][4 * k4 + 3];
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const float4 cv = *reinterpret_cast<const float4*>(&Cs[rbase + r][4 * k4]);      // broadcast read
-            acc[r] = fmaf(cv.x, w0, acc[r]);
-            acc[r] = fmaf(cv.y, w1, acc[r]);
-            acc[r] = fmaf(cv.z, w2, acc[r]);
-            acc[r] = fmaf(cv.w, w3, acc[r]);
+        for (int g0 = 0; g0 < LMAX; g0 += 16) {     // 8 MFMAs per group: the 16 operand reads go out together, ahead of them
+            if (g0 >= L) break;                     // (uniform)
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = g0 + 2 * u + h;
+                av[u] = k < L ? Cs[r][k] : 0.f;
+                bv[u] = k < L ? Ws[wv * 32 + r][k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        LSTAMP(a, 4);
+        if (ocol < a.d[mi]) {
+            float* out = a.g1[mi] + ocol;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int b = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (b < B) out[(long long)b * a.d[mi]] = acc[e] + bias;
+            }
         }
     }
-    if (blockIdx.x == 0) LSTAMP(a, 3);
-    if (c0 + c < a.d[mi]) {
-        const float bias = a.dec0_b[mi][c0 + c];
-        float* out = a.g1[mi] + c0 + c;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int b = r0 + rbase + r;
-            if (b < B) out[(long long)b * a.d[mi]] = acc[r] + bias;
-        }
-    }
+    LSTAMP(a, 5);
 }
 
 // ---- backward: d(mu | logvar) (+ bf16 copies), per-workgroup partial sums of d(sigma) and of the head-bias gradients ----
 // `smp` (optional): ONE extra workgroup draws the NEXT step's batch (jamie_latent_m_bwd_ex): the sampler is a one-workgroup job
 // whose own launch costs 5 us of every step; here, in the middle of the backward pass, it is early enough for the batch gather
 // to ride in the optimiser launch.  The norm kernel has not advanced the step counter yet: smp.step_add = 1.
-template <int LMAX>
+template <int LMAX, int COLS, int MM>
 __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleArgs smp, const uint64_t* state) {
+    constexpr int WB_BYTES = 2 * LMAX * COLS * 4;          // the head-weight chunk of phase B: [2L][COLS] fp32 (64 KB)
+    constexpr int BIG = WB_BYTES > (int)sizeof(SampleLds) ? WB_BYTES : (int)sizeof(SampleLds);
+    __shared__ __attribute__((aligned(16))) unsigned char big[BIG];      // sampler workgroup: its tables; the others: Ws
     const int n_work = (int)gridDim.x - (smp.idx ? 1 : 0);
     if (smp.idx && (int)blockIdx.x == n_work) {
-        __shared__ SampleLds smp_lds;
-        jamie_sample_block(smp_lds, smp.idx, smp.B, smp.N, smp.offset, smp.replace, state, smp.rng_stream, smp.step_add);
+        jamie_sample_block(*reinterpret_cast<SampleLds*>(big), smp.idx, smp.B, smp.N, smp.offset, smp.replace, state,
+                           smp.rng_stream, smp.step_add);
         return;
     }
     constexpr int EPT = LF_ROWS * LMAX / LF_NT;
+    constexpr int WV = 2 * LMAX * COLS / 4 / LF_NT;        // float4 of the head-weight chunk per thread (upper bound)
     __shared__ float red[(LF_NT / 64 + 1) * (SM_SLOTS + 2)];
-    __shared__ float T[LF_ROWS][2 * LMAX + 1];            // one modality's d(mu | logvar) of this workgroup's cells
-    const int B = a.B, L = a.L, M = a.M, n = B * L, tid = threadIdx.x;
-    const int rb = blockIdx.x, r0 = rb * LF_ROWS;
+    __shared__ float T[LF_ROWS][2 * LMAX + 2];           // one modality's d(mu | logvar) of this workgroup's cells (+2: the MFMA
+                                                           // operand read T[lane & 31][k + (lane >> 5)] is conflict-free)
+    constexpr int M = MM;
+    const int B = a.B, L = a.L, n = B * L, tid = threadIdx.x;
+    // workgroup (rb, chunk): chunk 0 = the OWNER of the 32 cells (stores, partial sums); chunks 1.. recompute the cells'
+    // d(mu | logvar) (a few KB from L2) and multiply one modality's by COLS columns of its head weight: the heads' input
+    // gradient without a GEMM launch of its own (K = 2L: 0.2 GFLOP per step, exact-fp32 MFMA)
+    const int n_rb = (B + LF_ROWS - 1) / LF_ROWS;
+    const int rb = blockIdx.x % n_rb, chunk = blockIdx.x / n_rb, r0 = rb * LF_ROWS;
+    const bool owner = chunk == 0;
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < LM; ++i)
+        if (i < M && chunk >= a.bchunk_begin[i]) mi = i;
+    const int c0 = owner ? 0 : (chunk - a.bchunk_begin[mi]) * COLS;
+    const int K2 = 2 * L, C4 = COLS / 4;
+    float4 wreg[WV];
+    auto load_w = [&]() {
+        const int dd = a.d[mi];
+#pragma unroll
+        for (int t = 0; t < WV; ++t) {
+            const int f = tid + LF_NT * t, k = f / C4, c4 = f % C4;
+            wreg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K2 && c0 + 4 * c4 < dd)            // (d is a multiple of 4: a float4 is inside the row or outside)
+                wreg[t] = *reinterpret_cast<const float4*>(a.head_W[mi] + (long long)k * dd + c0 + 4 * c4);
+        }
+    };
+    // the weight chunk's loads go out first: their latency hides under phase A (L > 64: phase A needs the registers)
+    if (!owner && LMAX < 128) load_w();
     const float invBL = 1.f / (float)n;
     const float kl_scale = a.hyper[0], w_al = a.hyper[2], w_f = a.hyper[3];
     float ds[LM] = {0.f, 0.f, 0.f, 0.f};
-    if (blockIdx.x == 0) LSTAMP(a, 8);
+    LSTAMP(a, 8);
     float S = 0.f, sgm[LM];
 #pragma unroll
-    for (int i = 0; i < LM; ++i) {
-        sgm[i] = i < M ? a.sigma[i] : 0.f;
-        S += sgm[i];
-    }
+    for (int i = 0; i < LM; ++i) sgm[i] = i < M ? a.sigma[i] : 0.f;       // (first used after the slab loop)
     // loads and arithmetic first (see the forward kernel), results in registers; the slab loop of the upstream gradient
     // d comb (every modality's decoder contributes; split-K slabs) is the outer loop: one round trip per slab
+    constexpr int TRIP = LMAX * MM <= 64 ? 8 : (LMAX * MM <= 128 ? 4 : 2);      // slabs whose loads are in flight together
+    constexpr bool PRE = LMAX <= 64;                     // the cells' saved state is loaded in front of the slab loop (registers permitting)
     float v_dmu[EPT][LM], v_dlv[EPT][LM], v_up[EPT];
+    float s_comb[EPT], s_z[EPT][LM], s_lv[EPT][LM], s_mu[EPT][LM], s_ep[EPT][LM];
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) v_up[j] = 0.f;
-    for (int s0 = 0; s0 < a.dcomb_nslab; s0 += 4) {
+    for (int j = 0; j < EPT; ++j) {
+        v_up[j] = 0.f;
+        if (!PRE) continue;
+        const int el = tid + LF_NT * j;
+        const int row = el / L, l = el % L, b = r0 + row;
+        const bool ok = el < LF_ROWS * L && b < B;
+        const int e = ok ? b * L + l : 0;
+        s_comb[j] = a.comb[e];
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            if (i >= M) continue;
+            s_z[j][i] = a.z[i][e]; s_lv[j][i] = a.lv[i][e]; s_mu[j][i] = a.mu[i][e]; s_ep[j][i] = a.eps[i][e];
+        }
+    }
+    for (int s0 = 0; s0 < a.dcomb_nslab; s0 += TRIP) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int el = tid + LF_NT * j;
             const int row = el / L, l = el % L, b = r0 + row;
             if (el >= LF_ROWS * L || b >= B) continue;
-            float tu[LM][4];
+            float tu[LM][TRIP];
 #pragma unroll
             for (int i = 0; i < LM; ++i)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < TRIP; ++u)
                     tu[i][u] = (i < M && s0 + u < a.dcomb_nslab) ? a.dcomb[i][(long long)b * L + l + (s0 + u) * a.dcomb_slab_stride] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < TRIP; ++u)
 #pragma unroll
                 for (int i = 0; i < LM; ++i) v_up[j] += tu[i][u];
         }
     }
+    LSTAMP(a, 10);
+#pragma unroll
+    for (int i = 0; i < LM; ++i) S += sgm[i];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int el = tid + LF_NT * j;
@@ -714,13 +788,13 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
 #pragma unroll
         for (int i = 0; i < LM; ++i) v_dmu[j][i] = v_dlv[j][i] = 0.f;
         if (!ok) continue;
-        const float comb = a.comb[e];
+        const float comb = PRE ? s_comb[j] : a.comb[e];
         float G = w_f * 2.f * comb * invBL + v_up[j];         // F loss acts on combined[0]; + the decoders' d comb
         float ga[LM], zz[LM];
 #pragma unroll
         for (int i = 0; i < LM; ++i) {
             if (i >= M) continue;
-            zz[i] = a.z[i][e];
+            zz[i] = PRE ? s_z[j][i] : a.z[i][e];
             ga[i] = w_al * 2.f * (zz[i] - comb) * invBL;      // d CosSim / d z_i ;  -ga[i] is d / d comb_i
             G -= ga[i];
         }
@@ -728,13 +802,69 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
         for (int i = 0; i < LM; ++i) {
             if (i >= M) continue;
             const float dz = sgm[i] / S * G + ga[i];
-            const float lv = a.lv[i][e];
-            const float dmu = dz + kl_scale * a.mu[i][e] * invBL;
-            float dlv = dz * a.eps[i][e] * 0.5f * expf(0.5f * lv);
+            const float lv = PRE ? s_lv[j][i] : a.lv[i][e];
+            const float dmu = dz + kl_scale * (PRE ? s_mu[j][i] : a.mu[i][e]) * invBL;
+            float dlv = dz * (PRE ? s_ep[j][i] : a.eps[i][e]) * 0.5f * expf(0.5f * lv);
             if (i == M - 1 && b < M) dlv += kl_scale * (-0.5f) * (1.f - expf(lv)) / (float)L;
             v_dmu[j][i] = dmu; v_dlv[j][i] = dlv;
             ds[i] += G * (zz[i] - comb) / S;
         }
+    }
+    LSTAMP(a, 11);
+    if (!owner) {                      // (uniform) ---- phase B: da2[32 cells, COLS] = T[32, 2L] Ws[2L, COLS] ----
+        float (*Ws)[COLS] = reinterpret_cast<float (*)[COLS]>(big);
+        if (LMAX >= 128) load_w();
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            if (i != mi) continue;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int el = tid + LF_NT * j;
+                if (el >= LF_ROWS * L) continue;
+                const int row = el / L, l = el % L;
+                T[row][l] = v_dmu[j][i]; T[row][L + l] = v_dlv[j][i];       // (rows beyond B hold zeros)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < WV; ++t) {
+            const int f = tid + LF_NT * t, k = f / C4, c4 = f % C4;
+            if (k < K2) *reinterpret_cast<float4*>(&Ws[k][4 * c4]) = wreg[t];
+        }
+        lds_barrier();
+        LSTAMP(a, 12);
+        // exact-fp32 MFMA (32x32x2): wave w < COLS / 32 owns the 32-column tile w and all of K = 2L (see the forward kernel).
+        // (One column x RPT rows per thread on the vector ALU was bound by its 12 LDS reads per 32 FMAs.)
+        constexpr int NTILE = COLS / 32;
+        const int wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+        if (wv >= NTILE) return;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int g0 = 0; g0 < 2 * LMAX; g0 += 16) {     // 8 MFMAs per group: the 16 operand reads go out together, ahead of them
+            if (g0 >= K2) break;                        // (uniform)
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = g0 + 2 * u + h;
+                av[u] = k < K2 ? T[r][k] : 0.f;
+                bv[u] = k < K2 ? Ws[k][wv * 32 + r] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        LSTAMP(a, 13);
+        const int col = c0 + wv * 32 + r;
+        if (col < a.d[mi]) {
+            float* out = a.da2[mi] + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int b = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (b < B) out[(long long)b * a.d[mi]] = acc[e];
+            }
+        }
+        LSTAMP(a, 14);
+        return;
     }
     // stores, and per modality the column sums over the workgroup's 32 cells through an LDS tile (rows added in order)
 #pragma unroll
@@ -770,6 +900,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
     LSTAMP(a, 9);
     block_sum_n<LM>(ds, red);
     if (tid < M) a.partials[(SM_DSIG + tid) * JAMIE_MAX_PARTIALS + rb] = red[tid];
+    LSTAMP(a, 15);
     // ---- the workgroup that finishes LAST finalises (losses, d sigma, head-bias gradients): a ticket counter instead of a
     // second launch.  Hand-off as MI355X_MICROARCH.md prescribes: every storing wave drains its stores, workgroup barrier,
     // one lane releases at agent scope and takes the ticket; the last one acquires at agent scope before anyone reads.
@@ -781,7 +912,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = ticket == (unsigned)(n_work - 1);
+        is_last = ticket == (unsigned)(n_rb - 1);          // (only the owner workgroups take tickets)
         if (is_last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -789,7 +920,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
         }
     }
     __syncthreads();
-    if (is_last) { LSTAMP(a, 10); latent_m_finalise(a.fin, red); LSTAMP(a, 14); }
+    if (is_last) latent_m_finalise(a.fin, red);
 }
 
 void jamie_latent_m_fill_final(const jamie_latent_m* a, LatFinal* f) {
@@ -830,6 +961,15 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
         chunks += a->g1[i] ? (a->d[i] + cols - 1) / cols : 0;
     }
     for (int i = a->M; i <= LM; ++i) d.chunk_begin[i] = chunks;
+    int bchunks = 1;
+    for (int i = 0; i < a->M; ++i) {
+        d.head_W[i] = a->head_W[i]; d.da2[i] = a->da2[i];
+        JAMIE_ARG(!a->da2[i] || (a->head_W[i] && a->d[i] > 0 && a->d[i] % 4 == 0 && ((uintptr_t)a->head_W[i] % 16) == 0),
+                  "heads' input gradient: head_W (16-byte aligned), d a multiple of 4");
+        d.bchunk_begin[i] = bchunks;
+        bchunks += a->da2[i] ? (a->d[i] + cols - 1) / cols : 0;
+    }
+    for (int i = a->M; i <= LM; ++i) d.bchunk_begin[i] = bchunks;
     d.colpart = a->colpart; d.accumulate = a->accumulate; d.ticket = a->ticket;
     d.ml_nslab = a->ml_nslab; d.ml_slab_stride = a->ml_slab_stride;
     d.sigma = a->sigma; d.hyper = a->hyper; d.comb = a->comb; d.partials = a->partials;
@@ -856,9 +996,16 @@ extern "C" int jamie_latent_m_fwd(const jamie_latent_m* a, const uint64_t* rng, 
     const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS;
     const int nblk = n_rb * d.chunk_begin[LM];
     hipStream_t st = (hipStream_t)stream;
-    if (a->L <= 32) hipLaunchKernelGGL((latent_m_fwd_kernel<32, 256>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);
-    else if (a->L <= 64) hipLaunchKernelGGL((latent_m_fwd_kernel<64, 128>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);
-    else hipLaunchKernelGGL((latent_m_fwd_kernel<128, 64>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);
+#define LATM_FWD(MM)                                                                                                          \
+    do {                                                                                                                      \
+        if (a->L <= 32) hipLaunchKernelGGL((latent_m_fwd_kernel<32, 256, MM>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);       \
+        else if (a->L <= 64) hipLaunchKernelGGL((latent_m_fwd_kernel<64, 128, MM>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);  \
+        else hipLaunchKernelGGL((latent_m_fwd_kernel<128, 64, MM>), dim3(nblk), dim3(LF_NT), 0, st, d, rng);                  \
+    } while (0)
+    if (a->M == 2) LATM_FWD(2);
+    else if (a->M == 3) LATM_FWD(3);
+    else LATM_FWD(4);
+#undef LATM_FWD
     return jamie_launch_status("jamie_latent_m_fwd");
 }
 
@@ -881,11 +1028,18 @@ static int latent_m_bwd_impl(const jamie_latent_m* a, const jamie_sample_args* s
         sa.idx = smp->idx; sa.B = smp->B; sa.N = smp->N; sa.offset = smp->offset; sa.replace = smp->replace;
         sa.rng_stream = smp->rng_stream; sa.step_add = smp->step_add;
     }
-    const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS + (sa.idx ? 1 : 0);
+    const int nblk = (a->B + LF_ROWS - 1) / LF_ROWS * d.bchunk_begin[LM] + (sa.idx ? 1 : 0);
     hipStream_t st = (hipStream_t)stream;
-    if (a->L <= 32) hipLaunchKernelGGL((latent_m_bwd_kernel<32>), dim3(n_rb), dim3(LF_NT), 0, st, d, sa, state);
-    else if (a->L <= 64) hipLaunchKernelGGL((latent_m_bwd_kernel<64>), dim3(n_rb), dim3(LF_NT), 0, st, d, sa, state);
-    else hipLaunchKernelGGL((latent_m_bwd_kernel<128>), dim3(n_rb), dim3(LF_NT), 0, st, d, sa, state);
+#define LATM_BWD(MM)                                                                                                               \
+    do {                                                                                                                           \
+        if (a->L <= 32) hipLaunchKernelGGL((latent_m_bwd_kernel<32, 256, MM>), dim3(nblk), dim3(LF_NT), 0, st, d, sa, state);       \
+        else if (a->L <= 64) hipLaunchKernelGGL((latent_m_bwd_kernel<64, 128, MM>), dim3(nblk), dim3(LF_NT), 0, st, d, sa, state);  \
+        else hipLaunchKernelGGL((latent_m_bwd_kernel<128, 64, MM>), dim3(nblk), dim3(LF_NT), 0, st, d, sa, state);                  \
+    } while (0)
+    if (a->M == 2) LATM_BWD(2);
+    else if (a->M == 3) LATM_BWD(3);
+    else LATM_BWD(4);
+#undef LATM_BWD
     return jamie_launch_status("jamie_latent_m_bwd");
 }
 

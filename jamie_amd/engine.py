@@ -566,8 +566,7 @@ class TrainEngine:
                 cfg = int(os.environ['JAMIE_F32_DX_CFG'])
             nv.gemm(probs, nv.NN, cfg)
 
-    def _dw_gemm(self, dy_key, a_key, lin):
-        """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer."""
+    def _dw_problems(self, dy_key, a_key, lin):
         probs = []
         for i, d in enumerate(self.dims):
             w = self.ws[i]
@@ -578,6 +577,17 @@ class TrainEngine:
             else:
                 probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate,
                                              store_nt=True))
+        return probs
+
+    def _dw_gemm(self, dy_key, a_key, lin, extra=None):
+        """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer.  `extra` = (dy_key, a_key, lin) of a
+        skinny layer whose dW rides in the same launch."""
+        probs = self._dw_problems(dy_key, a_key, lin)
+        if extra is not None:
+            if len(probs) + self.M <= nv.MAX_GEMM_GROUP and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(extra[2])):
+                probs += self._dw_problems(*extra)
+            else:
+                self._dw_gemm(*extra)
         if self.bf16:
             nv.gemm_bf16(probs, self._dw_cfg(lin))
         else:
@@ -622,13 +632,18 @@ class TrainEngine:
         off, t = self.dw_partial[f'm{i}.{lin}']
         return self.norm_partials[off:off + t]
 
-    def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key):
+    def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key, extra=None):
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
-        K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch."""
+        K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch.
+        `extra` = (dy_key, a_key, lin): the dW problems of a skinny layer ride in the same launch."""
         if not self.bf16 or 2 * self.M > nv.MAX_GROUP:
-            self._dw_gemm(dy_key, a_key, lin)
+            self._dw_gemm(dy_key, a_key, lin, extra)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
+        if extra is not None and not (3 * self.M <= nv.MAX_GEMM_GROUP and self._dw_cfg(extra[2]) == self.gcfg.get(sk_key, -1)
+                                      and self._dw_tr(extra[2])):
+            self._dw_gemm(*extra)
+            extra = None
         # the dX tiles run 2-3x as long as the dW tiles (K = features / slices vs K = batch): they go first in the
         # grid so that the short dW tiles fill in behind them (in-kernel stamps: the launch ends 4-5 us earlier)
         probs = []
@@ -643,6 +658,8 @@ class TrainEngine:
                                              nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         for i, d in enumerate(self.dims):
             probs.append(self._dw_problem(i, dy_key, a_key, lin))
+        if extra is not None:
+            probs += self._dw_problems(*extra)
         nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
@@ -666,6 +683,8 @@ class TrainEngine:
             d.dec0_W[i], d.dec0_b[i] = nv.ptr(self.m.p[f'm{i}.dec0.W']), nv.ptr(self.m.p[f'm{i}.dec0.b'])
             d.d[i] = self.dims[i]
             d.dbias_head[i] = nv.ptr(self.g[f'm{i}.head.b'])
+            if self._fuse_da2():
+                d.head_W[i], d.da2[i] = nv.ptr(self.m.p[f'm{i}.head.W']), nv.ptr(w['da2'])
             if self.bf16:
                 d.dml_bf16[i] = nv.ptr(w['dml_bf'])
                 d.dmlT_bf16[i] = nv.ptr(w['dml_T']) if 'dml' in self.need_T else None
@@ -680,6 +699,12 @@ class TrainEngine:
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses, d.rng_stream = nv.ptr(self.losses), 100
         return d
+
+    def _fuse_da2(self):
+        """The heads' input gradient d a2 = d(mu | logvar) W_head as extra workgroups of the fused latent backward launch
+        (exact fp32, K = 2L) instead of a GEMM launch; the heads' dW then rides in the next layer's launch."""
+        return (all(d % 4 == 0 for d in self.dims) and all(w['sk']['d_a2'] == 1 for w in self.ws)
+                and (not self.bf16 or self.skinny_tr) and os.environ.get('JAMIE_NO_FUSED_DA2') != '1')
 
     def _fused_latent(self, corr, Fblk):
         if self.M == 2 and os.environ.get('JAMIE_NO_FUSED_LATENT') == '1':      # A/B switch (tools/ab.sh): the general kernels
@@ -909,11 +934,17 @@ class TrainEngine:
         if not (isinstance(lat, nv.LatentM) and lat.colpart):                   # (fused kernels: bf16 dml + head-bias gradients done)
             self._cast('dml')
             nv.colsum_group([(self.ws[i]['dml'], self.g[f'm{i}.head.b']) for i in range(len(self.dims))], acc)
-        self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
-        self._region(allreduce, 'head')
+        head_dw = None
+        if isinstance(lat, nv.LatentM) and lat.da2[0]:      # d a2 came out of the latent launch: only the heads' dW is left,
+            head_dw = ('dml', 'a2', 'head')                 # and it rides in the next layer's launch
+        else:
+            self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
+            self._region(allreduce, 'head')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
         self._cast('da2')
-        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1')
+        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=head_dw)
+        if head_dw is not None:
+            self._region(allreduce, 'head')
         self._region(allreduce, 'enc1')
         self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
         self._cast('da1')

@@ -407,7 +407,8 @@ def test_latent_m_fused_kernels(nv, M, B, L, dims, nslab, bf, acc):
     with corr = I, model.py:190 decoder layer 0, jamie.py:618-668 losses) against a float64 autograd restatement:
     forward = mu / logvar / z / comb from the heads' split-K slabs, the decoder's first pre-activation g1 = comb W^T + b for
     every modality (ragged column chunks, ragged last row block) and the losses; backward = d(mu | logvar), d sigma and
-    the head-bias gradients (column sums; accumulated when asked), with the bf16 copies the bf16 GEMMs read."""
+    the head-bias gradients (column sums; accumulated when asked), with the bf16 copies the bf16 GEMMs read, and (feature counts
+    that are multiples of 4) the heads' input gradient d a2 = d(mu | logvar) W_head (model.py:141-143 backward)."""
     f32 = dict(device='cuda', dtype=torch.float32)
     g = torch.Generator().manual_seed(M * 1000 + B + L)
     ml = [torch.randn(nslab, B, 2 * L, generator=g) * .5 for _ in range(M)]
@@ -416,6 +417,8 @@ def test_latent_m_fused_kernels(nv, M, B, L, dims, nslab, bf, acc):
     sigma = torch.rand(M, generator=g) + .2
     W = [torch.randn(d, L, generator=g) / L ** .5 for d in dims]
     bd = [torch.randn(d, generator=g) * .1 for d in dims]
+    Wh = [torch.randn(2 * L, d, generator=g) / d ** .5 for d in dims]      # head weights [2L, d]
+    with_da2 = all(d % 4 == 0 for d in dims)
     ndc = 2
     dcomb = [torch.randn(ndc, B, L, generator=g) * 1e-3 for _ in range(M)]
     hyper = torch.zeros(16)
@@ -462,6 +465,9 @@ def test_latent_m_fused_kernels(nv, M, B, L, dims, nslab, bf, acc):
         d.g1[i], d.dec0_W[i], d.dec0_b[i], d.d[i] = nv.ptr(keep[f'g1{i}']), nv.ptr(keep[f'W{i}']), nv.ptr(keep[f'b{i}']), dims[i]
         d.dcomb[i], d.dml[i], d.dbias_head[i] = nv.ptr(keep[f'dcomb{i}']), nv.ptr(keep[f'dml{i}']), nv.ptr(keep[f'db{i}'])
         d.comb_alias[i] = nv.ptr(keep[f'alias{i}'])
+        if with_da2:       # fused tail of the backward launch: the heads' input gradient
+            keep[f'Wh{i}'], keep[f'da2{i}'] = dev(Wh[i]), torch.full((B, dims[i]), float('nan'), **f32)
+            d.head_W[i], d.da2[i] = nv.ptr(keep[f'Wh{i}']), nv.ptr(keep[f'da2{i}'])
         if bf:
             keep[f'cb{i}'] = torch.zeros(B, L, device='cuda', dtype=torch.bfloat16)
             keep[f'cT{i}'] = torch.zeros(L, B, device='cuda', dtype=torch.bfloat16)
@@ -485,6 +491,9 @@ def test_latent_m_fused_kernels(nv, M, B, L, dims, nslab, bf, acc):
         close(keep[f'g1{i}'], g1_ref[i], 1e-5, 5e-6, f'g1 {i}')
         scale = float(grads[i].abs().max())
         close(keep[f'dml{i}'], grads[i], 2e-4, 2e-6 * scale, f'dml{i}')
+        if with_da2:
+            want = grads[i] @ Wh[i].double()
+            close(keep[f'da2{i}'], want, 2e-4, 2e-6 * float(want.abs().max()), f'da2 {i}')
         want_db = grads[i].sum(0) + (prev_db[i].double() if acc else 0)
         close(keep[f'db{i}'], want_db, 2e-4, 1e-5 * float(want_db.abs().max()), f'head bias grad {i}')
         if bf:
@@ -526,6 +535,45 @@ def test_latent_rng_eps_is_standard_normal(nv):
     assert abs((e0 * e1).mean().item()) < 0.02                       # the two modalities use different streams
     assert abs((e0 ** 4).mean().item() - 3) < 0.2                     # kurtosis of a normal
     close(keep['z0'], e0 * (1 + 1e-7), 1e-6, 1e-6)
+
+
+def test_latent_m_rng_eps_is_standard_normal(nv):
+    """The fused kernel's own draws (one Philox call and one Box-Muller pair per element and pair of modalities): standard
+    normal, independent between the modalities of a pair and between pairs, a new draw every step, the same draw in every
+    workgroup of a row block (the decoder product of every column chunk must see the same comb), z = mu + eps std."""
+    M, B, L, dims = 3, 1024, 32, (520, 264, 136)
+    f32 = dict(device='cuda', dtype=torch.float32)
+    d = nv.LatentM()
+    d.B, d.L, d.M = B, L, M
+    keep = {'hyper': torch.ones(16, **f32), 'sigma': torch.ones(M, **f32), 'comb': torch.zeros(B, L, **f32),
+            'partials': torch.zeros(20 * nv.load().jamie_max_partials(), **f32)}
+    for i in range(M):
+        keep[f'ml{i}'], keep[f'hb{i}'] = torch.zeros(1, B, 2 * L, **f32), torch.zeros(2 * L, **f32)
+        keep[f'W{i}'], keep[f'b{i}'] = torch.randn(dims[i], L, **f32), torch.zeros(dims[i], **f32)
+        keep[f'g1{i}'] = torch.zeros(B, dims[i], **f32)
+        d.ml[i], d.head_bias[i], d.eps_in[i] = nv.ptr(keep[f'ml{i}']), nv.ptr(keep[f'hb{i}']), None
+        d.g1[i], d.dec0_W[i], d.dec0_b[i], d.d[i] = nv.ptr(keep[f'g1{i}']), nv.ptr(keep[f'W{i}']), nv.ptr(keep[f'b{i}']), dims[i]
+        for k in ('mu', 'lv', 'z', 'eps'):
+            keep[f'{k}{i}'] = torch.zeros(B, L, **f32)
+            getattr(d, k)[i] = nv.ptr(keep[f'{k}{i}'])
+    d.ml_nslab, d.ml_slab_stride, d.rng_stream = 1, B * 2 * L, 100
+    d.sigma, d.hyper, d.partials, d.comb = nv.ptr(keep['sigma']), nv.ptr(keep['hyper']), nv.ptr(keep['partials']), nv.ptr(keep['comb'])
+    state = torch.tensor([99, 5, 0, 0], dtype=torch.int64, device='cuda')
+    nv.latent_fwd(d, state)
+    e = [keep[f'eps{i}'].cpu().clone() for i in range(M)]
+    for i in range(M):
+        assert abs(e[i].mean().item()) < 0.02 and abs(e[i].std().item() - 1) < 0.02
+        assert abs((e[i] ** 4).mean().item() - 3) < 0.2                    # kurtosis of a normal
+        close(keep[f'z{i}'], e[i] * (1 + 1e-7), 1e-6, 1e-6)
+        for j in range(i):
+            assert abs((e[i] * e[j]).mean().item()) < 0.02                # no correlation within a pair or between pairs
+            assert abs((e[i] ** 2 * e[j] ** 2).mean().item() - 1) < 0.05     # ... nor between the magnitudes
+    comb = sum(e) / M
+    for i in range(M):     # every column chunk's workgroup drew the same eps: its product is comb W^T for the stored comb
+        close(keep[f'g1{i}'], comb.double() @ keep[f'W{i}'].cpu().double().t(), 1e-4, 2e-5, f'g1 {i}')
+    state[1] += 1
+    nv.latent_fwd(d, state)
+    assert abs((keep['eps0'].cpu() * e[0]).mean().item()) < 0.02           # a new draw every step
 
 
 # ------------------------------------------------------------------------------------------------

@@ -59,14 +59,3 @@ for variant in os.environ.get('VARIANTS', 'full,nodec,eps,nobf').split(','):
     for cold in (False, True):
         print(f'{variant:6s} cold={int(cold)}  fwd {timeit(lambda: nv.latent_fwd(d, state), cold=cold):7.1f} us   '
               f'bwd+final {timeit(lambda: nv.latent_bwd(d), cold=cold):7.1f} us', flush=True)
-
-if os.environ.get('STAMPS'):
-    d = desc('full')
-    MAXP = nv.load().jamie_max_partials()
-    for rep in range(3):
-        nv.latent_fwd(d, state); nv.latent_bwd(d); torch.cuda.synchronize()
-        st = keep['full']['partials'][19 * MAXP:19 * MAXP + 16].cpu().tolist()
-        f = [round((st[k] - st[0]) / 100, 2) for k in (4, 1, 2, 3)]
-        b = [round((st[k] - st[8]) / 100, 2) for k in (9, 10, 11, 12, 13, 14)]
-        print('fwd us since entry: slabs loaded, phase A done, partials done, FMA done:', f)
-        print('bwd us since block-0 entry: math+stores done(last blk), ticket+acquire, loads issued, loads landed+cols, sums, end:', b)

@@ -4,4 +4,4 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 JAMIE_HIPCC_FLAGS="-DJAMIE_LAT_STAMP" python -c "import jamie_amd.build as b; b.build_library(force=False)" 
-STAMPS=1 VARIANTS=full python tools/bench_latent_m.py
+python tools/stamp_latent.py
