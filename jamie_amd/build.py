@@ -26,17 +26,22 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else -1.0
 
 
-def build_variant(tag, flags, verbose=False):
+def build_variant(tag, flags, verbose=False, only=None):
     """An A/B build of the same sources with extra hipcc flags (e.g. -DJAMIE_OLD_REDUCE): `libjamie_hip_<tag>.so` next to
-    the product library, selected at run time with JAMIE_LIB=<path> (tools/ab.sh)."""
+    the product library, selected at run time with JAMIE_LIB=<path> (tools/ab.sh).  `only`: the source files (base names) the
+    flags concern; the other objects are the product build's."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     odir = os.path.join(CSRC, '_obj_' + tag)
     os.makedirs(odir, exist_ok=True)
     srcs = sources()
-    objs = [os.path.join(odir, os.path.basename(s)[:-4] + '.o') for s in srcs]
+    if only is not None:
+        build_library()
+    objs = [os.path.join(odir if (only is None or os.path.basename(s) in only) else OBJ, os.path.basename(s)[:-4] + '.o')
+            for s in srcs]
 
     def cc(so):
-        subprocess.run([hipcc] + FLAGS + list(flags) + ['-c', so[0], '-o', so[1]], check=True)
+        if only is None or os.path.basename(so[0]) in only:
+            subprocess.run([hipcc] + FLAGS + list(flags) + ['-c', so[0], '-o', so[1]], check=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(cc, zip(srcs, objs)))
     out = os.path.join(_HERE, f'libjamie_hip_{tag}.so')

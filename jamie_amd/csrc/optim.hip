@@ -311,6 +311,19 @@ extern "C" int jamie_grad_sqnorm(const float* g, long long n, float* partials, i
     return jamie_launch_status("jamie_grad_sqnorm");
 }
 
+// launch shape of clip + Adam (tools/sweep_adam.sh builds the alternatives): float4 per thread and array in flight, threads per
+// workgroup, streaming workgroups
+#ifndef JAMIE_ADAM_U
+#define JAMIE_ADAM_U 1
+#endif
+#ifndef JAMIE_ADAM_T
+#define JAMIE_ADAM_T 512
+#endif
+#ifndef JAMIE_ADAM_GRID
+#define JAMIE_ADAM_GRID 256
+#endif
+static constexpr int ADAM_U = JAMIE_ADAM_U, ADAM_T = JAMIE_ADAM_T, ADAM_GRID = JAMIE_ADAM_GRID;
+
 static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m, float* v, long long n, const float* partials,
                           int n_partials, const float* hyper, const uint64_t* state, void* p_bf16, const jamie_sample_args* smp,
                           const jamie_cast_problem* casts, int n_casts, void* stream) {
@@ -319,8 +332,8 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
                   ((uintptr_t)v % 16) == 0 && ((uintptr_t)g_bf16 % 8) == 0, "buffers must be 16-byte aligned (bf16 gradient: 8)");
     JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
     JAMIE_ARG(p_bf16 == nullptr || ((uintptr_t)p_bf16 % 8) == 0, "p_bf16 must be 8-byte aligned");
-    long long need = (n / 4 + 511) / 512;
-    const int grid = (int)(need < 1 ? 1 : (need > 256 ? 256 : need));
+    long long need = (n / 4 + ADAM_T - 1) / ADAM_T;
+    const int grid = (int)(need < 1 ? 1 : (need > ADAM_GRID ? ADAM_GRID : need));
     // one workgroup per CU (fewer, longer streams keep more DRAM pages open: 2048 workgroups x 1 float4 4.8 TB/s), eight
     // waves each with one float4 per array in flight: 5.8 TB/s where four waves x two float4 reached 5.0-5.2 on the slower
     // boxes of the pool and 5.7 on the faster ones (tools/bench_adam.py; in the step 231 -> 209 us on a slow box)
@@ -336,16 +349,16 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
         JAMIE_ARG(smp->N + smp->offset <= 0x7fffffffLL, "sampler: indices must fit int32");
         sa.idx = smp->idx; sa.B = smp->B; sa.N = smp->N; sa.offset = smp->offset; sa.replace = smp->replace;
         sa.rng_stream = smp->rng_stream; sa.step_add = smp->step_add;
-        hipLaunchKernelGGL((clip_adam_kernel<1, 512, true>), dim3(grid + 1), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
+        hipLaunchKernelGGL((clip_adam_kernel<ADAM_U, ADAM_T, true>), dim3(grid + 1), dim3(ADAM_T), 0, (hipStream_t)stream, p, g, m, v, n,
                            partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, sa, cg, grid);
     } else if (has_cast) {
         int blocks = 0;
         const int rc = jamie_cast_fill_group(casts, n_casts, &cg, &blocks);
         if (rc) return rc;
-        hipLaunchKernelGGL((clip_adam_kernel<1, 512, true>), dim3(grid + blocks), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
+        hipLaunchKernelGGL((clip_adam_kernel<ADAM_U, ADAM_T, true>), dim3(grid + blocks), dim3(ADAM_T), 0, (hipStream_t)stream, p, g, m, v, n,
                            partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, sa, cg, grid);
     } else {
-        hipLaunchKernelGGL((clip_adam_kernel<1, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, g, m, v, n,
+        hipLaunchKernelGGL((clip_adam_kernel<ADAM_U, ADAM_T, false>), dim3(grid), dim3(ADAM_T), 0, (hipStream_t)stream, p, g, m, v, n,
                            partials, n_partials, hyper, state, (unsigned short*)p_bf16, (const unsigned short*)g_bf16, sa, cg, grid);
     }
     return jamie_launch_status("jamie_clip_adam");
