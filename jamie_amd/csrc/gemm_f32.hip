@@ -370,6 +370,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
                     if (P.accumulate) v += *cp;
                     if (P.store_nt) __builtin_nontemporal_store(v, cp);     // weight gradients: see gemm_bf16.hip
                     else *cp = v;
+                    local += v * v;                                         // (used when `partial` is given: the clip norm)
                 } else if (P.epi == JAMIE_EPI_MSE) {
                     const float d = v - P.aux0[(long long)m * P.aux_ld + n];
                     local += d * d;
@@ -384,6 +385,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+    // weight gradients: the tile's sum of squares (fixed order) for the global-norm clip, as in the bf16 kernel -- the
+    // separate pass over the 161 MB gradient buffer (27 us) is then only a pass over the ranges no GEMM writes
+    if (P.epi == JAMIE_EPI_STORE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot;
     }
 #ifdef JAMIE_GEMMB_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -593,6 +600,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
                     if (P.accumulate) v += *cp;
                     if (P.store_nt) __builtin_nontemporal_store(v, cp);     // weight gradients: see gemm_bf16.hip
                     else *cp = v;
+                    local += v * v;                                         // (used when `partial` is given: the clip norm)
                 } else if (P.epi == JAMIE_EPI_MSE) {
                     const float d = v - P.aux0[(long long)m * P.aux_ld + n];
                     local += d * d;
@@ -607,6 +615,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
     if (P.epi == JAMIE_EPI_MSE && P.partial != nullptr) {
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
+    }
+    // weight gradients: the tile's sum of squares (fixed order) for the global-norm clip, as in the bf16 kernel -- the
+    // separate pass over the 161 MB gradient buffer (27 us) is then only a pass over the ranges no GEMM writes
+    if (P.epi == JAMIE_EPI_STORE && P.partial != nullptr) {
+        const float tot = block_sum(local, red);
+        if (tid == 0) P.partial[t] = tot;
     }
 #ifdef JAMIE_GEMMB_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -761,6 +775,7 @@ extern "C" int jamie_gemm_f32_cfg(const jamie_gemm_problem* pr, int count, int l
         if (layout == JAMIE_TN) JAMIE_ARG(s.lda >= s.M && s.ldb >= s.N, "TN: lda < M or ldb < N");
         JAMIE_ARG(s.epi >= JAMIE_EPI_STORE && s.epi <= JAMIE_EPI_BN_EVAL, "epilogue id");
         JAMIE_ARG(s.epi == JAMIE_EPI_STORE || s.splitk <= 1, "fused epilogues need splitk == 1");
+        JAMIE_ARG(s.epi != JAMIE_EPI_STORE || !s.partial || s.splitk <= 1, "a sum-of-squares partial needs splitk == 1");
         JAMIE_ARG(s.splitk <= 1 || !s.accumulate, "split-K slabs cannot accumulate");
         JAMIE_ARG(s.epi != JAMIE_EPI_MSE || (s.aux0 && s.aux_ld >= s.N), "MSE epilogue needs aux0 = X");
         JAMIE_ARG(s.epi != JAMIE_EPI_BN_EVAL || (s.aux0 && s.aux1 && s.aux2 && s.aux3), "BN_EVAL needs aux0..3");

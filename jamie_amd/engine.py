@@ -83,6 +83,7 @@ def plan_bf16_bwd(B, shapes):
 
 F32_CFG_ROWS = 12           # 128x128x32 tile on 16 waves of 32x32 (gemm_f32.hip; 8 waves of 64x32, cfg 4, is 5-7 % slower)
 F32_CFG_DW = 1              # fp32 dW (TN, K = batch): 64x64x32 tile (sweep: tools/sweep_f32_dw.sh)
+F32_CFG_DW_FUSED = 12       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
 
 
 def plan_f32_rows(B, shapes, target=2 * N_CU):
@@ -194,9 +195,11 @@ class TrainEngine:
         # split too and its MSE / gradient come from jamie_mse_cast (a fused epilogue needs an unsplit K: 126 us)
         self.fcfg = {}
         if not self.bf16:
-            for key, shp in (('enc0', [(2 * d, d) for d in self.dims]), ('enc1', [(d, 2 * d) for d in self.dims]),
+            dx_nn = [] if os.environ.get('JAMIE_NO_F32_DX_PLAN') == '1' else \
+                [('d_e2', [(2 * d, d) for d in self.dims]), ('d_a1', [(2 * d, d) for d in self.dims])]
+            for key, shp in [('enc0', [(2 * d, d) for d in self.dims]), ('enc1', [(d, 2 * d) for d in self.dims]),
                              ('dec1', [(2 * d, d) for d in self.dims]), ('dec2', [(d, 2 * d) for d in self.dims]),
-                             ('d_e1', [(d, 2 * d) for d in self.dims])):
+                             ('d_e1', [(d, 2 * d) for d in self.dims])] + dx_nn:
                 cfg, sks = plan_f32_rows(B, shp)
                 if cfg >= 0:
                     self.fcfg[key] = cfg
@@ -250,6 +253,7 @@ class TrainEngine:
                     w[k + '_T'] = torch.empty(nf, B, **bf)
             self.ws.append(w)
         # dec2 (MSE epilogue) uses the 64x128 tile config unless N <= 64
+        self.wT = {}
         if self.bf16:
             # bf16 copies of the weights: same flat layout, plus K-contiguous transposes for the dX products
             self.wbf_flat = torch.zeros(model.layout.total, device=self.dev, dtype=torch.bfloat16)
@@ -270,8 +274,13 @@ class TrainEngine:
         self.fused_norm, self._fuse_now, self._norm_ready = False, False, False
         self._lat_deferred, self._ranges_done = None, False
         big = {'dec2': 'd_e2', 'dec1': 'd_e1', 'enc1': 'd_a1', 'enc0': 'dw'}
-        if self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values()):
-            bm_d, bn_d = BF16_TILE[self.gcfg['dw']]
+        # (fp32 mode: the TN dW launches of the large layers take the 128 x 128 tile then -- the same speed as the 64 x 64 one
+        #  inside the step, profiles/r02_f32_dw_tile_sweep.log, and a quarter of the partial sums)
+        f32_fused = (not self.bf16 and world_size == 1 and B >= 256 and os.environ.get('JAMIE_NO_F32_FUSED_NORM') != '1'
+                     and all(min(model.p[f'm{i}.{lin}.W'].shape) >= 512 for lin in big for i in range(self.M)))
+        self._f32_dw_fused = f32_fused
+        if f32_fused or (self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values())):
+            bm_d, bn_d = nv.gemm_tile(nv.TN, 1 << 20, 1 << 20, B, F32_CFG_DW_FUSED) if f32_fused else BF16_TILE[self.gcfg['dw']]
             self.dw_partial, off, covered = {}, 0, []
             for lin in big:
                 for i in range(self.M):
@@ -315,7 +324,8 @@ class TrainEngine:
         # 2 instead of 4 bytes of gradient per parameter (26 instead of 28 bytes per parameter in all; the dW launches
         # store 80 instead of 161 MB per step).  The norm partials are sums of squares of the fp32 values.  Not with
         # accumulating gradients (batch_step=False): set_grad_bf16(False) before the first backward pass of such a run.
-        self.grad_bf16 = bool(grad_bf16) and self.fused_norm
+        self._f32_dw_fused = self._f32_dw_fused and self.fused_norm
+        self.grad_bf16 = bool(grad_bf16) and self.fused_norm and self.bf16
         self._g16_now = self._g16_last = self._g16_pending = False
         if self.grad_bf16:
             self.grad16 = torch.zeros(n, device=self.dev, dtype=torch.bfloat16)
@@ -576,7 +586,7 @@ class TrainEngine:
                 probs.append(self._dw_problem(i, dy_key, a_key, lin))
             else:
                 probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate,
-                                             store_nt=True))
+                                             store_nt=True, partial=self._dw_partial(i, lin)))
         return probs
 
     def _dw_gemm(self, dy_key, a_key, lin, extra=None):
@@ -597,6 +607,8 @@ class TrainEngine:
         """fp32 dW launch (TN, K = batch): tile configuration (-1: the library's 64 x 64 default)."""
         env = os.environ.get('JAMIE_F32_DW_CFG')
         big = self.B >= 256 and all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 512 for i in range(self.M))
+        if big and self._f32_dw_fused:
+            return F32_CFG_DW_FUSED           # (the partial sums are laid out for this tile)
         return (int(env) if env else F32_CFG_DW) if big else -1
 
     def _dw_cfg(self, lin):
@@ -742,7 +754,9 @@ class TrainEngine:
 
     # ---- the step ----
     def _batch_problems(self, data, idx):
-        """cast_transpose problems of the batch: row gather + fp32 / bf16 (/ transposed) copies."""
+        """cast_transpose problems of the batch: row gather + fp32 / bf16 (/ transposed) copies (fp32 mode: the gather only)."""
+        if not self.bf16:
+            return [nv.cast_problem(data[i], None, None, rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)]
         return [nv.cast_problem(data[i], self.ws[i]['x_bf'], self.ws[i]['x_T'] if 'x' in self.need_T else None,
                                 rows=idx[i], dst32=self.ws[i]['x']) for i in range(self.M)]
 
@@ -1088,7 +1102,8 @@ class TrainEngine:
             # ... and where the latent backward launch can carry the sampler (fused M-modality kernels, identity
             # correspondence, no weight transposes waiting for Adam's output) the next batch's GATHER rides in clip + Adam
             # too: the batch buffers are free once the last dW product has run, and the step is then fwd + bwd + norm + Adam
-            early = (fused and self.bf16 and not self.wT and not replace and self._fused_latent(corr, None)
+            early = (fused and not self.wT and not replace and self._fused_latent(corr, None)
+                     and all(x.shape[1] % 4 == 0 and x.dtype == torch.float32 for x in data)
                      and os.environ.get('JAMIE_NO_GATHER_RIDE') != '1')
             if fused:
                 nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
