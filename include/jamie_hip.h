@@ -294,6 +294,12 @@ int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* 
                                  int count, float* partials, int n_partials, uint64_t* state,
                                  const jamie_latent_m* fin /*host*/, const jamie_colsum_problem* colsums /*host or NULL*/,
                                  int n_colsums, void* stream);
+/* jamie_gemm_bf16 (tile configuration 29: the dW launches) + jamie_grad_sqnorm_ranges_fin (without column sums) in ONE launch:
+ * the range chunks and the finaliser run as extra workgroups behind the GEMM tiles.  For the LAST dW launch of a backward pass:
+ * every gradient the ranges cover must be complete before the launch.  `fin` may be NULL (n_partials = range blocks). */
+int jamie_gemm_bf16_ranges(const jamie_gemm_problem* problems /*host*/, int count, int cfg, const float* g, void* g_bf16,
+                           const long long* offsets /*host*/, const long long* lengths /*host*/, int n_ranges, float* partials,
+                           int n_partials, uint64_t* state, const jamie_latent_m* fin /*host or NULL*/, void* stream);
 int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,

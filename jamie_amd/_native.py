@@ -126,6 +126,8 @@ EXPORTS = {
     'jamie_gemm_f32_cfg': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'jamie_gemm_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'jamie_gemm_bf16': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
+    'jamie_gemm_bf16_ranges': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
     'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'jamie_cast_transpose': (C.c_int, [C.POINTER(CastProblem), C.c_int, C.c_void_p]),
     'jamie_mse_cast': (C.c_int, [C.POINTER(MseProblem), C.c_int, C.c_void_p]),
@@ -334,8 +336,15 @@ def gemm_tile(layout, max_m, max_n, max_k, cfg=-1):
     return bm.value, bn.value
 
 
-def gemm_bf16(problems, cfg=-1):
+def gemm_bf16(problems, cfg=-1, ranges=None):
+    """`ranges` = (g, g16 or None, SqRanges, partials, state, fin or None): the range-norm work (grad_sqnorm_ranges) rides as
+    extra workgroups of this launch (tile configuration 29: the last dW launch of a backward pass)."""
     arr = (GemmProblem * len(problems))(*problems)
+    if ranges is not None:
+        g, g16, rg, partials, state, fin = ranges
+        _call('jamie_gemm_bf16_ranges', arr, len(problems), cfg, ptr(g), ptr(g16), rg.off, rg.len, rg.count, ptr(partials),
+              partials.numel(), ptr(state), C.pointer(fin) if fin is not None else None, _stream())
+        return
     _call('jamie_gemm_bf16', arr, len(problems), cfg, _stream())
 
 

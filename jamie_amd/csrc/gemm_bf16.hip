@@ -13,6 +13,7 @@
 // are padded to BK*2 + 16 bytes (16 * odd): conflict-free ds_read_b128.  Staging, double buffering, fragment
 // prefetch, grouped launch, XCD mapping, split-K slabs and epilogues are those of gemm_f32.hip.
 #include "common.h"
+#include "range_norm.h"
 #include <type_traits>
 
 // diagnostic ablations (timing only, wrong results): 1 = no global loads in the k-loop, 2 = no MFMAs,
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
 // TRM = 0: no problem of the launch has a k-row-major operand (forward launches): the a_tr / b_tr paths are compiled out,
 // TRM = 1: per-problem flags (backward launches: dX reads W as stored, dW reads dy and a as stored)
 template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup g) {
+__device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g) {
     constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_SZ = BM * 128, B_SZ = BN * 128, T_SZ = A_SZ + B_SZ;
@@ -836,6 +837,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup
 #endif
 }
 
+template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup g) {
+    gemm_bf16_dma2_body<BM, BN, WM, WN, TAG, NB, TRM>(g);
+}
+
+// The same launch with RIDERS: the workgroups after the `n_tiles` GEMM tiles take the gradient ranges no GEMM writes (their sums
+// of squares for the clip norm) and the deferred finalisation of the latent backward pass (range_norm.h).  Used for the LAST dW
+// launch of a backward pass, when every other gradient exists: the range-norm launch (10 us between the last GEMM and the
+// optimiser) disappears into it.
+template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_ride_kernel(GemmBGroup g, RangeRide rr, int n_tiles) {
+    if ((int)blockIdx.x >= n_tiles) {
+        __shared__ float ride_red[(WM * WN + 1) * (SM_SLOTS + 2)];
+        range_ride_block(rr, (int)blockIdx.x - n_tiles, ride_red);
+        return;
+    }
+    gemm_bf16_dma2_body<BM, BN, WM, WN, TAG, NB, TRM>(g);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int D>
 static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     GemmBGroup g;
@@ -874,7 +894,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN, int NB, int ILV = 0, int V2 = 0>
-static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
+static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, const RangeRide* rr = nullptr, int ride_blocks = 0) {
     constexpr int BK = 64;
     GemmBGroup g;
     memset(&g, 0, sizeof(g));
@@ -921,6 +941,16 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         }
         bool trm = false;
         for (int i = 0; i < count; ++i) trm = trm || pr[i].a_tr || pr[i].b_tr;
+        if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 4 && NB == 2) {
+            if (rr) {       // (jamie_gemm_bf16_ranges: configuration 29 only)
+                if (big)
+                    hipLaunchKernelGGL((gemm_bf16_dma2_ride_kernel<BM, BN, WM, WN, 1, NB, 1>), dim3(tiles + ride_blocks), dim3(WM * WN * 64), 0, st, g, *rr, tiles);
+                else
+                    hipLaunchKernelGGL((gemm_bf16_dma2_ride_kernel<BM, BN, WM, WN, 0, NB, 1>), dim3(tiles + ride_blocks), dim3(WM * WN * 64), 0, st, g, *rr, tiles);
+                return jamie_launch_status("jamie_gemm_bf16_ranges");
+            }
+        }
+        if (rr) return jamie_fail(-1, "%s: riders need tile configuration 29 [%lld %lld]", "jamie_gemm_bf16_ranges", BM, BN);
         if constexpr (BN == 128) {
             if (trm) {
                 if (big)
@@ -936,6 +966,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st) {
             hipLaunchKernelGGL((gemm_bf16_dma2_kernel<BM, BN, WM, WN, 0, NB, 0>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
         return jamie_launch_status("jamie_gemm_bf16");
     }
+    if (rr) return jamie_fail(-1, "%s: riders need tile configuration 29 [%lld %lld]", "jamie_gemm_bf16_ranges", BM, BN);
     if (big)
         hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN, 1, NB, ILV>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     else
@@ -954,7 +985,7 @@ static const int BT[33][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}
 // (forward / dX: 36 vs 40 us cold), 2 buffers (cfg 10) when K is the batch (dW, K = 512: 8 k-steps only)
 static int pick_cfg_b(int max_m, int max_n, int min_k) { (void)max_m; (void)max_n; return min_k >= 1000 ? 7 : 10; }
 
-extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg, void* stream) {
+static int gemm_bf16_impl(const jamie_gemm_problem* pr, int count, int cfg, void* stream, const RangeRide* rr, int ride_blocks) {
     JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GEMM_GROUP, "1 <= count <= JAMIE_MAX_GEMM_GROUP");
     int max_m = 0, max_n = 0, min_k = 1 << 30;
     for (int i = 0; i < count; ++i) {
@@ -981,6 +1012,7 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
     }
     hipStream_t st = (hipStream_t)stream;
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, min_k);
+    if (rr && cfg != 29) return jamie_fail(-1, "%s: riders need tile configuration 29 [%lld %lld]", "jamie_gemm_bf16_ranges", cfg, 0);
     switch (cfg) {
         case 0: return launch_b<128, 128, 64, 2, 2, 2>(pr, count, st);
         case 1: return launch_b<64, 64, 64, 2, 2, 3>(pr, count, st);
@@ -1011,12 +1043,26 @@ extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg,
         case 26: return launch_dma<128, 256, 2, 4, 3, 0, 1>(pr, count, st);
         case 27: return launch_dma<64, 64, 2, 2, 3, 0, 1>(pr, count, st);
         case 28: return launch_dma<256, 256, 4, 4, 2, 0, 1>(pr, count, st);
-        case 29: return launch_dma<128, 128, 2, 4, 2, 0, 1>(pr, count, st);      // 8 waves of 64x32, 2 buffers
+        case 29: return launch_dma<128, 128, 2, 4, 2, 0, 1>(pr, count, st, rr, ride_blocks);      // 8 waves of 64x32, 2 buffers
         case 30: return launch_dma<128, 128, 4, 2, 2, 0, 1>(pr, count, st);      // 8 waves of 32x64, 2 buffers
         case 31: return launch_dma<256, 128, 4, 4, 3, 0, 1>(pr, count, st);      // 16 waves of 64x32, 3 buffers
         case 32: return launch_dma<128, 128, 2, 4, 3, 0, 1>(pr, count, st);      // 8 waves of 64x32, 3 buffers
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
+}
+
+extern "C" int jamie_gemm_bf16(const jamie_gemm_problem* pr, int count, int cfg, void* stream) {
+    return gemm_bf16_impl(pr, count, cfg, stream, nullptr, 0);
+}
+
+extern "C" int jamie_gemm_bf16_ranges(const jamie_gemm_problem* pr, int count, int cfg, const float* g, void* g_bf16,
+                                      const long long* offsets, const long long* lengths, int n_ranges, float* partials,
+                                      int n_partials, uint64_t* state, const jamie_latent_m* fin, void* stream) {
+    RangeRide rr;
+    int blocks = 0;
+    const int rc = jamie_range_ride_fill(g, g_bf16, offsets, lengths, n_ranges, partials, n_partials, state, fin, &rr, &blocks);
+    if (rc) return rc;
+    return gemm_bf16_impl(pr, count, cfg, stream, &rr, blocks);
 }
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {

@@ -12,6 +12,7 @@
 #include "latent_final.h"
 #include "colsum.h"
 #include "cast_tile.h"
+#include "range_norm.h"
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n,
                                                           float* partials, uint64_t* state) {
@@ -164,11 +165,7 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
     }
 }
 
-// Sum of squares over a list of ranges of the gradient buffer (the parameters whose producers do not emit partial sums
-// themselves: biases, BatchNorm affine parameters, sigma, the skinny head / latent matrices), one chunk of <= 4096
-// elements per workgroup; also advances the step counter, as jamie_grad_sqnorm does.
-#define JAMIE_SQ_CHUNK 4096
-struct SqRanges { long long off[128]; int len[128]; };
+// jamie_grad_sqnorm_ranges*: the range chunks and the finaliser of range_norm.h as a launch of their own (+ column-sum riders)
 template <bool FIN>
 __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __restrict__ g, unsigned short* __restrict__ g16,
                                                                  SqRanges r, float* partials, uint64_t* state, LatFinal fin,
@@ -195,27 +192,44 @@ __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __
         }
     }
     __shared__ float red[4];
-    const float* p = g + r.off[blockIdx.x];
-    unsigned short* q = g16 ? g16 + r.off[blockIdx.x] : nullptr;          // bf16 copy of the range (same offsets)
-    const int n = r.len[blockIdx.x], n4 = n >> 2;
-    float acc = 0.f;
-    auto bf = [](float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); };
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            const float4 v = reinterpret_cast<const float4*>(p)[i];
-            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            if (q) *reinterpret_cast<uint2*>(q + 4 * i) = make_uint2((unsigned)bf(v.x) | ((unsigned)bf(v.y) << 16),
-                                                                      (unsigned)bf(v.z) | ((unsigned)bf(v.w) << 16));
+    sqnorm_range_chunk(g, g16, r, (int)blockIdx.x, partials, state, red);
+}
+
+static int fill_ranges(const long long* offsets, const long long* lengths, int count, bool g16, SqRanges* r, int* nb_out) {
+    int nb = 0;
+    for (int i = 0; i < count; ++i) {
+        JAMIE_ARG(offsets[i] >= 0 && lengths[i] >= 0, "negative range");
+        JAMIE_ARG(!g16 || offsets[i] % 4 == 0, "bf16 copies need range offsets that are multiples of 4");
+        for (long long o = 0; o < lengths[i]; o += JAMIE_SQ_CHUNK) {
+            JAMIE_ARG(nb < 128, "more than 128 chunks of 4096 elements");
+            r->off[nb] = offsets[i] + o;
+            r->len[nb] = (int)(lengths[i] - o < JAMIE_SQ_CHUNK ? lengths[i] - o : JAMIE_SQ_CHUNK);
+            ++nb;
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) { acc += p[i] * p[i]; if (q) q[i] = bf(p[i]); }
-    } else {
-        for (int i = threadIdx.x; i < n; i += 256) { acc += p[i] * p[i]; if (q) q[i] = bf(p[i]); }
     }
-    const float t = block_sum(acc, red);
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x] = t;
-        if (blockIdx.x == 0 && state) state[1] += 1;
+    *nb_out = nb;
+    return 0;
+}
+
+int jamie_range_ride_fill(const float* g, void* g16, const long long* offsets, const long long* lengths, int count, float* partials,
+                          int n_partials, uint64_t* state, const jamie_latent_m* fin, RangeRide* rr, int* blocks) {
+    JAMIE_ARG(g && offsets && lengths && partials && count >= 1 && rr && blocks, "null pointer / empty");
+    memset(rr, 0, sizeof(*rr));
+    int nb = 0;
+    const int rc = fill_ranges(offsets, lengths, count, g16 != nullptr, &rr->r, &nb);
+    if (rc) return rc;
+    JAMIE_ARG(nb >= 1 && n_partials == nb + (fin ? 1 : 0), "n_partials must equal jamie_sqnorm_range_blocks() (+ 1 with a finaliser)");
+    JAMIE_ARG(n_partials <= JAMIE_MAX_PARTIALS, "too many partial sums");
+    rr->g = g; rr->g16 = (unsigned short*)g16; rr->partials = partials; rr->state = state; rr->n_range_blocks = nb;
+    if (fin) {
+        JAMIE_ARG(fin->defer_final && !fin->accumulate && fin->partials && fin->hyper && fin->losses && fin->dsigma,
+                  "finaliser: a deferred, non-accumulating jamie_latent_m");
+        JAMIE_ARG(fin->M * 2 * fin->L <= 256 * 64, "finaliser: too many head-bias columns");
+        jamie_latent_m_fill_final(fin, &rr->fin);
+        rr->has_fin = 1;
     }
+    *blocks = nb + (fin ? 1 : 0);
+    return 0;
 }
 
 static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offsets, const long long* lengths, int count,
@@ -224,16 +238,8 @@ static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offset
     JAMIE_ARG(g && offsets && lengths && partials && count >= 1, "null pointer / empty");
     SqRanges r;
     int nb = 0;
-    for (int i = 0; i < count; ++i) {
-        JAMIE_ARG(offsets[i] >= 0 && lengths[i] >= 0, "negative range");
-        JAMIE_ARG(!g16 || offsets[i] % 4 == 0, "bf16 copies need range offsets that are multiples of 4");
-        for (long long o = 0; o < lengths[i]; o += JAMIE_SQ_CHUNK) {
-            JAMIE_ARG(nb < 128, "more than 128 chunks of 4096 elements");
-            r.off[nb] = offsets[i] + o;
-            r.len[nb] = (int)(lengths[i] - o < JAMIE_SQ_CHUNK ? lengths[i] - o : JAMIE_SQ_CHUNK);
-            ++nb;
-        }
-    }
+    const int frc = fill_ranges(offsets, lengths, count, g16 != nullptr, &r, &nb);
+    if (frc) return frc;
     ColsumGroup cs;
     memset(&cs, 0, sizeof(cs));
     int cs_blocks = 0;

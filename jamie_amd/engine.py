@@ -589,9 +589,9 @@ class TrainEngine:
                                              store_nt=True, partial=self._dw_partial(i, lin)))
         return probs
 
-    def _dw_gemm(self, dy_key, a_key, lin, extra=None):
+    def _dw_gemm(self, dy_key, a_key, lin, extra=None, ranges=None):
         """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer.  `extra` = (dy_key, a_key, lin) of a
-        skinny layer whose dW rides in the same launch."""
+        skinny layer whose dW rides in the same launch; `ranges` (bf16 large-tile launch only): the range-norm work rides too."""
         probs = self._dw_problems(dy_key, a_key, lin)
         if extra is not None:
             if len(probs) + self.M <= nv.MAX_GEMM_GROUP and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(extra[2])):
@@ -599,7 +599,7 @@ class TrainEngine:
             else:
                 self._dw_gemm(*extra)
         if self.bf16:
-            nv.gemm_bf16(probs, self._dw_cfg(lin))
+            nv.gemm_bf16(probs, self._dw_cfg(lin), ranges)
         else:
             nv.gemm(probs, nv.TN, self._f32_dw_cfg(lin))
 
@@ -964,26 +964,33 @@ class TrainEngine:
         self._cast('da1')
         # (the range-norm launch on a second stream beside this last dW product: +11 us per step for the two cross-stream
         #  events, profiles/r02_ab_range_norm_side_stream_rejected.log)
-        self._dw_gemm('da1', 'x', 'enc0')
+        # ... but as EXTRA workgroups of that last dW launch the range norm (and the latent finalisation) costs nothing: every
+        # other gradient exists by now
+        ride = (self._fuse_now and self.bf16 and self._dw_cfg('enc0') == BF16_CFG_DW and os.environ.get('JAMIE_NO_RANGE_RIDE') != '1')
+        self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else None)
+        self._ranges_done = ride
         self._region(allreduce, 'enc0')
         self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
 
-    def _range_norm(self, launch=True):
-        """Sum of squares of the gradient ranges no dW launch covers (+ the deferred latent finalisation in an extra
-        workgroup); returns the live slice of `norm_partials` the optimiser sums."""
+    def _range_args(self):
+        """(live slice of `norm_partials` the optimiser sums, arguments of the range-norm work): the sums of squares of the
+        gradient ranges no dW launch covers, + the deferred latent finalisation in an extra workgroup."""
+        g16 = self.grad16 if self._g16_now else None
         if self._lat_deferred is not None:
             n_live = self.n_dw_partials + self.sq_ranges_nofin.blocks + 1
             norm = self.norm_partials[:n_live]
-            if launch:
-                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges_nofin, norm[self.n_dw_partials:], self.state,
-                                      self.grad16 if self._g16_now else None, self._lat_deferred)
-        else:
-            n_live = self.n_dw_partials + self.sq_ranges.blocks
-            norm = self.norm_partials[:n_live]
-            if launch:
-                nv.grad_sqnorm_ranges(self.grad, self.sq_ranges, norm[self.n_dw_partials:], self.state,
-                                      self.grad16 if self._g16_now else None)
+            return norm, (self.grad, g16, self.sq_ranges_nofin, norm[self.n_dw_partials:], self.state, self._lat_deferred)
+        n_live = self.n_dw_partials + self.sq_ranges.blocks
+        norm = self.norm_partials[:n_live]
+        return norm, (self.grad, g16, self.sq_ranges, norm[self.n_dw_partials:], self.state, None)
+
+    def _range_norm(self, launch=True):
+        """The range-norm launch (unless the last dW launch of the backward pass carried it: `launch` False); returns the live
+        slice of `norm_partials`."""
+        norm, (g, g16, ranges, part, state, fin) = self._range_args()
+        if launch:
+            nv.grad_sqnorm_ranges(g, ranges, part, state, g16, fin)
         return norm
 
     def optimizer_step(self, g16=None, after_norm=None, sample=None, casts=None):

@@ -1037,9 +1037,8 @@ def test_fused_gradient_norm_equals_the_norm_of_the_gradient(jam, grad_bf16):
         eng.set_batch([torch.randn(B, d, generator=g).cuda() for d in dims])
         eng.accumulate = step == 2                      # step 2 adds its gradient to step 1's buffer
         fall_back = step == 3
-        eng.forward_backward()
-        if fall_back:
-            eng._norm_ready = False                     # what a reduced (multi-GPU) gradient does
+        # (a backward pass that is to be followed by a gradient exchange emits no partial sums: one pass after the reduction)
+        eng.forward_backward(allreduce=(lambda flat: None) if fall_back else None)
         want = float(eng.grad_flat().double().norm())
         eng.optimizer_step()
         n_live = eng.n_norm if fall_back else eng.n_dw_partials + eng.sq_ranges.blocks
