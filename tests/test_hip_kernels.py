@@ -672,6 +672,127 @@ def test_sampler_without_replacement(nv):
 
 
 # ------------------------------------------------------------------------------------------------
+# riders: a small launch's work as extra workgroups of a launch that is there anyway
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('what', ['sampler', 'gather'])
+def test_clip_adam_riders_equal_their_own_launches(nv, what):
+    """jamie_clip_adam_ride: clip + Adam with the next batch's sampler (np.random.choice, jamie.py:556) or its row gather
+    + bf16 casts (jamie.py:583) as extra workgroups == the stand-alone launches, bit for bit: parameters, moments, indices
+    or gathered rows."""
+    n, N, B, d = 3_000_017, 50000, 512, 264
+    g = torch.Generator().manual_seed(5)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-3
+    hyper = torch.zeros(16)
+    hyper[8:14] = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1.0, 1.0])
+    hd = dev(hyper)
+    data = dev(torch.randn(N, d, generator=g))
+    rows = dev(torch.randint(0, N, (B,), generator=g, dtype=torch.int32))
+    out = {}
+    for ride in (False, True):
+        pd, gd = dev(p0), dev(gr)
+        md, vd = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+        pb = torch.zeros(n, device='cuda', dtype=torch.bfloat16)
+        state = torch.tensor([11, 3, 0, 0], dtype=torch.int64, device='cuda')
+        part = torch.zeros(nv.optim_blocks(n), device='cuda')
+        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+        x32 = torch.zeros(B, d, device='cuda')
+        xbf, xT = torch.zeros(B, d, device='cuda', dtype=torch.bfloat16), torch.zeros(d, B, device='cuda', dtype=torch.bfloat16)
+        cast = [nv.cast_problem(data, xbf, xT, rows=rows, dst32=x32)]
+        nv.grad_sqnorm(gd, part, state)                     # state[1]: 3 -> 4
+        if not ride:
+            nv.clip_adam(pd, gd, md, vd, part, hd, state, pb)
+            if what == 'sampler':
+                nv.sample_indices(idx, N, 7, False, state, 200)
+            else:
+                nv.cast_transpose(cast)
+        elif what == 'sampler':
+            nv.clip_adam(pd, gd, md, vd, part, hd, state, pb, sample=nv.sample_args(idx, N, 7, False, 200))
+        else:
+            nv.clip_adam(pd, gd, md, vd, part, hd, state, pb, casts=cast)
+        out[ride] = [t.cpu() for t in (pd, md, vd, pb.float(), idx, x32, xbf.float(), xT.float())]
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+    if what == 'sampler':
+        v = out[True][4].numpy()
+        assert len(set(v.tolist())) == B and v.min() >= 7 and v.max() < N + 7
+    else:
+        assert torch.equal(out[True][5], data.cpu()[rows.cpu().long()])
+
+
+def test_latent_backward_sampler_rider_draws_the_next_steps_batch(nv):
+    """jamie_latent_m_bwd_ex: the extra workgroup draws what jamie_sample_indices draws one step later (step_add = 1: the
+    norm kernel has not advanced the counter yet), and the backward launch's own results do not change."""
+    M, B, L, N = 2, 512, 32, 100000
+    f32 = dict(device='cuda', dtype=torch.float32)
+    res = {}
+    for ride in (False, True):
+        g = torch.Generator().manual_seed(12)
+        d = nv.LatentM()
+        d.B, d.L, d.M = B, L, M
+        keep = {'sigma': torch.ones(M, **f32), 'hyper': torch.ones(16, **f32), 'comb': dev(torch.randn(B, L, generator=g)),
+                'partials': torch.zeros(20 * nv.load().jamie_max_partials(), **f32), 'losses': torch.zeros(8, **f32),
+                'dsigma': torch.zeros(M, **f32), 'colpart': torch.zeros(int(nv.load().jamie_latent_m_colpart_size(B, L)), **f32),
+                'ticket': torch.zeros(4, dtype=torch.int32, device='cuda'), 'rec': torch.zeros(1, **f32)}
+        for i in range(M):
+            for k in ('mu', 'lv', 'z', 'eps'):
+                keep[f'{k}{i}'] = dev(torch.randn(B, L, generator=g) * .3)
+                getattr(d, k)[i] = nv.ptr(keep[f'{k}{i}'])
+            keep[f'dcomb{i}'], keep[f'dml{i}'] = dev(torch.randn(1, B, L, generator=g) * 1e-3), torch.zeros(B, 2 * L, **f32)
+            keep[f'db{i}'] = torch.zeros(2 * L, **f32)
+            d.dcomb[i], d.dml[i], d.dbias_head[i] = nv.ptr(keep[f'dcomb{i}']), nv.ptr(keep[f'dml{i}']), nv.ptr(keep[f'db{i}'])
+        d.sigma, d.hyper, d.partials, d.comb = nv.ptr(keep['sigma']), nv.ptr(keep['hyper']), nv.ptr(keep['partials']), nv.ptr(keep['comb'])
+        d.dcomb_nslab, d.dcomb_slab_stride, d.dsigma, d.losses = 1, B * L, nv.ptr(keep['dsigma']), nv.ptr(keep['losses'])
+        d.rec_partials, d.n_rec_partials = nv.ptr(keep['rec']), 1
+        d.colpart, d.ticket = nv.ptr(keep['colpart']), nv.ptr(keep['ticket'])
+        state = torch.tensor([99, 41, 0, 0], dtype=torch.int64, device='cuda')
+        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+        if ride:
+            nv.latent_bwd(d, nv.sample_args(idx, N, 0, False, 200, step_add=1), state)
+        else:
+            nv.latent_bwd(d)
+            state[1] += 1
+            nv.sample_indices(idx, N, 0, False, state, 200)
+        res[ride] = [keep[k].cpu() for k in ('dml0', 'dml1', 'db0', 'db1', 'dsigma', 'losses')] + [idx.cpu()]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    assert len(set(res[True][-1].tolist())) == B
+
+
+def test_gemm_bf16_range_norm_rider(nv):
+    """jamie_gemm_bf16_ranges: the dW products of a launch (a_tr + b_tr, tile configuration 29) are bit-identical with and
+    without riders, the riders' partial sums are the sums of squares of the ranges, block 0 advances the step counter."""
+    B, nout, nin = 512, 520, 264
+    g = torch.Generator().manual_seed(21)
+    dy = dev(torch.randn(B, nout, generator=g)).to(torch.bfloat16)
+    a = dev(torch.randn(B, nin, generator=g)).to(torch.bfloat16)
+    flat = dev(torch.randn(nout * nin + 10000, generator=g))
+    ranges = nv.SqRanges([(nout * nin, 4100), (nout * nin + 4100 + 4, 3), (nout * nin + 5000, 4096)])
+    assert ranges.blocks == 4
+    outs = {}
+    for ride in (False, True):
+        dW = torch.zeros(nout, nin, device='cuda')
+        tiles = ((nout + 127) // 128) * ((nin + 127) // 128)
+        part_dw = torch.zeros(tiles, device='cuda')
+        part = torch.full((ranges.blocks,), float('nan'), device='cuda')
+        state = torch.tensor([1, 8, 0, 0], dtype=torch.int64, device='cuda')
+        prob = [nv.gemm_problem(dy, a, dW, nout, nin, B, nout, nin, nin, partial=part_dw, a_tr=True, b_tr=True, store_nt=True)]
+        if ride:
+            nv.gemm_bf16(prob, 29, (flat, None, ranges, part, state, None))
+        else:
+            nv.gemm_bf16(prob, 29)
+            nv.grad_sqnorm_ranges(flat, ranges, part, state)
+        outs[ride] = (dW.cpu(), part_dw.cpu(), part.cpu(), int(state[1].item()))
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    assert outs[True][3] == 9 and outs[False][3] == 9
+    f = flat.cpu().double()
+    want = torch.stack([(f[o:o + n] ** 2).sum() for o, n in ((nout * nin, 4096), (nout * nin + 4096, 4), (nout * nin + 4104, 3),
+                                                              (nout * nin + 5000, 4096))])
+    close(outs[True][2], want, 1e-5, 1e-6, 'rider partial sums')
+    close(outs[False][2], want, 1e-5, 1e-6, 'stand-alone partial sums')
+    close(outs[True][0], dy.float().cpu().double().t() @ a.float().cpu().double(), 1e-3, 1e-2, 'dW')
+
+
+# ------------------------------------------------------------------------------------------------
 # bf16 compute mode
 # ------------------------------------------------------------------------------------------------
 def _bf16(t):
