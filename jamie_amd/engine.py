@@ -31,9 +31,10 @@ def choose_splitk(M, N, K, bm=64, bn=64):
     if tiles >= 384:
         return 1
     s = max(1, math.ceil(512 / tiles))
-    # (skinny heads / latent products: slices of >= 160; at config 2 six slabs instead of three took 3-5 us off the step,
-    #  profiles/r02_ab_skinny_slabs.log: the launch is a latency chain of k-steps, not bandwidth)
-    return int(max(1, min(s, K // (512 if N > 64 else 160))))
+    # (skinny heads / latent products: slices of >= 125, at most 8 -- what the fused latent kernels sum in ONE round trip; at
+    #  config 2 six slabs instead of three took 3-5 us off the step and eight another 5, profiles/r02_ab_skinny_slabs.log:
+    #  the launch is a latency chain of k-steps, not bandwidth)
+    return int(max(1, min(s, K // 512) if N > 64 else min(s, 8, K // 125)))
 
 
 # ---- bf16 GEMM launch plans (tile configuration + per-problem split-K), from tools/bench_gemm_bf16.py ----
