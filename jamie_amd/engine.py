@@ -591,14 +591,14 @@ class TrainEngine:
         return probs
 
     def _dw_gemm(self, dy_key, a_key, lin, extra=None, ranges=None):
-        """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer.  `extra` = (dy_key, a_key, lin) of a
-        skinny layer whose dW rides in the same launch; `ranges` (bf16 large-tile launch only): the range-norm work rides too."""
+        """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer.  `extra` = [(dy_key, a_key, lin)] of
+        skinny layers whose dW rides in the same launch; `ranges` (bf16 large-tile launch only): the range-norm work rides too."""
         probs = self._dw_problems(dy_key, a_key, lin)
-        if extra is not None:
-            if len(probs) + self.M <= nv.MAX_GEMM_GROUP and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(extra[2])):
-                probs += self._dw_problems(*extra)
+        for ex in (extra or []):
+            if len(probs) + self.M <= nv.MAX_GEMM_GROUP and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(ex[2])):
+                probs += self._dw_problems(*ex)
             else:
-                self._dw_gemm(*extra)
+                self._dw_gemm(*ex)
         if self.bf16:
             nv.gemm_bf16(probs, self._dw_cfg(lin), ranges)
         else:
@@ -648,15 +648,18 @@ class TrainEngine:
     def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key, extra=None):
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
         K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch.
-        `extra` = (dy_key, a_key, lin): the dW problems of a skinny layer ride in the same launch."""
+        `extra` = [(dy_key, a_key, lin)]: the dW problems of skinny layers ride in the same launch."""
         if not self.bf16 or 2 * self.M > nv.MAX_GROUP:
             self._dw_gemm(dy_key, a_key, lin, extra)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
-        if extra is not None and not (3 * self.M <= nv.MAX_GEMM_GROUP and self._dw_cfg(extra[2]) == self.gcfg.get(sk_key, -1)
-                                      and self._dw_tr(extra[2])):
-            self._dw_gemm(*extra)
-            extra = None
+        riding, n_prob = [], 2 * self.M
+        for ex in (extra or []):
+            if n_prob + self.M <= nv.MAX_GEMM_GROUP and self._dw_cfg(ex[2]) == self.gcfg.get(sk_key, -1) and self._dw_tr(ex[2]):
+                riding.append(ex)
+                n_prob += self.M
+            else:
+                self._dw_gemm(*ex)
         # the dX tiles run 2-3x as long as the dW tiles (K = features / slices vs K = batch): they go first in the
         # grid so that the short dW tiles fill in behind them (in-kernel stamps: the launch ends 4-5 us earlier)
         probs = []
@@ -671,8 +674,8 @@ class TrainEngine:
                                              nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
         for i, d in enumerate(self.dims):
             probs.append(self._dw_problem(i, dy_key, a_key, lin))
-        if extra is not None:
-            probs += self._dw_problems(*extra)
+        for ex in riding:
+            probs += self._dw_problems(*ex)
         nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
 
     def _latent_desc_m(self, corr, Fblk, noise):
@@ -938,8 +941,17 @@ class TrainEngine:
         self._region(allreduce, 'dec1')
         self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
         self._cast('de1')
-        self._bwd_gemms('de1', 'dec0', 'comb', 'dcomb', 'd_comb')
-        self._region(allreduce, 'dec0')
+        # the heads' input gradient comes out of the latent backward launch (fused kernels); the dW products of the two skinny
+        # layers (decoder layer 0, heads: K = batch, the longest tiles of their launches) then ride in the next big layer's
+        # launch, and what is left here is the short d comb product alone
+        late_dw = []
+        fused_tail = isinstance(lat, nv.LatentM) and bool(lat.da2[0])
+        if fused_tail and os.environ.get('JAMIE_NO_LATE_DEC0_DW') != '1':
+            self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
+            late_dw.append(('de1', 'comb', 'dec0'))
+        else:
+            self._bwd_gemms('de1', 'dec0', 'comb', 'dcomb', 'd_comb')
+            self._region(allreduce, 'dec0')
         if sample is not None:                 # + the NEXT batch's sampler as an extra workgroup (make_plan)
             nv.latent_bwd(lat, sample, self.state)
         else:
@@ -949,17 +961,16 @@ class TrainEngine:
         if not (isinstance(lat, nv.LatentM) and lat.colpart):                   # (fused kernels: bf16 dml + head-bias gradients done)
             self._cast('dml')
             nv.colsum_group([(self.ws[i]['dml'], self.g[f'm{i}.head.b']) for i in range(len(self.dims))], acc)
-        head_dw = None
         if isinstance(lat, nv.LatentM) and lat.da2[0]:      # d a2 came out of the latent launch: only the heads' dW is left,
-            head_dw = ('dml', 'a2', 'head')                 # and it rides in the next layer's launch
+            late_dw.append(('dml', 'a2', 'head'))           # and it rides in the next layer's launch
         else:
             self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
             self._region(allreduce, 'head')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
         self._cast('da2')
-        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=head_dw)
-        if head_dw is not None:
-            self._region(allreduce, 'head')
+        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=late_dw)
+        for ex in late_dw:
+            self._region(allreduce, ex[2])
         self._region(allreduce, 'enc1')
         self._bn_bwd('bn0', 'da1', 'h1', 'enc0', 10, noise, 'enc_masks', 0)   # da1[0] <- dh1p
         self._cast('da1')
