@@ -173,7 +173,7 @@ class TrainEngine:
         # bf16: tile configuration of every large launch + per-modality slab counts (plan_bf16_*)
         self.gcfg, plan_sk = {}, {}
         if self.bf16:
-            grouped = 2 * self.M <= nv.MAX_GROUP
+            grouped = 2 * self.M <= nv.MAX_GEMM_GROUP
             for key, shp, bwd in (('enc0', [(2 * d, d) for d in self.dims], False),
                                   ('enc1', [(d, 2 * d) for d in self.dims], False),
                                   ('dec1', [(2 * d, d) for d in self.dims], False),
@@ -186,7 +186,7 @@ class TrainEngine:
             # the skinny head / latent backward launches go through the 128 x 128 k-row-major kernel as well: the same speed as
             # the 64 x 64 kernel on transposed copies (profiles/r02_ab_skinny_tr.log), and with no transposed weight copy left
             # the next batch's gather can ride in the optimiser launch (make_plan)
-            self.skinny_tr = bool(skinny_tr) and self.gcfg['dw'] == BF16_CFG_DW and L % 8 == 0 and 2 * self.M <= nv.MAX_GROUP
+            self.skinny_tr = bool(skinny_tr) and self.gcfg['dw'] == BF16_CFG_DW and L % 8 == 0 and 2 * self.M <= nv.MAX_GEMM_GROUP
             if self.skinny_tr:
                 self.gcfg['d_comb'] = self.gcfg['d_a2'] = BF16_CFG_DW
         # dW = dy^T a: the 128 x 128 large-tile kernel reads dy [B, out] and a [B, in] as the layers wrote them (a_tr + b_tr),
@@ -649,17 +649,19 @@ class TrainEngine:
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
         K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch.
         `extra` = [(dy_key, a_key, lin)]: the dW problems of skinny layers ride in the same launch."""
-        if not self.bf16 or 2 * self.M > nv.MAX_GROUP:
+        if not self.bf16 or 2 * self.M > nv.MAX_GEMM_GROUP:
             self._dw_gemm(dy_key, a_key, lin, extra)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
-        riding, n_prob = [], 2 * self.M
+        riding, left, n_prob = [], [], 2 * self.M
         for ex in (extra or []):
             if n_prob + self.M <= nv.MAX_GEMM_GROUP and self._dw_cfg(ex[2]) == self.gcfg.get(sk_key, -1) and self._dw_tr(ex[2]):
                 riding.append(ex)
                 n_prob += self.M
             else:
-                self._dw_gemm(*ex)
+                left.append(ex)
+        if left:                      # (more than two modalities: the skinny layers' dW share a launch of their own)
+            self._dw_gemm(*left[0], extra=left[1:])
         # the dX tiles run 2-3x as long as the dW tiles (K = features / slices vs K = batch): they go first in the
         # grid so that the short dW tiles fill in behind them (in-kernel stamps: the launch ends 4-5 us earlier)
         probs = []
