@@ -659,7 +659,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int g0 = 0; g0 < LMAX; g0 += 16) {     // 8 MFMAs per group: the 16 operand reads go out together, ahead of them
-            if (g0 >= L) break;                     // (uniform)
+            if (g0 >= L) continue;                  // (uniform)
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int g0 = 0; g0 < 2 * LMAX; g0 += 16) {     // 8 MFMAs per group: the 16 operand reads go out together, ahead of them
-            if (g0 >= K2) break;                        // (uniform)
+            if (g0 >= K2) continue;                     // (uniform)
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
