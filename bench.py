@@ -157,7 +157,7 @@ def cpu_baseline(dims, L, B, budget_s=24.0):
     return out
 
 
-def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=30, warmup=6):
+def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20):
     """The parity configuration (exact-fp32 MFMA) on the same workload: cells/s, ms/step and the roofline of ITS dominant
     kernel, the forward d <-> 2d Linear GEMM launch (north_star: >= 60 % of the binding roofline on the encoder matmul)."""
     from jamie_amd.engine import TrainEngine
