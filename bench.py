@@ -236,6 +236,9 @@ def main():
     ap.add_argument('--grad-comm', default='auto', choices=['auto', 'f32', 'bf16'],
                     help='dtype of the gradient all-reduce messages (auto: the compute dtype; tests/test_host_cpu.py::test_bf16_message_sum_keeps_the_clip_norm)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dry-run-world', type=int, default=0,
+                    help='one GPU: run the per-rank step of an N-rank job with the collectives skipped (message casts, side stream, '
+                         'one-pass norm of the "reduced" gradient): the compute-side cost of data parallelism; NOT a benchmark line')
     ap.add_argument('--no-f32-record', action='store_true', help='skip the short fp32 (parity configuration) leg')
     ap.add_argument('--pipeline', action='store_true',
                     help='clip + Adam on a second stream under the next forward pass (+2-3 %; default: main stream, so '
@@ -280,11 +283,11 @@ def main():
     model = edModelVar(dims, L, device=dev, pad_features=pad)
     if world > 1:
         jd.broadcast_flat(model.flat)
-    eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype,
+    eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=max(world, args.dry_run_world), compute_dtype=args.dtype,
                       dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr)
     data = eng.pad_cells(data_real)
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
-    allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm) if world > 1 else None
+    allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm, dry_run_world=args.dry_run_world) if (world > 1 or args.dry_run_world > 1) else None
     idx = torch.zeros(B, dtype=torch.int32, device=dev)      # 'diag' sampling: same rows in both modalities
     # the reference's quirk `replace = min(features) < batch_size` (jamie.py:553) belongs to its two-modality loop; the
     # 3-modality generalisation always samples without replacement (duplicates would need a non-identity corr)
@@ -407,6 +410,9 @@ def main():
             'kernel_event_timing_ms': timing_detail,
             'final_loss': total,
         }
+        if args.dry_run_world > 1:
+            out['dry_run_world'] = args.dry_run_world
+            out['metric'] += f' [DRY RUN: per-rank compute path of a {args.dry_run_world}-rank step, collectives skipped; not a benchmark line]'
         if world > 1:
             out['rccl'] = rccl_record(world, log_dir) if log_dir else {'backend': torch.distributed.get_backend(),
                                                                         'world': torch.distributed.get_world_size(), 'algo': None}

@@ -76,10 +76,16 @@ class OverlappedGradAllReduce:
     (the last region is only ready when the backward pass ends); bf16 halves it, at the precision the bf16 GEMMs
     produced the gradient with.  Every rank receives the same reduced values, so the replicas stay identical."""
 
-    def __init__(self, group=None, min_bytes=32 << 20, comm_dtype=None):
+    def __init__(self, group=None, min_bytes=32 << 20, comm_dtype=None, dry_run_world=0):
+        """`dry_run_world` = N > 1 (one process, no process group): everything the N-rank step does on the device EXCEPT the
+        collectives themselves -- region bookkeeping, message casts, side stream and events -- so that the per-rank compute
+        path of the data-parallel step can be timed on a one-GPU box (bench.py --dry-run-world)."""
         self.group = group
         self.min_bytes = min_bytes
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.dry = int(dry_run_world) > 1 and self.world == 1
+        if self.dry:
+            self.world = int(dry_run_world)
         self.comm_dtype = None if comm_dtype in (None, torch.float32) else comm_dtype
         self.comm = None             # persistent low-precision exchange buffer (same offsets as the flat gradient)
         self.works = []
@@ -103,8 +109,8 @@ class OverlappedGradAllReduce:
 
     def _issue(self, flat, lo, hi):
         if self.comm_dtype is None:
-            self.works.append((dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True),
-                               None, None, None))
+            self.works.append((None if self.dry else dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                                     async_op=True), None, None, None))
             return
         if self.comm is None or self.comm.numel() != flat.numel() or self.comm.device != flat.device:
             self.comm = torch.zeros(flat.numel(), dtype=self.comm_dtype, device=flat.device)
@@ -124,10 +130,10 @@ class OverlappedGradAllReduce:
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 cast.run(self.stream)                     # fp32 region -> bf16 message buffer (HIP launch, no ATen op)
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             buf.copy_(flat[lo:hi])
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.works.append((work, flat, lo, hi))
 
     def finish(self, copy_back=True):
@@ -138,7 +144,10 @@ class OverlappedGradAllReduce:
             self._issue(*self.pending)
             self.pending = None
         for w, flat, lo, hi in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
+            elif self.stream is not None:       # (dry run: what work.wait() does for a device collective)
+                torch.cuda.current_stream().wait_stream(self.stream)
             if flat is not None and copy_back:
                 flat[lo:hi].copy_(self.comm[lo:hi])
         self.works = []
