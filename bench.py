@@ -236,6 +236,8 @@ def main():
     ap.add_argument('--grad-comm', default='auto', choices=['auto', 'f32', 'bf16'],
                     help='dtype of the gradient all-reduce messages (auto: the compute dtype; tests/test_host_cpu.py::test_bf16_message_sum_keeps_the_clip_norm)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--grad-fp32', action='store_true', help='A/B (bf16 mode, one GPU): fp32 weight gradients (TrainEngine(grad_bf16=False)); default: the large dW launches '
+                    'store their results as bf16, as the weight gradient of a torch.autocast(bfloat16) Linear is')
     ap.add_argument('--dry-run-world', type=int, default=0,
                     help='one GPU: run the per-rank step of an N-rank job with the collectives skipped (message casts, side stream, '
                          'one-pass norm of the "reduced" gradient): the compute-side cost of data parallelism; NOT a benchmark line')
@@ -284,7 +286,7 @@ def main():
     if world > 1:
         jd.broadcast_flat(model.flat)
     eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=max(world, args.dry_run_world), compute_dtype=args.dtype,
-                      dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr)
+                      dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr, grad_bf16=False if args.grad_fp32 else None)
     data = eng.pad_cells(data_real)
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
     allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm, dry_run_world=args.dry_run_world) if (world > 1 or args.dry_run_world > 1) else None

@@ -93,9 +93,19 @@ class OverlappedGradAllReduce:
         self.pending = None          # (flat, lo, hi) not yet issued
         self._casts = {}             # (lo, hi) -> prepared fp32 -> bf16 cast launch of that region (jamie_cast_transpose)
 
-    def region_done(self, flat, lo, hi):
+    def message_buffer(self, flat):
+        """The persistent low-precision exchange buffer (same offsets as the flat gradient): a producer that writes its
+        gradients into it directly (the bf16 dW epilogues, TrainEngine) announces its regions with `precast=True`."""
+        if self.comm is None or self.comm.numel() != flat.numel() or self.comm.device != flat.device:
+            self.comm = torch.zeros(flat.numel(), dtype=self.comm_dtype, device=flat.device)
+        return self.comm
+
+    def region_done(self, flat, lo, hi, precast=False):
+        """`precast`: the region's gradients are already in `message_buffer()` (every region of a step alike): no cast pass,
+        no side stream -- the collective is issued where it stands (RCCL orders it behind the launches before it)."""
         if self.world == 1:
             return
+        self._precast = bool(precast)
         if self.pending is not None and self.pending[2] == lo:       # forward-adjacent
             lo = self.pending[1]
         elif self.pending is not None and self.pending[1] == hi:     # backward-adjacent (the usual case)
@@ -108,13 +118,16 @@ class OverlappedGradAllReduce:
             self.pending = None
 
     def _issue(self, flat, lo, hi):
+        if self.comm_dtype is not None and getattr(self, '_precast', False):
+            buf = self.message_buffer(flat)[lo:hi]
+            self.works.append((None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                               None, None, None))
+            return
         if self.comm_dtype is None:
             self.works.append((None if self.dry else dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                                      async_op=True), None, None, None))
             return
-        if self.comm is None or self.comm.numel() != flat.numel() or self.comm.device != flat.device:
-            self.comm = torch.zeros(flat.numel(), dtype=self.comm_dtype, device=flat.device)
-        buf = self.comm[lo:hi]
+        buf = self.message_buffer(flat)[lo:hi]
         if flat.is_cuda:
             # the cast into the message buffer (a pass over the region: 45 us per step at config 2) and the collective
             # go to a side stream behind an event, so the backward kernels that follow on the main stream do not queue

@@ -111,7 +111,7 @@ def kl_anneal(epoch, min_epochs, epoch_DNN):
 
 class TrainEngine:
     def __init__(self, model, batch_size, lr=1e-3, loss_weights=None, dist_method='euclidean', seed=666,
-                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=True, grad_bf16=False):
+                 world_size=1, compute_dtype='f32', dx_from_weights=True, skinny_tr=True, grad_bf16=None):
         """compute_dtype 'f32': exact-fp32 MFMA GEMMs (the parity configuration).  'bf16': bf16 MFMA GEMMs with
         fp32 accumulation, fp32 master weights / optimiser / BatchNorm / losses (BASELINE config 2); needs every
         feature count, the latent size and the batch size to be multiples of 8."""
@@ -302,7 +302,7 @@ class TrainEngine:
             # the same without d sigma and the head-bias gradients: a step with the fused latent kernels defers their
             # finalisation to the range-norm launch's extra workgroup, which also adds their squares (optimizer_step)
             cut = [model.layout.entries['sigma']] + [model.layout.entries[f'm{i}.head.b'] for i in range(self.M)]
-            cut = sorted((o, o + int(np.prod(shp))) for o, shp in cut)
+            cut = sorted((o, o + (int(np.prod(shp)) + 3) // 4 * 4) for o, shp in cut)     # (whole 4-aligned slots: the padding is zero)
             rest2 = []
             for lo, ln in rest:
                 hi = lo + ln
@@ -326,8 +326,13 @@ class TrainEngine:
         # store 80 instead of 161 MB per step).  The norm partials are sums of squares of the fp32 values.  Not with
         # accumulating gradients (batch_step=False): set_grad_bf16(False) before the first backward pass of such a run.
         self._f32_dw_fused = self._f32_dw_fused and self.fused_norm
-        self.grad_bf16 = bool(grad_bf16) and self.fused_norm and self.bf16
+        # Default ON in bf16 compute mode: this is what torch.autocast(bfloat16) does to the same step -- the weight gradient of an
+        # autocast Linear is the OUTPUT of a bf16 matmul (rounded to bf16) before it is accumulated into the fp32 .grad -- and
+        # it takes 23 us off the step (profiles/r02_ab_grad_bf16.log: clip + Adam reads 2 bytes less per parameter, the dW
+        # launches store half).  grad_bf16=False keeps fp32 weight gradients.
+        self.grad_bf16 = (True if grad_bf16 is None else bool(grad_bf16)) and self.fused_norm and self.bf16
         self._g16_now = self._g16_last = self._g16_pending = False
+        self._direct_now, self._direct = False, None       # (data parallel, bf16 messages: see _direct_setup)
         if self.grad_bf16:
             self.grad16 = torch.zeros(n, device=self.dev, dtype=torch.bfloat16)
             self.g16 = model.layout.views(self.grad16)
@@ -630,6 +635,9 @@ class TrainEngine:
         dW = self.g[f'm{i}.{lin}.W']
         nout, nin = dW.shape
         if self._dw_tr(lin):      # dy [B, out], a [B, in] row-major as produced: no transposed copies
+            if self._direct_now:      # data parallel, bf16 messages: straight into the exchange buffer (no fp32 copy, no cast pass)
+                return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], self._direct['views'][f'm{i}.{lin}.W'], nout, nin,
+                                       self.B, nout, nin, nin, a_tr=True, b_tr=True, store_nt=True, c_bf16=True)
             g16 = self._g16_now and f'm{i}.{lin}' in self.dw_partial
             return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], self.g16[f'm{i}.{lin}.W'] if g16 else dW, nout, nin,
                                    self.B, nout, nin, nin, accumulate=self.accumulate, partial=self._dw_partial(i, lin),
@@ -645,12 +653,12 @@ class TrainEngine:
         off, t = self.dw_partial[f'm{i}.{lin}']
         return self.norm_partials[off:off + t]
 
-    def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key, extra=None):
+    def _bwd_gemms(self, dy_key, lin, a_key, out_key, sk_key, extra=None, ranges=None):
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
         K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch.
         `extra` = [(dy_key, a_key, lin)]: the dW problems of skinny layers ride in the same launch."""
         if not self.bf16 or 2 * self.M > nv.MAX_GEMM_GROUP:
-            self._dw_gemm(dy_key, a_key, lin, extra)
+            self._dw_gemm(dy_key, a_key, lin, extra, ranges)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
         riding, left, n_prob = [], [], 2 * self.M
@@ -678,7 +686,7 @@ class TrainEngine:
             probs.append(self._dw_problem(i, dy_key, a_key, lin))
         for ex in riding:
             probs += self._dw_problems(*ex)
-        nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
+        nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1), ranges)
 
     def _latent_desc_m(self, corr, Fblk, noise):
         """Identity correspondence, F = 0, euclidean alignment (every BASELINE config; any 2 <= M <= 4): the fused latent
@@ -782,7 +790,10 @@ class TrainEngine:
         """Tell an overlapping all-reduce that the gradients of parameter region `name` have been launched."""
         if ar is not None and hasattr(ar, 'region_done'):
             lo, hi = self.m.layout.regions[name]
-            fn = lambda: ar.region_done(self.grad, lo, hi)   # noqa: E731
+            if self._direct_now:
+                fn = lambda: ar.region_done(self.grad, lo, hi, precast=True)   # noqa: E731
+            else:
+                fn = lambda: ar.region_done(self.grad, lo, hi)   # noqa: E731
             nv.record_callable(fn)
             fn()
 
@@ -799,7 +810,7 @@ class TrainEngine:
     def grad_view(self, name):
         """The gradient of parameter tensor `name` (fp32, without padding) as the last backward pass left it: the large
         weight matrices live in the bf16 buffer when that pass wrote them there."""
-        if self._g16_last and name.endswith('.W') and name[:-2] in self.dw_partial:
+        if self._g16_last and name.endswith('.W') and (self._direct_now or name[:-2] in self.dw_partial):
             return self.m.layout.unpad(name, self.g16[name].float())
         return self.m.layout.unpad(name, self.g[name])
 
@@ -807,7 +818,8 @@ class TrainEngine:
         """The whole flat gradient of the last backward pass as one fp32 tensor (tests / diagnostics)."""
         out = self.grad.clone()
         if self._g16_last:
-            for key in self.dw_partial:
+            keys = [k[:-2] for k in self.m.layout.entries if k.endswith('.W')] if self._direct_now else self.dw_partial
+            for key in keys:
                 o, shp = self.m.layout.entries[key + '.W']
                 n = shp[0] * shp[1]
                 out[o:o + n] = self.grad16[o:o + n].float()
@@ -914,9 +926,48 @@ class TrainEngine:
         self._cast('dxhat')
         return lat
 
+    def _direct_setup(self, allreduce):
+        """Data parallel with bf16 messages: every producer writes its gradients into the exchange's bf16 buffer itself -- the
+        dW epilogues store bf16 there (c_bf16; no fp32 copy of the weight gradients), the few KB of bias / BatchNorm / sigma
+        gradients of a region are copied by riders of that region's GEMM launch (range_norm.h with the message buffer as the
+        bf16 copy; no step-counter increment) -- so the fp32 -> bf16 cast pass over the 161 MB gradient (a second stream beside
+        the backward GEMMs, two events per region) does not exist.  Returns None where the path does not apply."""
+        ok = (allreduce is not None and hasattr(allreduce, 'message_buffer') and getattr(allreduce, 'comm_dtype', None) == torch.bfloat16
+              and getattr(allreduce, 'world', 1) > 1 and self.bf16 and self.grad.is_cuda and not self.accumulate
+              and self.gcfg.get('dw', -1) == BF16_CFG_DW and self.skinny_tr and 3 * self.M <= nv.MAX_GEMM_GROUP
+              and all(self.gcfg.get(k, -1) == BF16_CFG_DW for k in ('d_e2', 'd_e1', 'd_a1'))
+              and self._fused_latent(None, None) and self._fuse_da2() and os.environ.get('JAMIE_NO_DIRECT_COMM') != '1')
+        if not ok:
+            return None
+        comm = allreduce.message_buffer(self.grad)
+        if self._direct is None or self._direct['comm'] is not comm:
+            lay = self.m.layout
+            small = {}
+            for name, (lo, hi) in lay.regions.items():
+                big = sorted((o, o + int(np.prod(shp))) for k, (o, shp) in lay.entries.items()
+                             if k.endswith('.W') and lo <= o < hi)
+                rest, pos = [], lo
+                for a, b in big:
+                    if a > pos:
+                        rest.append((pos, a - pos))
+                    pos = b
+                if hi > pos:
+                    rest.append((pos, hi - pos))
+                small[name] = rest
+            groups = {'dec2': ['dec2'], 'dec1': ['dec1'], 'enc1': ['dec0', 'head', 'enc1'], 'enc0': ['enc0']}
+            rides = {}
+            for key, names in groups.items():
+                rg = nv.SqRanges([r for nm in names for r in small[nm]])
+                rides[key] = (self.grad, comm, rg, torch.zeros(rg.blocks, device=self.dev, dtype=torch.float32), None, None)
+            self._direct = {'comm': comm, 'views': lay.views(comm), 'rides': rides}
+        return self._direct
+
     def _backward(self, lat, noise, allreduce, sample=None):
         B, L = self.B, self.L
         acc = self.accumulate
+        direct = self._direct_setup(allreduce) if isinstance(lat, nv.LatentM) and lat.da2[0] else None
+        self._direct_now = direct is not None
+        dr = direct['rides'] if direct else {}
         self._wait_wT()
         if self.bf16 and self._wT_stale:          # an optimiser step without a new batch since (tests): refresh here
             self.refresh_weights_bf16(transposes_only=True)
@@ -927,6 +978,8 @@ class TrainEngine:
             raise nv.JamieHipError('gradients accumulate onto a backward pass that wrote bf16 weight gradients: call '
                                    'set_grad_bf16(False) before the first backward pass of an accumulating run')
         self._g16_last = self._g16_pending = self._g16_now
+        if self._direct_now:           # (grad_view / grad_flat read the weight gradients from the message buffer)
+            self.grad16, self.g16, self._g16_last = direct['comm'], direct['views'], True
         # the decoder's output-bias gradient (column sums of d x_hat) rides in the first BatchNorm-backward launch as extra
         # workgroups (47 short ones beside 375 long ones) instead of being a launch of its own at the head of the backward
         # pass; with an overlapped gradient exchange the region must be complete before it is announced: own launch
@@ -934,12 +987,12 @@ class TrainEngine:
         cs_items = [(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))]
         if not ride:
             nv.colsum_group(cs_items, acc)
-        self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2')
+        self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2', ranges=dr.get('dec2'))
         self._region(allreduce, 'dec2')
         self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1,
                      colsums=nv.colsum_problems(cs_items, acc) if ride else None)   # de2[0] <- dg2p
         self._cast('de2')
-        self._bwd_gemms('de2', 'dec1', 'e1', 'de1', 'd_e1')
+        self._bwd_gemms('de2', 'dec1', 'e1', 'de1', 'd_e1', ranges=dr.get('dec1'))
         self._region(allreduce, 'dec1')
         self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
         self._cast('de1')
@@ -948,7 +1001,7 @@ class TrainEngine:
         # launch, and what is left here is the short d comb product alone
         late_dw = []
         fused_tail = isinstance(lat, nv.LatentM) and bool(lat.da2[0])
-        if fused_tail and os.environ.get('JAMIE_NO_LATE_DEC0_DW') != '1':
+        if fused_tail and (self._direct_now or os.environ.get('JAMIE_NO_LATE_DEC0_DW') != '1'):
             self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
             late_dw.append(('de1', 'comb', 'dec0'))
         else:
@@ -970,7 +1023,7 @@ class TrainEngine:
             self._region(allreduce, 'head')
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1)   # da2[0] <- dh2p
         self._cast('da2')
-        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=late_dw)
+        self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=late_dw, ranges=dr.get('enc1'))
         for ex in late_dw:
             self._region(allreduce, ex[2])
         self._region(allreduce, 'enc1')
@@ -981,7 +1034,7 @@ class TrainEngine:
         # ... but as EXTRA workgroups of that last dW launch the range norm (and the latent finalisation) costs nothing: every
         # other gradient exists by now
         ride = (self._fuse_now and self.bf16 and self._dw_cfg('enc0') == BF16_CFG_DW and os.environ.get('JAMIE_NO_RANGE_RIDE') != '1')
-        self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else None)
+        self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else dr.get('enc0'))
         self._ranges_done = ride
         self._region(allreduce, 'enc0')
         self._norm_ready = self._fuse_now

@@ -24,7 +24,7 @@ def _torchrun(script, port, nproc=2, timeout=600):
     return r.stdout
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16_msgs', 'bf16_f32msgs'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16_msgs', 'bf16_f32msgs', 'bf16_msgs_direct'])
 def test_two_ranks_with_identical_batches_reproduce_one_rank(tmp_path, mode):
     script = tmp_path / 'same.py'
     script.write_text(f'''
@@ -36,11 +36,12 @@ from jamie_amd.model import edModelVar
 rank, world, local = jd.init_from_env()
 dev = torch.device('cuda', local)
 mode = {mode!r}
-dims, L, B, N = (264, 136), 8, 128, 1024
+# (_direct: layers large enough for the large-tile dW launches, whose epilogues then write bf16 straight into the message buffer)
+dims, L, B, N = ((328, 264) if mode == 'bf16_msgs_direct' else (264, 136)), 8, 128, 1024
 g = torch.Generator(device=dev).manual_seed(50)          # the SAME cells on every rank
 data = [torch.randn(N, d, generator=g, device=dev) for d in dims]
 compute = 'f32' if mode == 'f32' else 'bf16'
-comm = torch.bfloat16 if mode == 'bf16_msgs' else None
+comm = torch.bfloat16 if mode in ('bf16_msgs', 'bf16_msgs_direct') else None
 flats = {{}}
 for label, w in (('one', 1), ('dp', world)):
     torch.manual_seed(3)
@@ -54,6 +55,7 @@ for label, w in (('one', 1), ('dp', world)):
         eng.step(None, None, None, ar)
     flats[label] = model.flat.clone()
     assert int(eng.state[1].item()) == 4
+    assert eng._direct_now == (w > 1 and mode == 'bf16_msgs_direct'), (label, eng._direct_now)
 a, b = flats['one'], flats['dp']
 d = (a - b).abs()
 if mode == 'f32':
