@@ -401,7 +401,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.config}: {len(dims)}-modality synthetic {n_cells} cells x {tuple(dims)} features, '
                                    f'latent={L}, B={B}/GPU, dropout={model.dropout}, '
-                                   + ('bf16 MFMA GEMMs, fp32 accumulate/master/optimiser, ' if args.dtype == 'bf16' else 'fp32 MFMA, ')
+                                   + (('bf16 MFMA GEMMs, fp32 accumulate/master/optimiser, ' + ('bf16 weight gradients (autocast semantics), ' if eng.grad_bf16 else 'fp32 weight gradients, ')) if args.dtype == 'bf16' else 'fp32 MFMA, ')
                                    + 'identity P (diag sampling), F=0, KL anneal per epoch',
                        'generator': 'SURVEY.md 8(d): numpy default_rng(0), 16-dim latent factor model + 0.1 noise, standardised per feature',
                        'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
