@@ -68,7 +68,9 @@ class OverlappedGradAllReduce:
     `region_done(flat[a:b])` is called right after the kernels that produce that contiguous region were
     launched (RCCL orders the collective after them on the device and runs it on its own stream);
     `finish()` waits for all of them before the gradient norm.  Adjacent regions are merged until a
-    bucket reaches `min_bytes`: xGMI is point-to-point, a few large messages beat many small ones.
+    bucket reaches `min_bytes`: xGMI is point-to-point, a few large messages beat many small ones.  The default (16 MB) lets
+    every large layer's region go out on its own (20 MB as bf16, 40 MB as fp32 at config 2): what stays exposed after the
+    backward pass is then the LAST layer's message alone, not a merged pair (reasoned, not measured: no multi-GPU box).
 
     `comm_dtype=torch.bfloat16` (the default of the bf16 compute mode) exchanges the gradient as bf16: a region is cast
     into a persistent bf16 buffer, all-reduced there and cast back into the fp32 gradient in `finish()`.  At config 2
@@ -76,7 +78,7 @@ class OverlappedGradAllReduce:
     (the last region is only ready when the backward pass ends); bf16 halves it, at the precision the bf16 GEMMs
     produced the gradient with.  Every rank receives the same reduced values, so the replicas stay identical."""
 
-    def __init__(self, group=None, min_bytes=32 << 20, comm_dtype=None, dry_run_world=0):
+    def __init__(self, group=None, min_bytes=16 << 20, comm_dtype=None, dry_run_world=0):
         """`dry_run_world` = N > 1 (one process, no process group): everything the N-rank step does on the device EXCEPT the
         collectives themselves -- region bookkeeping, message casts, side stream and events -- so that the per-rank compute
         path of the data-parallel step can be timed on a one-GPU box (bench.py --dry-run-world)."""
