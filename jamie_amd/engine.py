@@ -46,7 +46,7 @@ def choose_splitk(M, N, K, bm=64, bn=64):
 #                 else 128x128; slices proportional to K_i such that the launch has ~one workgroup per CU
 #                 (config 2: (3, 2) slices -> 256 workgroups; 37.5 -> 30.5 us and 34.2 -> 26.7 us per launch)
 #   dW (+ dX) grouped launch: 128x128 tiles on 8 waves of 64x32 (cfg 29; +2.4 % end to end over 4 waves of 64x64, cfg 25),
-#                 two LDS buffers (two workgroups per CU); dX slices ~ K_i / 1000
+#                 two LDS buffers (two workgroups per CU); dX slices ~ K_i / 1700
 # (more waves per tile measured faster at equal tiles: 256x128 on 16 waves of 64x32 instead of 8 of 64x64: 26.8 -> 24.8 us per
 #  forward launch; 128x128 on 8 waves of 64x32 instead of 4 of 64x64: 25.1 -> 22.4 us forward, +2.4 % end to end backward)
 BF16_CFG_ROWS_WIDE, BF16_CFG_ROWS, BF16_CFG_DW = 31, 32, 29
@@ -79,7 +79,11 @@ def plan_bf16_bwd(B, shapes):
     """shapes = [(N_i, K_i)] of the dX problems grouped with their dW problems -> (cfg, [splitk_i of the dX])."""
     if not _big_enough(B, shapes):
         return -1, [choose_splitk(B, N, K) for (N, K) in shapes]
-    return BF16_CFG_DW, [int(max(1, min(round(K / 1000), 4, K // 256))) for (N, K) in shapes]
+    # dX slices of ~1700 of K (config 2: (1, 1), (2, 1), (1, 1) for the three layers): re-swept at the end of round 2, when a
+    # slab costs the BatchNorm launch that sums it more than it saves the GEMM (K / 1000: +5.7 us per step, unsplit K = 4000: +25,
+    # profiles/r02_bwd_splitk_sweep.log)
+    per = float(os.environ.get('JAMIE_BWD_K_PER_SLAB', '1700'))        # (tuning knob, tools/ab.sh)
+    return BF16_CFG_DW, [int(max(1, min(round(K / per), 4, K // 256))) for (N, K) in shapes]
 
 
 F32_CFG_ROWS = 12           # 128x128x32 tile on 16 waves of 32x32 (gemm_f32.hip; 8 waves of 64x32, cfg 4, is 5-7 % slower)
