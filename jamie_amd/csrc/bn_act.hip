@@ -521,13 +521,24 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
 #pragma unroll
     for (int j = 0; j < R; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned keepbits = 0xFFFFFFFFu;              // bit 4 j + e: element (row j, column e) of this thread is kept
-    for (int s = 0; s < nslab; s += 2) {
-        float4 a[R], b[R];
-        const bool two = s + 1 < nslab;
+    // (R == 4: THREE slabs per round trip -- the forward launches of config 2 have (3, 2) K slices, and a third slab in a second
+    //  trip was one more memory latency for every workgroup of the larger modality; R == 8 keeps two: registers)
+#ifdef JAMIE_BN_TRIP2      // (A/B build: two slabs per trip as before)
+    constexpr int TRIP = 2;
+#else
+    constexpr int TRIP = R <= 4 ? 3 : 2;
+#endif
+    for (int s = 0; s < nslab; s += TRIP) {
+        float4 a[R], b[R], c[TRIP > 2 ? R : 1];
+        const bool two = s + 1 < nslab, three = TRIP > 2 && s + 2 < nslab;
 #pragma unroll
         for (int j = 0; j < R; ++j) a[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
 #pragma unroll
         for (int j = 0; j < R; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
+        if constexpr (TRIP > 2) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) c[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !three || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 2) * slab_bytes);
+        }
         if (s == 0 && drop) {                     // VALU work under the loads just issued
             keepbits = 0u;
 #pragma unroll
@@ -549,6 +560,7 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
         for (int j = 0; j < R; ++j) {
             v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w;
             v[j].x += b[j].x; v[j].y += b[j].y; v[j].z += b[j].z; v[j].w += b[j].w;
+            if constexpr (TRIP > 2) { v[j].x += c[j].x; v[j].y += c[j].y; v[j].z += c[j].z; v[j].w += c[j].w; }
         }
     }
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
