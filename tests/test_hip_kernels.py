@@ -401,7 +401,8 @@ def test_latent_fwd_bwd(nv, B, L, general, useF, cosine, nslab):
 
 @pytest.mark.parametrize('M,B,L,dims,nslab,bf,acc', [
     (2, 512, 32, (2000, 1000), 3, True, False), (2, 50, 8, (72, 45), 1, False, False), (3, 130, 64, (300, 200, 136), 2, True, True),
-    (4, 64, 16, (40, 33, 24, 16), 1, False, False), (2, 96, 128, (70, 52), 2, False, False)])
+    (4, 64, 16, (40, 33, 24, 16), 1, False, False), (2, 96, 128, (70, 52), 2, False, False),
+    (2, 70, 128, (72, 52), 3, True, False), (4, 64, 16, (40, 32, 24, 16), 9, True, False), (3, 40, 64, (260, 136, 72), 8, False, True)])
 def test_latent_m_fused_kernels(nv, M, B, L, dims, nslab, bf, acc):
     """The fused latent kernels of the identity-correspondence step (jamie_latent_m_fwd / _bwd; reference model.py:225-259
     with corr = I, model.py:190 decoder layer 0, jamie.py:618-668 losses) against a float64 autograd restatement:
