@@ -191,6 +191,21 @@ for comm, tol in ((None, 0.0), (torch.bfloat16, 2e-2)):
     dist.all_gather(both, g)
     assert torch.equal(both[0], both[1]), comm
     assert not ov.works and ov.pending is None
+# producers that write the bf16 message buffer themselves (the engine's dW epilogues): precast regions are reduced where they
+# stand, the fp32 buffer is neither read nor written, and the dry run (one process pretending to be N ranks) issues nothing
+ov = jd.OverlappedGradAllReduce(min_bytes=1024, comm_dtype=torch.bfloat16)
+g = torch.full((1003,), -7.0)                                  # (must stay untouched)
+msg = ov.message_buffer(g)
+assert msg.dtype == torch.bfloat16 and msg.numel() == 1003 and ov.message_buffer(g) is msg
+msg.copy_((torch.full((1003,), float(rank + 1)) + torch.arange(1003) * 0.001).to(torch.bfloat16))
+mine16 = msg.clone()
+for lo, hi in ((900, 1003), (600, 900), (590, 600), (100, 590), (0, 100)):
+    ov.region_done(g, lo, hi, precast=True)
+ov.finish(copy_back=False)
+both = [torch.zeros(1003, dtype=torch.bfloat16) for _ in range(world)]
+dist.all_gather(both, mine16)
+assert torch.equal(msg.float(), (both[0].float() + both[1].float()).to(torch.bfloat16).float())
+assert torch.equal(g, torch.full((1003,), -7.0)) and not ov.works and ov.pending is None
 # averaging happens inside the optimiser through grad_scale = 1/world: emulate the oracle update
 from oracle import jamie_oracle as orc
 p = [torch.ones(8)]
@@ -205,6 +220,23 @@ assert (lo, hi) == ((0, 6) if rank == 0 else (6, 11))
 dist.destroy_process_group()
 print('OK', rank)
 '''
+
+
+def test_dry_run_exchange_issues_no_collective():
+    """OverlappedGradAllReduce(dry_run_world=N) in one process without a process group: the region bookkeeping of an N-rank
+    step, no collective (bench.py --dry-run-world)."""
+    from jamie_amd import distributed as jd
+    ov = jd.OverlappedGradAllReduce(min_bytes=64, comm_dtype=torch.bfloat16, dry_run_world=8)
+    assert ov.world == 8 and ov.dry
+    g = torch.arange(100, dtype=torch.float32)
+    ov.region_done(g, 50, 100)
+    ov.region_done(g, 0, 50)
+    ov.finish(copy_back=False)
+    assert torch.equal(ov.comm.float(), g.to(torch.bfloat16).float()) and not ov.works       # cast into the message buffer, nothing reduced
+    ov.message_buffer(g).zero_()
+    ov.region_done(g, 0, 100, precast=True)
+    ov.finish(copy_back=False)
+    assert float(ov.comm.abs().sum()) == 0.0 and torch.equal(g, torch.arange(100, dtype=torch.float32))
 
 
 def test_gradient_exchange_world2_gloo(tmp_path):
