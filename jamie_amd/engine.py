@@ -146,9 +146,12 @@ class TrainEngine:
         assert len(self.loss_weights) == 4, f'There are 4 losses and {len(self.loss_weights)} weights'
         f32 = dict(device=self.dev, dtype=torch.float32)
         n = model.layout.total
-        self.grad = torch.zeros(n, **f32)
-        self.exp_avg = torch.zeros(n, **f32)
-        self.exp_avg_sq = torch.zeros(n, **f32)
+        # the streams clip + Adam walks in lock step (p, m, v, g, the bf16 weight copy) start 4 KB apart modulo the allocator's
+        # 2 MB alignment: 211 instead of 215-220 us stand-alone (tools/bench_adam_offsets.py, profiles/r02_adam_buffer_placement.log)
+        self._stagger = 0 if os.environ.get('JAMIE_NO_STAGGER') == '1' else 4096
+        self.exp_avg = self._flat_alloc(n, torch.float32, 1)
+        self.exp_avg_sq = self._flat_alloc(n, torch.float32, 2)
+        self.grad = self._flat_alloc(n, torch.float32, 3)
         self.g = model.layout.views(self.grad)
         self.n_norm = nv.optim_blocks(n)
         self.norm_partials = torch.zeros(self.n_norm, **f32)
@@ -261,7 +264,7 @@ class TrainEngine:
         self.wT = {}
         if self.bf16:
             # bf16 copies of the weights: same flat layout, plus K-contiguous transposes for the dX products
-            self.wbf_flat = torch.zeros(model.layout.total, device=self.dev, dtype=torch.bfloat16)
+            self.wbf_flat = self._flat_alloc(model.layout.total, torch.bfloat16, 4)
             self.wbf = model.layout.views(self.wbf_flat)
             # dX = dy W: the large-tile kernel reads W [out, in] as stored (b_tr: [k][n] LDS image, transposed fragment
             # reads), so only the layers whose backward launch does not take that kernel keep a transposed copy
@@ -338,7 +341,7 @@ class TrainEngine:
         self._g16_now = self._g16_last = self._g16_pending = False
         self._direct_now, self._direct = False, None       # (data parallel, bf16 messages: see _direct_setup)
         if self.grad_bf16:
-            self.grad16 = torch.zeros(n, device=self.dev, dtype=torch.bfloat16)
+            self.grad16 = self._flat_alloc(n, torch.bfloat16, 3)
             self.g16 = model.layout.views(self.grad16)
         bm_t, bn_t = (nv.gemm_bf16_tile(B, max(self.dims)) if self.bf16 else
                       nv.gemm_tile(nv.NT, B, max(self.dims), 2 * max(self.dims)))   # tile of the grouped launch
@@ -461,6 +464,12 @@ class TrainEngine:
             return {'mean': float(t.mean()), 'median': float(np.median(t)), 'p90': float(np.percentile(t, 90)),
                     'max': float(t.max()), 'n': int(t.size)}
         return float(t.mean())
+
+    def _flat_alloc(self, n, dtype, slot):
+        """A zeroed flat buffer of `n` elements that starts `slot * self._stagger` bytes into its allocation."""
+        es = 4 if dtype == torch.float32 else 2
+        off = slot * self._stagger // es
+        return torch.zeros(n + off, device=self.dev, dtype=dtype)[off:]
 
     # ---- bf16 compute mode: bf16 / bf16-transposed copies of GEMM operands ----
     def refresh_weights_bf16(self, transposes_only=False, lins=('enc0', 'enc1', 'head', 'dec0', 'dec1', 'dec2')):
