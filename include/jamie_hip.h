@@ -36,6 +36,8 @@ const char* jamie_last_error(void);
 int jamie_version(void);
 /* number of fp32 loss partial slots a GEMM epilogue / latent kernel may write (sizing helper) */
 int jamie_max_partials(void);
+/* number of sum-of-squares partials (dW tiles + range chunks) jamie_clip_adam* accepts */
+int jamie_max_norm_partials(void);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM (fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32).  Replaces every nn.Linear forward

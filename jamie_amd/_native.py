@@ -122,6 +122,7 @@ EXPORTS = {
     'jamie_last_error': (C.c_char_p, []),
     'jamie_version': (C.c_int, []),
     'jamie_max_partials': (C.c_int, []),
+    'jamie_max_norm_partials': (C.c_int, []),
     'jamie_gemm_f32': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
     'jamie_gemm_f32_cfg': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'jamie_gemm_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -9,6 +9,7 @@
 
 #define JAMIE_WAVE 64
 #define JAMIE_MAX_PARTIALS 4096
+#define JAMIE_MAX_NORM_PARTIALS 32768     // partial sums of squares clip + Adam adds up (one per dW tile + the range chunks)
 
 // ------------------------------------------------------------------------------------------------
 // error reporting

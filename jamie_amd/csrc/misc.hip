@@ -8,6 +8,7 @@ thread_local char g_jamie_err[512] = {0};
 extern "C" const char* jamie_last_error(void) { return g_jamie_err; }
 extern "C" int jamie_version(void) { return 100; }
 extern "C" int jamie_max_partials(void) { return JAMIE_MAX_PARTIALS; }
+extern "C" int jamie_max_norm_partials(void) { return JAMIE_MAX_NORM_PARTIALS; }
 
 // ---- dst[b,:] = src[idx[b],:]  (dataset[i][random_batch[i]], jamie.py:583): one wave per row piece ----
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, long long n_rows, int d,

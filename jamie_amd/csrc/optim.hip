@@ -219,7 +219,7 @@ int jamie_range_ride_fill(const float* g, void* g16, const long long* offsets, c
     const int rc = fill_ranges(offsets, lengths, count, g16 != nullptr, &rr->r, &nb);
     if (rc) return rc;
     JAMIE_ARG(nb >= 1 && n_partials == nb + (fin ? 1 : 0), "n_partials must equal jamie_sqnorm_range_blocks() (+ 1 with a finaliser)");
-    JAMIE_ARG(n_partials <= JAMIE_MAX_PARTIALS, "too many partial sums");
+    JAMIE_ARG(n_partials <= JAMIE_MAX_NORM_PARTIALS, "too many partial sums");
     rr->g = g; rr->g16 = (unsigned short*)g16; rr->partials = partials; rr->state = state; rr->n_range_blocks = nb;
     if (fin) {
         JAMIE_ARG(fin->defer_final && !fin->accumulate && fin->partials && fin->hyper && fin->losses && fin->dsigma,
@@ -257,7 +257,7 @@ static int sqnorm_ranges_impl(const float* g, void* g16, const long long* offset
     }
     JAMIE_ARG(nb >= 1 && n_partials == nb + (lat ? 1 : 0) + cs_blocks,
               "n_partials must equal jamie_sqnorm_range_blocks() (+ 1 with a finaliser, + ceil(N / 64) per column-sum problem)");
-    JAMIE_ARG(n_partials <= JAMIE_MAX_PARTIALS, "too many partial sums");
+    JAMIE_ARG(n_partials <= JAMIE_MAX_NORM_PARTIALS, "too many partial sums");
     JAMIE_ARG(!g16 || ((uintptr_t)g16 % 8) == 0, "g_bf16 must be 8-byte aligned");
     LatFinal fin;
     memset(&fin, 0, sizeof(fin));
@@ -336,7 +336,7 @@ static int clip_adam_impl(float* p, const float* g, const void* g_bf16, float* m
     JAMIE_ARG(p && (g || g_bf16) && m && v && partials && hyper && state && n > 0, "null pointer / empty");
     JAMIE_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                   ((uintptr_t)v % 16) == 0 && ((uintptr_t)g_bf16 % 8) == 0, "buffers must be 16-byte aligned (bf16 gradient: 8)");
-    JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_PARTIALS, "n_partials");
+    JAMIE_ARG(n_partials >= 1 && n_partials <= JAMIE_MAX_NORM_PARTIALS, "n_partials");
     JAMIE_ARG(p_bf16 == nullptr || ((uintptr_t)p_bf16 % 8) == 0, "p_bf16 must be 8-byte aligned");
     long long need = (n / 4 + ADAM_T - 1) / ADAM_T;
     const int grid = (int)(need < 1 ? 1 : (need > ADAM_GRID ? ADAM_GRID : need));

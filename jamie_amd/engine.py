@@ -282,6 +282,9 @@ class TrainEngine:
         self.fused_norm, self._fuse_now, self._norm_ready = False, False, False
         self._lat_deferred, self._ranges_done = None, False
         big = {'dec2': 'd_e2', 'dec1': 'd_e1', 'enc1': 'd_a1', 'enc0': 'dw'}
+        # (the skinny head / latent layers' dW take the large tile too: their sums of squares come from the epilogue as well -- at
+        #  L = 64 those two matrices alone are more range chunks than the range-norm launch carries)
+        skinny_lins = ('head', 'dec0') if (self.bf16 and getattr(self, 'skinny_tr', False)) else ()
         # (fp32 mode: the TN dW launches of the large layers take the 128 x 128 tile then -- the same speed as the 64 x 64 one
         #  inside the step, profiles/r02_f32_dw_tile_sweep.log, and a quarter of the partial sums)
         f32_fused = (not self.bf16 and world_size == 1 and B >= 256 and os.environ.get('JAMIE_NO_F32_FUSED_NORM') != '1'
@@ -290,7 +293,7 @@ class TrainEngine:
         if f32_fused or (self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values())):
             bm_d, bn_d = nv.gemm_tile(nv.TN, 1 << 20, 1 << 20, B, F32_CFG_DW_FUSED) if f32_fused else BF16_TILE[self.gcfg['dw']]
             self.dw_partial, off, covered = {}, 0, []
-            for lin in big:
+            for lin in tuple(big) + skinny_lins:
                 for i in range(self.M):
                     o, shp = model.layout.entries[f'm{i}.{lin}.W']
                     t = math.ceil(shp[0] / bm_d) * math.ceil(shp[1] / bn_d)
@@ -322,7 +325,7 @@ class TrainEngine:
                 if hi > lo:
                     rest2.append((lo, hi - lo))
             self.sq_ranges_nofin = nv.SqRanges(rest2)
-            if off + self.sq_ranges.blocks <= nv.load().jamie_max_partials() and self.sq_ranges.blocks <= 128:
+            if off + self.sq_ranges.blocks + 2 <= nv.load().jamie_max_norm_partials() and self.sq_ranges.blocks <= 128:
                 self.fused_norm = True
                 self.n_dw_partials = off
                 self.norm_partials = torch.zeros(max(off + self.sq_ranges.blocks, self.n_norm) + 2 + sum((d + 63) // 64 for d in self.dims), **f32)
