@@ -111,51 +111,78 @@ __global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uin
 struct MmJob { const float* Mtx; const float* Z; float* out; float* sums; int transpose; int active; };
 struct MmJobs { MmJob j[2]; int B, L; };
 
-// 256 threads = R rows x Lp latent columns (Lp = L rounded up to a power of two, R = 256 / Lp); the [B,B] matrix and Z are
+// 256 threads = R rows x LP latent columns (LP = L rounded up to a power of two, R = 256 / LP); the [B,B] matrix and Z are
 // streamed through LDS in 64-column chunks (coalesced: a chunk of Z is one contiguous block), every thread adds its 64
 // products in ascending column order with fmaf -- the order of the first version of this kernel (one thread per output
 // walking a whole matrix row from global memory: 1024 dependent round trips, 150-290 us per launch at B = 512-1024; the
 // general correspondence / F blocks of partial-correspondence training pay four to six such products per step).
+// The global loads of MM_NB chunks go out together, into registers, before the first of them is published to LDS: one memory
+// round trip per MM_NB chunks instead of one per chunk (B = 512: 2 instead of 8; 44 -> 1x us per launch at config 1).
 #define MM_CH 64
+#define MM_NB 4
+template <int LP>
 __global__ __launch_bounds__(256) void small_mm_kernel(MmJobs js) {
-    __shared__ float Msh[256 / 4][MM_CH + 1];       // R <= 64 rows (Lp >= 4)
-    __shared__ float Zsh[MM_CH][64 + 1];            // Lp <= 64 per pass
+    constexpr int R = 256 / LP;                      // rows per workgroup
+    constexpr int NM = R * MM_CH / 256, NZ = MM_CH * LP / 256;      // matrix / Z elements per thread and chunk
+    __shared__ float Msh[R][MM_CH + 1];
+    __shared__ float Zsh[MM_CH][LP + 1];
     const MmJob& J = js.j[blockIdx.y];
     if (!J.active) return;
     const int B = js.B, L = js.L;
-    int Lp = 4;
-    while (Lp < L && Lp < 64) Lp <<= 1;
-    const int R = 256 / Lp;
-    const int r = threadIdx.x / Lp, lq = threadIdx.x % Lp;
+    const int r = threadIdx.x / LP, lq = threadIdx.x % LP;
     const int row0 = blockIdx.x * R, row = row0 + r;
-    for (int l0 = 0; l0 < L; l0 += Lp) {            // L > 64: several passes over the latent columns
+    for (int l0 = 0; l0 < L; l0 += LP) {            // L > 64: several passes over the latent columns
         const int l = l0 + lq;
         float acc = 0.f, sm = 0.f;
         if (J.Mtx == nullptr) {
             if (row < B && l < L) { J.out[(long long)row * L + l] = J.Z[(long long)row * L + l]; if (J.sums && l == 0) J.sums[row] = 1.f; }
             continue;
         }
-        for (int c0 = 0; c0 < B; c0 += MM_CH) {
-            for (int i = threadIdx.x; i < R * MM_CH; i += 256) {
-                int rr, cc;
-                if (!J.transpose) { rr = i / MM_CH; cc = i % MM_CH; } else { cc = i / R; rr = i % R; }
-                const int gr = row0 + rr, gc = c0 + cc;
-                float w = 0.f;
-                if (gr < B && gc < B) w = J.transpose ? J.Mtx[(long long)gc * B + gr] : J.Mtx[(long long)gr * B + gc];
-                Msh[rr][cc] = w;
+        for (int cb = 0; cb < B; cb += MM_NB * MM_CH) {
+            float mreg[MM_NB][NM], zreg[MM_NB][NZ];
+#pragma unroll
+            for (int u = 0; u < MM_NB; ++u) {
+                const int c0 = cb + u * MM_CH;
+#pragma unroll
+                for (int t = 0; t < NM; ++t) {
+                    const int i = threadIdx.x + 256 * t;
+                    int rr, cc;
+                    if (!J.transpose) { rr = i / MM_CH; cc = i % MM_CH; } else { cc = i / R; rr = i % R; }
+                    const int gr = row0 + rr, gc = c0 + cc;
+                    mreg[u][t] = (gr < B && gc < B) ? (J.transpose ? J.Mtx[(long long)gc * B + gr] : J.Mtx[(long long)gr * B + gc]) : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < NZ; ++t) {
+                    const int i = threadIdx.x + 256 * t;
+                    const int cc = i / LP, ll = l0 + i % LP, gc = c0 + cc;
+                    zreg[u][t] = (gc < B && ll < L) ? J.Z[(long long)gc * L + ll] : 0.f;
+                }
             }
-            for (int i = threadIdx.x; i < MM_CH * Lp; i += 256) {
-                const int cc = i / Lp, ll = l0 + i % Lp, gc = c0 + cc;
-                Zsh[cc][i % Lp] = (gc < B && ll < L) ? J.Z[(long long)gc * L + ll] : 0.f;
+#pragma unroll
+            for (int u = 0; u < MM_NB; ++u) {
+                const int c0 = cb + u * MM_CH;
+                if (c0 >= B) break;                  // (uniform)
+#pragma unroll
+                for (int t = 0; t < NM; ++t) {
+                    const int i = threadIdx.x + 256 * t;
+                    int rr, cc;
+                    if (!J.transpose) { rr = i / MM_CH; cc = i % MM_CH; } else { cc = i / R; rr = i % R; }
+                    Msh[rr][cc] = mreg[u][t];
+                }
+#pragma unroll
+                for (int t = 0; t < NZ; ++t) {
+                    const int i = threadIdx.x + 256 * t;
+                    Zsh[i / LP][i % LP] = zreg[u][t];
+                }
+                __syncthreads();
+                const int nc = min(MM_CH, B - c0);
+                for (int cc = 0; cc < nc; ++cc) {
+                    const float w = Msh[r][cc];
+                    acc = fmaf(w, Zsh[cc][lq], acc);
+                    sm += w;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            const int nc = min(MM_CH, B - c0);
-            for (int cc = 0; cc < nc; ++cc) {
-                const float w = Msh[r][cc];
-                acc = fmaf(w, Zsh[cc][lq], acc);
-                sm += w;
-            }
-            __syncthreads();
         }
         if (row < B && l < L) {
             J.out[(long long)row * L + l] = acc;
@@ -170,7 +197,14 @@ static void launch_mm(hipStream_t st, int B, int L, const MmJob& j0, const MmJob
     int Lp = 4;
     while (Lp < L && Lp < 64) Lp <<= 1;
     const int R = 256 / Lp;
-    hipLaunchKernelGGL(small_mm_kernel, dim3((B + R - 1) / R, 2), dim3(256), 0, st, js);
+    const dim3 grid((B + R - 1) / R, 2);
+    switch (Lp) {
+        case 4: hipLaunchKernelGGL(small_mm_kernel<4>, grid, dim3(256), 0, st, js); break;
+        case 8: hipLaunchKernelGGL(small_mm_kernel<8>, grid, dim3(256), 0, st, js); break;
+        case 16: hipLaunchKernelGGL(small_mm_kernel<16>, grid, dim3(256), 0, st, js); break;
+        case 32: hipLaunchKernelGGL(small_mm_kernel<32>, grid, dim3(256), 0, st, js); break;
+        default: hipLaunchKernelGGL(small_mm_kernel<64>, grid, dim3(256), 0, st, js); break;
+    }
 }
 
 // per-row cosine pieces: s = a.c / (|a||c|)
