@@ -176,10 +176,19 @@ __global__ __launch_bounds__(256) void small_mm_kernel(MmJobs js) {
                 }
                 __syncthreads();
                 const int nc = min(MM_CH, B - c0);
-                for (int cc = 0; cc < nc; ++cc) {
-                    const float w = Msh[r][cc];
-                    acc = fmaf(w, Zsh[cc][lq], acc);
-                    sm += w;
+                if (nc == MM_CH) {                   // (uniform) whole chunk: unrolled, the LDS reads run ahead of the FMA chain
+#pragma unroll
+                    for (int cc = 0; cc < MM_CH; ++cc) {
+                        const float w = Msh[r][cc];
+                        acc = fmaf(w, Zsh[cc][lq], acc);
+                        sm += w;
+                    }
+                } else {
+                    for (int cc = 0; cc < nc; ++cc) {
+                        const float w = Msh[r][cc];
+                        acc = fmaf(w, Zsh[cc][lq], acc);
+                        sm += w;
+                    }
                 }
                 __syncthreads();
             }
