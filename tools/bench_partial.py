@@ -10,7 +10,8 @@ Z = rng.standard_normal((N, 16)).astype(np.float32)
 data = [(Z @ rng.standard_normal((16, d)).astype(np.float32) + 0.1 * rng.standard_normal((N, d)).astype(np.float32)) for d in dims]
 k = N // 2
 P = sp.csr_matrix((np.ones(k, np.float32), (np.arange(k), np.arange(k))), shape=(N, N))
-for dtype, sampler in (('bf16', 'numpy'), ('bf16', 'device'), ('f32', 'device')):
+VARIANTS = [v.split(':') for v in os.environ.get('VARIANTS', 'bf16:numpy,bf16:device,f32:device').split(',')]
+for dtype, sampler in VARIANTS:
     jm = JAMIE(output_dim=32, pca_dim=None, use_f_tilde=False, compute_dtype=dtype, epoch_DNN=epochs, min_epochs=2,
                log_DNN=10 ** 9, batch_size=512, debug=True, sampler=sampler)
     np.random.seed(0)
