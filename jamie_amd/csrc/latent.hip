@@ -109,110 +109,99 @@ __global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uin
 // ---- small [B,B] x [B,L] products.  job 0: out = Mtx Z (+ row sums); job 1: out = Mtx^T Z (+ column sums).
 // Mtx == nullptr means identity (out = Z, sums = 1). ----
 struct MmJob { const float* Mtx; const float* Z; float* out; float* sums; int transpose; int active; };
-struct MmJobs { MmJob j[2]; int B, L; };
+struct MmJobs { MmJob j[2]; int B, L, l0; };       // l0: first latent column of this launch (L > 128: several launches)
 
-// 256 threads = R rows x LP latent columns (LP = L rounded up to a power of two, R = 256 / LP); the [B,B] matrix and Z are
-// streamed through LDS in 64-column chunks (coalesced: a chunk of Z is one contiguous block), every thread adds its 64
-// products in ascending column order with fmaf -- the order of the first version of this kernel (one thread per output
-// walking a whole matrix row from global memory: 1024 dependent round trips, 150-290 us per launch at B = 512-1024; the
-// general correspondence / F blocks of partial-correspondence training pay four to six such products per step).
-// The global loads of MM_NB chunks go out together, into registers, before the first of them is published to LDS: one memory
-// round trip per MM_NB chunks instead of one per chunk (B = 512: 2 instead of 8; 44 -> 1x us per launch at config 1).
-#define MM_CH 64
-#define MM_NB 4
-template <int LP>
-__global__ __launch_bounds__(256) void small_mm_kernel(MmJobs js) {
-    constexpr int R = 256 / LP;                      // rows per workgroup
-    constexpr int NM = R * MM_CH / 256, NZ = MM_CH * LP / 256;      // matrix / Z elements per thread and chunk
-    __shared__ float Msh[R][MM_CH + 1];
-    __shared__ float Zsh[MM_CH][LP + 1];
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): workgroup = 32 output rows x all L columns, 16 waves; wave w multiplies the k-slice
+// [w KS, (w + 1) KS) of the B columns of the matrix (operands straight from global memory in the MFMA lane layout: 4 bytes per
+// lane and k-step, 8-16 k-steps' loads in flight together), the 16 partial tiles are added in wave order through LDS (wave w
+// adds accumulator register w).  The row
+// (job 1: column) sums of the matrix ride along.  History: one thread per output walking a matrix row from global memory (1024
+// dependent round trips, 150-290 us per launch at B = 512-1024); LDS-staged 64-column chunks on the vector ALU (16-44 us: a
+// latency chain of chunk loads and LDS reads on four waves); this one 6-9 us.  The general correspondence / F blocks of
+// partial-correspondence training pay four to six such products per step, config 1 (batch with duplicates) two.
+template <int NCT>
+__global__ __launch_bounds__(1024) void small_mm_kernel(MmJobs js) {
+    __shared__ float red[16][16][64];                 // one 32 x 32 tile per wave
+    __shared__ float smred[16][64];
     const MmJob& J = js.j[blockIdx.y];
     if (!J.active) return;
-    const int B = js.B, L = js.L;
-    const int r = threadIdx.x / LP, lq = threadIdx.x % LP;
-    const int row0 = blockIdx.x * R, row = row0 + r;
-    for (int l0 = 0; l0 < L; l0 += LP) {            // L > 64: several passes over the latent columns
-        const int l = l0 + lq;
-        float acc = 0.f, sm = 0.f;
-        if (J.Mtx == nullptr) {
-            if (row < B && l < L) { J.out[(long long)row * L + l] = J.Z[(long long)row * L + l]; if (J.sums && l == 0) J.sums[row] = 1.f; }
-            continue;
-        }
-        for (int cb = 0; cb < B; cb += MM_NB * MM_CH) {
-            float mreg[MM_NB][NM], zreg[MM_NB][NZ];
-#pragma unroll
-            for (int u = 0; u < MM_NB; ++u) {
-                const int c0 = cb + u * MM_CH;
-#pragma unroll
-                for (int t = 0; t < NM; ++t) {
-                    const int i = threadIdx.x + 256 * t;
-                    int rr, cc;
-                    if (!J.transpose) { rr = i / MM_CH; cc = i % MM_CH; } else { cc = i / R; rr = i % R; }
-                    const int gr = row0 + rr, gc = c0 + cc;
-                    mreg[u][t] = (gr < B && gc < B) ? (J.transpose ? J.Mtx[(long long)gc * B + gr] : J.Mtx[(long long)gr * B + gc]) : 0.f;
-                }
-#pragma unroll
-                for (int t = 0; t < NZ; ++t) {
-                    const int i = threadIdx.x + 256 * t;
-                    const int cc = i / LP, ll = l0 + i % LP, gc = c0 + cc;
-                    zreg[u][t] = (gc < B && ll < L) ? J.Z[(long long)gc * L + ll] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < MM_NB; ++u) {
-                const int c0 = cb + u * MM_CH;
-                if (c0 >= B) break;                  // (uniform)
-#pragma unroll
-                for (int t = 0; t < NM; ++t) {
-                    const int i = threadIdx.x + 256 * t;
-                    int rr, cc;
-                    if (!J.transpose) { rr = i / MM_CH; cc = i % MM_CH; } else { cc = i / R; rr = i % R; }
-                    Msh[rr][cc] = mreg[u][t];
-                }
-#pragma unroll
-                for (int t = 0; t < NZ; ++t) {
-                    const int i = threadIdx.x + 256 * t;
-                    Zsh[i / LP][i % LP] = zreg[u][t];
-                }
-                __syncthreads();
-                const int nc = min(MM_CH, B - c0);
-                if (nc == MM_CH) {                   // (uniform) whole chunk: unrolled, the LDS reads run ahead of the FMA chain
-#pragma unroll
-                    for (int cc = 0; cc < MM_CH; ++cc) {
-                        const float w = Msh[r][cc];
-                        acc = fmaf(w, Zsh[cc][lq], acc);
-                        sm += w;
-                    }
-                } else {
-                    for (int cc = 0; cc < nc; ++cc) {
-                        const float w = Msh[r][cc];
-                        acc = fmaf(w, Zsh[cc][lq], acc);
-                        sm += w;
-                    }
-                }
-                __syncthreads();
+    const int B = js.B, L = js.L, l0 = js.l0, tid = threadIdx.x;
+    const int row0 = blockIdx.x * 32;
+    if (J.Mtx == nullptr) {                           // identity: out = Z, sums = 1
+        if (l0 == 0) {
+            for (int i = tid; i < 32 * L; i += 1024) {
+                const int row = row0 + i / L, l = i % L;
+                if (row < B) { J.out[(long long)row * L + l] = J.Z[(long long)row * L + l]; if (J.sums && l == 0) J.sums[row] = 1.f; }
             }
         }
-        if (row < B && l < L) {
-            J.out[(long long)row * L + l] = acc;
-            if (J.sums && l == 0) J.sums[row] = sm;
+        return;
+    }
+    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int KS = ((B + 15) / 16 + 1) / 2 * 2;       // k-slice per wave (even)
+    const int kbeg = w * KS, kend = min(B, kbeg + KS);
+    const int row = row0 + r;
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+    float sm = 0.f;
+    constexpr int NB = NCT == 1 ? 16 : 8;             // k-steps (of two columns each) whose loads are in flight together
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * NB) {
+        float av[NB], bv[NB][NCT];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int kk = k0 + 2 * u + h;
+            const bool ok = kk < kend;
+            av[u] = (ok && row < B) ? (J.transpose ? J.Mtx[(long long)kk * B + row] : J.Mtx[(long long)row * B + kk]) : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int n = l0 + ct * 32 + r;
+                bv[u][ct] = (ok && n < L) ? J.Z[(long long)kk * L + n] : 0.f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            sm += av[u];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][ct], acc[ct], 0, 0, 0);
+        }
+    }
+    smred[w][lane] = sm;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (ct) lds_barrier();                        // (the previous tile's sums have been read)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[w][e][lane] = acc[ct][e];
+        lds_barrier();
+        {                                             // wave w adds accumulator register w of all 16 waves (in wave order)
+            const int n = l0 + ct * 32 + r, e = w;
+            float t = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) t += red[ww][e][lane];
+            const int m = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < B && n < L) J.out[(long long)m * L + n] = t;
+        }
+    }
+    if (J.sums && l0 == 0 && w == 1 && lane < 32 && row < B) {   // (smred was published by the barrier above)
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) t += smred[ww][lane] + smred[ww][lane + 32];
+        J.sums[row] = t;
     }
 }
 
 static void launch_mm(hipStream_t st, int B, int L, const MmJob& j0, const MmJob& j1) {
     MmJobs js;
     js.j[0] = j0; js.j[1] = j1; js.B = B; js.L = L;
-    int Lp = 4;
-    while (Lp < L && Lp < 64) Lp <<= 1;
-    const int R = 256 / Lp;
-    const dim3 grid((B + R - 1) / R, 2);
-    switch (Lp) {
-        case 4: hipLaunchKernelGGL(small_mm_kernel<4>, grid, dim3(256), 0, st, js); break;
-        case 8: hipLaunchKernelGGL(small_mm_kernel<8>, grid, dim3(256), 0, st, js); break;
-        case 16: hipLaunchKernelGGL(small_mm_kernel<16>, grid, dim3(256), 0, st, js); break;
-        case 32: hipLaunchKernelGGL(small_mm_kernel<32>, grid, dim3(256), 0, st, js); break;
-        default: hipLaunchKernelGGL(small_mm_kernel<64>, grid, dim3(256), 0, st, js); break;
+    const dim3 grid((B + 31) / 32, 2);
+    for (int l0 = 0; l0 < L; l0 += 128) {
+        js.l0 = l0;
+        const int nct = (min(L - l0, 128) + 31) / 32;
+        if (nct <= 1) hipLaunchKernelGGL(small_mm_kernel<1>, grid, dim3(1024), 0, st, js);
+        else if (nct == 2) hipLaunchKernelGGL(small_mm_kernel<2>, grid, dim3(1024), 0, st, js);
+        else if (nct == 3) hipLaunchKernelGGL(small_mm_kernel<3>, grid, dim3(1024), 0, st, js);
+        else hipLaunchKernelGGL(small_mm_kernel<4>, grid, dim3(1024), 0, st, js);
     }
 }
 
