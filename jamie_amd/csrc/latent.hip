@@ -80,10 +80,16 @@ __global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uin
     for (int i = 0; i < 2; ++i) {
         if (!ok) continue;
         float mu = a.head_bias[i][l], lv = a.head_bias[i][L + l];
-        for (int s = 0; s < a.ml_nslab; ++s) {
-            const float* p = a.ml[i] + s * a.ml_slab_stride + (long long)b * 2 * L;
-            mu += p[l];
-            lv += p[L + l];
+        for (int s0 = 0; s0 < a.ml_nslab; s0 += 8) {        // eight slabs' loads in flight per round trip, added in slab order
+            float tm[8], tl[8];                              // (one slab per iteration was a memory round trip each: 16 per launch)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* p = a.ml[i] + (s0 + u) * a.ml_slab_stride + (long long)b * 2 * L;
+                tm[u] = s0 + u < a.ml_nslab ? p[l] : 0.f;
+                tl[u] = s0 + u < a.ml_nslab ? p[L + l] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { mu += tm[u]; lv += tl[u]; }
         }
         float ep;
         if (a.eps_in[i]) {
@@ -305,9 +311,15 @@ __global__ __launch_bounds__(256) void latent_bwd_a_kernel(LatDev a) {
         fsq = E * E;
         float G0 = w_f * 2.f * E * invBL;
         float G1 = a.Fblk ? -w_f * 2.f * a.fte[e] * invBL : 0.f;
-        for (int s = 0; s < a.dcomb_nslab; ++s) {
-            G0 += a.dcomb[0][e + s * a.dcomb_slab_stride];
-            G1 += a.dcomb[1][e + s * a.dcomb_slab_stride];
+        for (int t0 = 0; t0 < a.dcomb_nslab; t0 += 8) {     // (see the forward kernel)
+            float u0[8], u1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                u0[u] = t0 + u < a.dcomb_nslab ? a.dcomb[0][e + (t0 + u) * a.dcomb_slab_stride] : 0.f;
+                u1[u] = t0 + u < a.dcomb_nslab ? a.dcomb[1][e + (t0 + u) * a.dcomb_slab_stride] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { G0 += u0[u]; G1 += u1[u]; }
         }
         float gz, gc;
         align_grads(a, 0, e, b, l, w_al, invBL, gz, gc);
