@@ -340,7 +340,6 @@ __global__ __launch_bounds__(256) void latent_bwd_a_kernel(LatDev a) {
 
 // ---- K8: d(mu|logvar); block 0 also finalises the losses and dsigma ----
 __global__ __launch_bounds__(256) void latent_bwd_b_kernel(LatDev a) {
-    __shared__ float red[4];
     const int B = a.B, L = a.L, n = B * L;
     const int e = blockIdx.x * 256 + threadIdx.x;
     const float invBL = 1.f / (float)n;
@@ -374,18 +373,23 @@ __global__ __launch_bounds__(256) void latent_bwd_b_kernel(LatDev a) {
     }
     if (blockIdx.x != 0) return;
     // ---- finalise (fixed summation order) ----
+    // every slot's loads first, then ONE pair of barriers for all ten sums (block_sum_n: the same wave-then-wave-order adds
+    // as block_sum): slot after slot it was ten dependent round trips + twenty barriers, 10 us for this launch
     const int nblk = (n + 255) / 256;
-    float tot[LAT_SLOTS];
+    constexpr int NS = S_DSIG1 + 1;
+    __shared__ float redn[(256 / 64 + 1) * (NS + 1)];
+    float v[NS + 1];
 #pragma unroll
-    for (int sl = 0; sl <= S_DSIG1; ++sl) {
-        float v = 0.f;
-        for (int i = threadIdx.x; i < nblk; i += 256) v += a.partials[sl * JAMIE_MAX_PARTIALS + i];
-        tot[sl] = block_sum(v, red);
-    }
-    float rec = 0.f;
-    for (int i = threadIdx.x; i < a.n_rec_partials; i += 256) rec += a.rec_partials[i];
-    rec = block_sum(rec, red);
+    for (int sl = 0; sl < NS; ++sl) v[sl] = (int)threadIdx.x < nblk ? a.partials[sl * JAMIE_MAX_PARTIALS + threadIdx.x] : 0.f;
+    v[NS] = (int)threadIdx.x < a.n_rec_partials ? a.rec_partials[threadIdx.x] : 0.f;
+    for (int i = threadIdx.x + 256; i < nblk; i += 256)
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) v[sl] += a.partials[sl * JAMIE_MAX_PARTIALS + i];
+    for (int i = threadIdx.x + 256; i < a.n_rec_partials; i += 256) v[NS] += a.rec_partials[i];
+    block_sum_n<NS + 1>(v, redn);
     if (threadIdx.x == 0) {
+        const float* tot = redn;
+        const float rec = redn[NS];
         const float w_rec = a.hyper[1], w_al = a.hyper[2], w_f = a.hyper[3];
         const float kl = -0.5f * (tot[S_TROW0] / (float)L - tot[S_MU2_0] * invBL)
                          - 0.5f * (tot[S_TROW1] / (float)L - tot[S_MU2_1] * invBL);
