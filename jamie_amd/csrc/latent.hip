@@ -67,6 +67,13 @@ __device__ __forceinline__ void put_partial(const LatDev& a, int slot, float v, 
     const float t = block_sum(v, red);
     if (threadIdx.x == 0) a.partials[slot * JAMIE_MAX_PARTIALS + blockIdx.x] = t;
 }
+// N per-workgroup partial sums behind ONE pair of barriers (block_sum_n: the same adds as N block_sum calls, bit for bit)
+template <int N>
+__device__ __forceinline__ void put_partials(const LatDev& a, const int (&slots)[N], float (&v)[N]) {
+    __shared__ float redn[(256 / 64 + 1) * N];
+    block_sum_n<N>(v, redn);
+    if ((int)threadIdx.x < N) a.partials[slots[threadIdx.x] * JAMIE_MAX_PARTIALS + blockIdx.x] = redn[threadIdx.x];
+}
 
 // ---- K1: mu/logvar from the heads GEMM slabs, reparameterise, KL partial sums ----
 __global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uint64_t* rng) {
@@ -106,10 +113,9 @@ __global__ __launch_bounds__(256) void latent_reparam_kernel(LatDev a, const uin
         // KL quirk: logvars[j] is ROW j of the LAST modality's logvar (jamie.py:619-628, model.py:243)
         if (i == 1 && b < 2) trow[b] = 1.f + lv - expf(lv);
     }
-    put_partial(a, S_MU2_0, mu2[0], red);
-    put_partial(a, S_MU2_1, mu2[1], red);
-    put_partial(a, S_TROW0, trow[0], red);
-    put_partial(a, S_TROW1, trow[1], red);
+    const int slots[4] = {S_MU2_0, S_MU2_1, S_TROW0, S_TROW1};
+    float pv[4] = {mu2[0], mu2[1], trow[0], trow[1]};
+    put_partials<4>(a, slots, pv);
 }
 
 // ---- small [B,B] x [B,L] products.  job 0: out = Mtx Z (+ row sums); job 1: out = Mtx^T Z (+ column sums).
@@ -333,9 +339,9 @@ __global__ __launch_bounds__(256) void latent_bwd_a_kernel(LatDev a) {
         ds0 = H0 * a.z[0][e] - H0 * c0 + H1 * a.cz[1][e] - q * H1 * c1;
         ds1 = H1 * a.z[1][e] - H1 * c1 + H0 * a.cz[0][e] - r * H0 * c0;
     }
-    put_partial(a, S_DSIG0, ds0, red);
-    put_partial(a, S_DSIG1, ds1, red);
-    put_partial(a, S_F, fsq, red);
+    const int slots[3] = {S_DSIG0, S_DSIG1, S_F};
+    float pv[3] = {ds0, ds1, fsq};
+    put_partials<3>(a, slots, pv);
 }
 
 // ---- K8: d(mu|logvar); block 0 also finalises the losses and dsigma ----
