@@ -332,6 +332,8 @@ int jamie_gather_rows(const float* src, long long n_rows, int d, const int32_t* 
  * (device-side counterpart of np.random.choice, jamie.py:556); one workgroup, deterministic. */
 int jamie_sample_indices(int32_t* idx, int B, long long N, long long offset, int replace,
                          const uint64_t* rng, int rng_stream, void* stream);
+/* up to 4 independent draws in one launch (one workgroup each): the hybrid sampler's pair numbers and rows of both modalities */
+int jamie_sample_indices_group(const jamie_sample_args* list /*host*/, int count, const uint64_t* rng, void* stream);
 /* 'hybrid' sampler of partial-correspondence training on the device (jamie.py:559-573, corrected): slot b is, with
  * probability true_ratio, known pair pairs[pidx[b] % num_corr] = (row of modality 0, row of modality 1), else (r0[b], r1[b]);
  * pidx / r0 / r1: candidate draws from jamie_sample_indices */

@@ -166,6 +166,7 @@ EXPORTS = {
     'jamie_axpby': (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_longlong, C.c_void_p]),
     'jamie_gather_rows': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p]),
+    'jamie_sample_indices_group': (C.c_int, [C.POINTER(SampleArgs), C.c_int, C.c_void_p, C.c_void_p]),
     'jamie_sample_indices': (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p,
                                        C.c_int, C.c_void_p]),
     'jamie_hybrid_assemble': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
@@ -480,6 +481,13 @@ def clip_adam(p, g, m, v, partials, hyper, state, p_bf16=None, sample=None, cast
 
 def gather_rows(src, idx, dst):
     _call('jamie_gather_rows', ptr(src), src.shape[0], src.shape[1], ptr(idx), idx.numel(), ptr(dst), _stream())
+
+
+def sample_indices_group(items, rng):
+    """items = [sample_args(...)] (<= 4): independent draws in ONE launch, one workgroup each."""
+    arr = (SampleArgs * len(items))(*items)
+    arr._keep = items
+    _call('jamie_sample_indices_group', arr, len(items), ptr(rng), _stream())
 
 
 def sample_indices(idx, N, offset, replace, rng, rng_stream):

@@ -58,6 +58,31 @@ extern "C" int jamie_sample_indices(int32_t* idx, int B, long long N, long long 
     return jamie_launch_status("jamie_sample_indices");
 }
 
+// several independent draws in ONE launch, one workgroup each (the hybrid sampler of partial-correspondence training draws pair
+// numbers and rows of both modalities: three one-workgroup launches before)
+struct SampleGroup { SampleArgs a[4]; };
+__global__ __launch_bounds__(1024) void sample_group_kernel(SampleGroup g, const uint64_t* rng) {
+    __shared__ SampleLds lds;
+    const SampleArgs& s = g.a[blockIdx.x];
+    jamie_sample_block(lds, s.idx, s.B, s.N, s.offset, s.replace, rng, s.rng_stream, s.step_add);
+}
+
+extern "C" int jamie_sample_indices_group(const jamie_sample_args* list, int count, const uint64_t* rng, void* stream) {
+    JAMIE_ARG(list && rng && count >= 1 && count <= 4, "1 <= count <= 4");
+    SampleGroup g;
+    memset(&g, 0, sizeof(g));
+    for (int i = 0; i < count; ++i) {
+        const jamie_sample_args& s = list[i];
+        JAMIE_ARG(s.idx && s.B > 0 && s.N > 0, "null pointer / empty");
+        JAMIE_ARG(s.replace || (s.B <= s.N && s.B <= SMP_HASH / 2), "without replacement: B <= N and B <= 2048");
+        JAMIE_ARG(s.N + s.offset <= 0x7fffffffLL, "indices must fit int32");
+        g.a[i].idx = s.idx; g.a[i].B = s.B; g.a[i].N = s.N; g.a[i].offset = s.offset; g.a[i].replace = s.replace;
+        g.a[i].rng_stream = s.rng_stream; g.a[i].step_add = s.step_add;
+    }
+    hipLaunchKernelGGL(sample_group_kernel, dim3(count), dim3(1024), 0, (hipStream_t)stream, g, rng);
+    return jamie_launch_status("jamie_sample_indices_group");
+}
+
 // ---- corr[a,b] = (idx0[a] == idx1[b]) / max(1, #matches in row a)  (jamie.py:586-589 with P = I) ----
 __global__ __launch_bounds__(256) void corr_from_idx_kernel(const int32_t* idx0, const int32_t* idx1, int B, float* corr) {
     __shared__ float red[4];

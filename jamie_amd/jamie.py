@@ -389,9 +389,9 @@ class JAMIE:
             hy = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(3)]
 
             def hybrid_step():
-                nv.sample_indices(hy[0], self.num_corr, 0, rep or self.num_corr < B, eng.state, 202)
-                nv.sample_indices(hy[1], rows[0], 0, rep, eng.state, 200)
-                nv.sample_indices(hy[2], rows[1], 0, rep, eng.state, 201)
+                nv.sample_indices_group([nv.sample_args(hy[0], self.num_corr, 0, rep or self.num_corr < B, 202),
+                                         nv.sample_args(hy[1], rows[0], 0, rep, 200),
+                                         nv.sample_args(hy[2], rows[1], 0, rep, 201)], eng.state)
                 nv.hybrid_assemble(pairs_dev, hy[0], hy[1], hy[2], self.num_corr, self.true_ratio, eng.state, 203,
                                    idx_dev[0], idx_dev[1])
                 eng.load_batch(data, idx_dev)
