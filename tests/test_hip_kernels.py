@@ -672,6 +672,20 @@ def test_sampler_without_replacement(nv):
     assert v.min() >= 0 and v.max() < 100 and len(set(v.tolist())) < 512
 
 
+def test_sampler_group_equals_single_draws(nv):
+    """jamie_sample_indices_group: several draws in one launch == the same draws launched one by one (the hybrid sampler's
+    pair numbers and rows of both modalities, jamie.py:556-583)."""
+    state = torch.tensor([5, 17, 0, 0], dtype=torch.int64, device='cuda')
+    specs = [(512, 50000, 0, False, 202), (512, 100000, 3, False, 200), (300, 700, 0, True, 201), (48, 50, 10, False, 203)]
+    single = [torch.zeros(B, dtype=torch.int32, device='cuda') for B, *_ in specs]
+    group = [torch.zeros(B, dtype=torch.int32, device='cuda') for B, *_ in specs]
+    for t, (B, N, off, rep, stream) in zip(single, specs):
+        nv.sample_indices(t, N, off, rep, state, stream)
+    nv.sample_indices_group([nv.sample_args(t, N, off, rep, stream) for t, (B, N, off, rep, stream) in zip(group, specs)], state)
+    for a, b in zip(single, group):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------
 # riders: a small launch's work as extra workgroups of a launch that is there anyway
 # ------------------------------------------------------------------------------------------------
