@@ -89,7 +89,13 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
     }
     __shared__ float red[T / 64];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n_partials; i += T) s += partials[i];
+    for (int i0 = threadIdx.x; i0 < n_partials; i0 += 8 * T) {      // eight loads in flight per round trip, added in index order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = i0 + u * T < n_partials ? partials[i0 + u * T] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
     s = block_sum(s, red);
     const float lr = hyper[8], b1 = hyper[9], b2 = hyper[10], eps = hyper[11], max_norm = hyper[12];
     const float gscale = hyper[13];
