@@ -87,41 +87,15 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
             return;
         }
     }
-    __shared__ float red[T / 64];
-    float s = 0.f;
-    for (int i0 = threadIdx.x; i0 < n_partials; i0 += 8 * T) {      // eight loads in flight per round trip, added in index order
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = i0 + u * T < n_partials ? partials[i0 + u * T] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += t[u];
-    }
-    s = block_sum(s, red);
-    const float lr = hyper[8], b1 = hyper[9], b2 = hyper[10], eps = hyper[11], max_norm = hyper[12];
-    const float gscale = hyper[13];
-    const float total = sqrtf(s) * gscale;                 // norm of the (averaged) gradient
-    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f) * gscale;
-    const double t = (double)state[1];
-    const float bc1 = (float)(1.0 - pow((double)b1, t));
-    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
-    const float step_size = lr / bc1;
-    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
-    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-        gg *= coef;
-        mm = mm + (gg - mm) * omb1;                        // exp_avg.lerp_(grad, 1 - beta1)
-        vv = vv * b2 + omb2 * gg * gg;                     // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = sqrtf(vv) / bc2s + eps;
-        pp -= step_size * (mm / denom);
-    };
     const long long n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
     const long long nwg = RIDE ? n_stream : gridDim.x;          // streaming workgroups
-    for (long long i0 = (long long)blockIdx.x * (T * U) + threadIdx.x; i0 < n4; i0 += nwg * (T * U)) {
-        // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
-        float4 pp[U], mm[U], vv[U], gg[U];
+    // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
+    float4 pp[U], mm[U], vv[U], gg[U];
+    auto load_batch = [&](long long i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long i = i0 + u * T;
@@ -141,6 +115,44 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
                 }
             }
         }
+    };
+    // the first batch of the streams is requested before the prologue below (norm, bias corrections): nothing in it depends on them
+    long long i0 = (long long)blockIdx.x * (T * U) + threadIdx.x;
+    if (i0 < n4) load_batch(i0);
+    __shared__ float red[T / 64];
+    // latency order: the first batch of partial sums, the hyper-parameters and the step counter are all requested up front; the
+    // bias corrections (two double-precision pow: a few hundred instructions) are computed while the partial sums are in flight
+    float s = 0.f;
+    float t0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t0[u] = (int)threadIdx.x + u * T < n_partials ? partials[threadIdx.x + u * T] : 0.f;
+    const float lr = hyper[8], b1 = hyper[9], b2 = hyper[10], eps = hyper[11], max_norm = hyper[12];
+    const float gscale = hyper[13];
+    const double t = (double)state[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t0[u];
+    for (int i0 = threadIdx.x + 8 * T; i0 < n_partials; i0 += 8 * T) {      // eight loads in flight per round trip, added in index order
+        float tt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tt[u] = i0 + u * T < n_partials ? partials[i0 + u * T] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += tt[u];
+    }
+    s = block_sum(s, red);
+    const float total = sqrtf(s) * gscale;                 // norm of the (averaged) gradient
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f) * gscale;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= coef;
+        mm = mm + (gg - mm) * omb1;                        // exp_avg.lerp_(grad, 1 - beta1)
+        vv = vv * b2 + omb2 * gg * gg;                     // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vv) / bc2s + eps;
+        pp -= step_size * (mm / denom);
+    };
+    for (; i0 < n4;) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long i = i0 + u * T;
@@ -161,6 +173,8 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
                 __builtin_nontemporal_store(pk, reinterpret_cast<unsigned long long*>(p_bf16) + i);
             }
         }
+        i0 += nwg * (T * U);
+        if (i0 < n4) load_batch(i0);
     }
     if (blockIdx.x == 0) {
         const long long i = (n4 << 2) + threadIdx.x;
