@@ -970,11 +970,28 @@ class TrainEngine:
                 if hi > pos:
                     rest.append((pos, hi - pos))
                 small[name] = rest
+            # the latent block's finalisation (d sigma, the head-bias gradients: fp32 and bf16 copies) is deferred to the rider that
+            # carries the head region's small pieces: those slots are cut out of its ranges
+            cut = sorted((o, o + (int(np.prod(shp)) + 3) // 4 * 4) for o, shp in
+                         [lay.entries['sigma']] + [lay.entries[f'm{i}.head.b'] for i in range(self.M)])
+            head_rest = []
+            for lo_, ln_ in small['head']:
+                hi_ = lo_ + ln_
+                for c0, c1 in cut:
+                    if c0 >= hi_ or c1 <= lo_:
+                        continue
+                    if c0 > lo_:
+                        head_rest.append((lo_, c0 - lo_))
+                    lo_ = max(lo_, c1)
+                if hi_ > lo_:
+                    head_rest.append((lo_, hi_ - lo_))
+            small['head'] = head_rest
             groups = {'dec2': ['dec2'], 'dec1': ['dec1'], 'enc1': ['dec0', 'head', 'enc1'], 'enc0': ['enc0']}
             rides = {}
             for key, names in groups.items():
                 rg = nv.SqRanges([r for nm in names for r in small[nm]])
-                rides[key] = (self.grad, comm, rg, torch.zeros(rg.blocks, device=self.dev, dtype=torch.float32), None, None)
+                extra = 1 if key == 'enc1' else 0               # (+ the finaliser's slot)
+                rides[key] = (self.grad, comm, rg, torch.zeros(rg.blocks + extra, device=self.dev, dtype=torch.float32), None, None)
             self._direct = {'comm': comm, 'views': lay.views(comm), 'rides': rides}
         return self._direct
 
@@ -983,7 +1000,10 @@ class TrainEngine:
         acc = self.accumulate
         direct = self._direct_setup(allreduce) if isinstance(lat, nv.LatentM) and lat.da2[0] else None
         self._direct_now = direct is not None
-        dr = direct['rides'] if direct else {}
+        dr = dict(direct['rides']) if direct else {}
+        if direct:                     # the finaliser rides with the head region's small pieces (enc1 launch)
+            lat.defer_final = 1
+            dr['enc1'] = dr['enc1'][:5] + (lat,)
         self._wait_wT()
         if self.bf16 and self._wT_stale:          # an optimiser step without a new batch since (tests): refresh here
             self.refresh_weights_bf16(transposes_only=True)
