@@ -568,7 +568,9 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
     const bool dec = !owner && a.g1[mi] != nullptr;
     LSTAMP(a, 0);
     // the W chunk's loads (and the bias of this lane's output column) go out first: their latency hides under phase A
-    const int L4 = L >> 2;
+    // (L % 4 != 0: a W row is not 16-byte aligned and its last quad is ragged -- element loads, the tail zero-filled)
+    const int L4 = (L + 3) >> 2;
+    const bool lvec = (L & 3) == 0;
     float4 wreg[WV];
     float bias = 0.f;
     const int ocol = c0 + ((tid >> 6) % (COLS / 32)) * 32 + (tid & 31);      // phase B: the column of this lane's MFMA results
@@ -577,8 +579,11 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         for (int t = 0; t < WV; ++t) {
             const int f = tid + LF_NT * t, c = f / L4, k4 = f % L4;
             wreg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < COLS * L4 && c0 + c < a.d[mi])
-                wreg[t] = *reinterpret_cast<const float4*>(a.dec0_W[mi] + (long long)(c0 + c) * L + 4 * k4);
+            if (f < COLS * L4 && c0 + c < a.d[mi]) {
+                const float* wp = a.dec0_W[mi] + (long long)(c0 + c) * L + 4 * k4;
+                if (lvec) wreg[t] = *reinterpret_cast<const float4*>(wp);
+                else wreg[t] = make_float4(wp[0], 4 * k4 + 1 < L ? wp[1] : 0.f, 4 * k4 + 2 < L ? wp[2] : 0.f, 4 * k4 + 3 < L ? wp[3] : 0.f);
+            }
         }
         if (ocol < a.d[mi]) bias = a.dec0_b[mi][ocol];
     }
@@ -991,7 +996,7 @@ static int latm_cols(int L) { return L <= 32 ? 256 : (L <= 64 ? 128 : 64); }
 static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
     JAMIE_ARG(a != nullptr, "null descriptor");
     JAMIE_ARG(a->M >= 2 && a->M <= LM, "2 <= M <= 4");
-    JAMIE_ARG(a->B >= a->M && a->L >= 4 && a->L % 4 == 0 && a->L <= 128, "B >= M (KL uses rows 0..M-1), L a multiple of 4, <= 128");
+    JAMIE_ARG(a->B >= a->M && a->L >= 1 && a->L <= 128, "B >= M (KL uses rows 0..M-1), 1 <= L <= 128");
     JAMIE_ARG((a->B + LF_ROWS - 1) / LF_ROWS <= JAMIE_MAX_PARTIALS, "B too large for the partial buffer");
     JAMIE_ARG(a->sigma && a->hyper && a->partials && a->comb, "null pointer");
     memset(&d, 0, sizeof(d));
@@ -1004,8 +1009,8 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
         d.mu[i] = a->mu[i]; d.lv[i] = a->lv[i]; d.z[i] = a->z[i]; d.eps[i] = a->eps[i];
         d.dcomb[i] = a->dcomb[i]; d.dml[i] = a->dml[i];
         d.g1[i] = a->g1[i]; d.dec0_W[i] = a->dec0_W[i]; d.dec0_b[i] = a->dec0_b[i]; d.d[i] = a->d[i];
-        JAMIE_ARG(!a->g1[i] || (a->dec0_W[i] && a->dec0_b[i] && a->d[i] > 0 && ((uintptr_t)a->dec0_W[i] % 16) == 0),
-                  "decoder layer 0: W (16-byte aligned), b, d");
+        JAMIE_ARG(!a->g1[i] || (a->dec0_W[i] && a->dec0_b[i] && a->d[i] > 0 && (a->L % 4 != 0 || ((uintptr_t)a->dec0_W[i] % 16) == 0)),
+                  "decoder layer 0: W (16-byte aligned when L is a multiple of 4), b, d");
         d.comb_alias[i] = a->comb_alias[i] == a->comb ? nullptr : a->comb_alias[i];
         d.dml_bf16[i] = (unsigned short*)a->dml_bf16[i]; d.dmlT_bf16[i] = (unsigned short*)a->dmlT_bf16[i];
         d.comb_bf16[i] = (unsigned short*)a->comb_bf16[i]; d.combT_bf16[i] = (unsigned short*)a->combT_bf16[i];

@@ -139,6 +139,8 @@ class TrainEngine:
         if self.bf16 and any(v % 8 for v in list(self.dims) + [L, B]):
             raise ValueError('bf16 compute needs feature counts, latent size and batch size that are multiples of 8 '
                              '(build the model with pad_features=8 for other feature counts)')
+        if self.M > 2 and L > 128:      # (the M-modality latent kernels keep a cell's latent row in registers / LDS)
+            raise ValueError(f'more than two modalities need output_dim <= 128 (got {L})')
         self.cosine = dist_method == 'cosine'
         if dist_method not in ('euclidean', 'cosine'):
             raise ValueError("dist_method must be 'euclidean' or 'cosine' (jamie.py:483-502)")
@@ -169,7 +171,7 @@ class TrainEngine:
         self.reset_best()
         self.lat_partials = torch.zeros(20 * nv.load().jamie_max_partials(), **f32)
         self.lat_ticket = torch.zeros(4, dtype=torch.int32, device=self.dev)
-        self.lat_colpart = torch.zeros(int(nv.load().jamie_latent_m_colpart_size(B, L)) if (L % 4 == 0 and L <= 128) else 1, **f32)
+        self.lat_colpart = torch.zeros(int(nv.load().jamie_latent_m_colpart_size(B, L)) if L <= 128 else 1, **f32)
         # ---- per-modality workspace ----
         self.ws = []
         # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
@@ -751,7 +753,7 @@ class TrainEngine:
     def _fused_latent(self, corr, Fblk):
         if self.M == 2 and os.environ.get('JAMIE_NO_FUSED_LATENT') == '1':      # A/B switch (tools/ab.sh): the general kernels
             return False
-        return corr is None and Fblk is None and not self.cosine and self.L % 4 == 0 and self.L <= 128
+        return corr is None and Fblk is None and not self.cosine and self.L <= 128
 
     def _latent_desc(self, corr, Fblk, noise, fused=False):
         if self.M != 2 or fused:
@@ -1264,6 +1266,22 @@ class TrainEngine:
         nv.replay(plan)
         self.m.num_batches_tracked += 1
         self._timing_step += 1
+
+    def operand_precision(self, corr=None, Fblk=None, allreduce=None):
+        """What bf16 compute mode rounds, for parity tests that restate the step with the same roundings (the oracle's
+        `emulate` argument): ({layer: (fwd, dx, dw)}, grad_bf16).  True = that product of the Linear layer -- forward
+        y = a W^T, input gradient dx = dy W, weight gradient dW = dy^T a -- reads bf16 operands (rounded to nearest even once,
+        where the producing kernel stores them; fp32 accumulation); `grad_bf16`: the optimiser reads every gradient rounded to
+        bf16 while the clip norm is taken from the fp32 values.  With identity correspondence the fused latent launches compute
+        decoder layer 0's forward product and the heads' input gradient in exact fp32.  fp32 mode: (None, False)."""
+        if not self.bf16:
+            return None, False
+        fused = self.M != 2 or self._fused_latent(corr, Fblk)
+        da2 = fused and self._fuse_da2()
+        prec = {k: (True, True, True) for k in ('enc0', 'enc1', 'dec1', 'dec2')}
+        prec['head'] = (True, not da2, True)
+        prec['dec0'] = (not fused, True, True)
+        return prec, bool(self.grad_bf16 and self.fused_norm and allreduce is None and not self.accumulate)
 
     def adam_bytes_per_param(self):
         """Algorithmic HBM bytes per parameter of one clip + Adam launch: read p, g, m, v; write p, m, v (fp32; the

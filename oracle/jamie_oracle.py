@@ -132,12 +132,69 @@ def draw_noise(input_dim, output_dim, B, p, dtype=torch.float32):
     return noise
 
 
+
+# --------------------------------------------------------------------------------------------
+# bf16-operand emulation (NOT in the reference, which is fp32 throughout: this restates what the HIP path's bf16 compute
+# mode does to the SAME algorithm, so that the benchmarked arithmetic can be compared tightly instead of against the
+# fp32 oracle at bf16 tolerances).  A Linear layer has three products -- forward y = a W^T, input gradient dx = dy W,
+# weight gradient dW = dy^T a (autograd of model.py:151 etc. via jamie.py:734) -- and the HIP step rounds the OPERANDS of a
+# product to bf16 (round to nearest even, once, where the producer stores them) and accumulates in fp32; everything else
+# (bias add, BatchNorm, LeakyReLU, dropout, latent block, losses, bias gradients) stays fp32.  `emulate` maps a layer key
+# ('enc0', 'enc1', 'head', 'dec0', 'dec1', 'dec2') to (fwd, dx, dw) booleans: True = that product reads bf16 operands.
+# `TrainEngine.operand_precision()` reports the map of the launch plan under test.
+# --------------------------------------------------------------------------------------------
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _LinearEmulated(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, W, b, fwd, dx, dw):
+        ctx.save_for_backward(a, W)
+        ctx.flags = (dx, dw)
+        if fwd:
+            return F.linear(bf16_round(a), bf16_round(W), b)
+        return F.linear(a, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, W = ctx.saved_tensors
+        dx, dw = ctx.flags
+        dyb = bf16_round(dy) if (dx or dw) else None
+        da = (dyb @ bf16_round(W)) if dx else dy @ W
+        dW = (dyb.t() @ bf16_round(a)) if dw else dy.t() @ a
+        return da, dW, dy.sum(0), None, None, None
+
+
+def _layer_key(name):
+    """Reference parameter prefix -> layer key: 'encoders.i.0' enc0, 'encoders.i.4' enc1, 'fc_mus.i' / 'fc_vars.i' head,
+    'decoders.i.0' dec0, 'decoders.i.4' dec1, 'decoders.i.8' dec2."""
+    parts = name.split('.')
+    if parts[0] in ('fc_mus', 'fc_vars'):
+        return 'head'
+    return {'encoders': 'enc', 'decoders': 'dec'}[parts[0]] + {'0': '0', '4': '1', '8': '2'}[parts[2]]
+
+
+def linear(P, name, h, emulate=None):
+    """`F.linear(h, P[name.weight], P[name.bias])`, or its bf16-operand emulation when `emulate` names the layer."""
+    W, b = P[name + '.weight'], P[name + '.bias']
+    flags = None if emulate is None else emulate.get(_layer_key(name))
+    if flags is None or not any(flags):
+        return F.linear(h, W, b)
+    return _LinearEmulated.apply(h, W, b, bool(flags[0]), bool(flags[1]), bool(flags[2]))
+
+
+# What the fused bf16 launch plan of the HIP step does at every BASELINE size (identity correspondence, F = 0): decoder layer 0's
+# forward product and the heads' input gradient are exact fp32 inside the fused latent kernels, every other product is bf16.
+EMULATE_HIP_BF16_FUSED = {'enc0': (True, True, True), 'enc1': (True, True, True), 'head': (True, False, True),
+                          'dec0': (False, True, True), 'dec1': (True, True, True), 'dec2': (True, True, True)}
+
 # --------------------------------------------------------------------------------------------
 # forward
 # --------------------------------------------------------------------------------------------
-def _block(h, P, Bf, lin, bn, train, p, mask):
+def _block(h, P, Bf, lin, bn, train, p, mask, emulate=None):
     """Linear -> BatchNorm1d -> LeakyReLU -> Dropout (model.py:151-154 and siblings)."""
-    h = F.linear(h, P[lin + '.weight'], P[lin + '.bias'])
+    h = linear(P, lin, h, emulate)
     h = F.batch_norm(h, Bf[bn + '.running_mean'], Bf[bn + '.running_var'], P[bn + '.weight'],
                      P[bn + '.bias'], training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
     if train:
@@ -149,28 +206,28 @@ def _block(h, P, Bf, lin, bn, train, p, mask):
     return h
 
 
-def encode(P, Bf, i, x, train=False, p=0., masks=(None, None)):
+def encode(P, Bf, i, x, train=False, p=0., masks=(None, None), emulate=None):
     """model.py:222-223 (Sequential at :149-165)."""
-    h = _block(x, P, Bf, f'encoders.{i}.0', f'encoders.{i}.1', train, p, masks[0])
-    return _block(h, P, Bf, f'encoders.{i}.4', f'encoders.{i}.5', train, p, masks[1])
+    h = _block(x, P, Bf, f'encoders.{i}.0', f'encoders.{i}.1', train, p, masks[0], emulate)
+    return _block(h, P, Bf, f'encoders.{i}.4', f'encoders.{i}.5', train, p, masks[1], emulate)
 
 
-def decode(P, Bf, i, c, train=False, p=0., masks=(None, None)):
+def decode(P, Bf, i, c, train=False, p=0., masks=(None, None), emulate=None):
     """model.py:261-262 (Sequential at :190-207)."""
-    h = _block(c, P, Bf, f'decoders.{i}.0', f'decoders.{i}.1', train, p, masks[0])
-    h = _block(h, P, Bf, f'decoders.{i}.4', f'decoders.{i}.5', train, p, masks[1])
-    return F.linear(h, P[f'decoders.{i}.8.weight'], P[f'decoders.{i}.8.bias'])
+    h = _block(c, P, Bf, f'decoders.{i}.0', f'decoders.{i}.1', train, p, masks[0], emulate)
+    h = _block(h, P, Bf, f'decoders.{i}.4', f'decoders.{i}.5', train, p, masks[1], emulate)
+    return linear(P, f'decoders.{i}.8', h, emulate)
 
 
-def refactor(P, hs, train, eps, index=None):
+def refactor(P, hs, train, eps, index=None, emulate=None):
     """model.py:225-243.  NB returns `logvar` of the LAST modality only (:243)."""
     if index is None:
         index = range(len(hs))
     zs, mus = [], []
     logvar = None
     for h, i in zip(hs, index):
-        mu = F.linear(h, P[f'fc_mus.{i}.weight'], P[f'fc_mus.{i}.bias'])
-        logvar = F.linear(h, P[f'fc_vars.{i}.weight'], P[f'fc_vars.{i}.bias'])
+        mu = linear(P, f'fc_mus.{i}', h, emulate)
+        logvar = linear(P, f'fc_vars.{i}', h, emulate)
         std = torch.exp(logvar / 2)
         if not train:
             zs.append(mu)
@@ -204,16 +261,16 @@ def combine(P, zs, corr):
     return out
 
 
-def forward(P, Bf, X, corr, train=False, p=0., noise=None):
+def forward(P, Bf, X, corr, train=False, p=0., noise=None, emulate=None):
     """edModelVar.forward, model.py:264-275."""
     M = len(X)
     enc_masks = noise['enc_masks'] if (train and noise is not None) else [(None, None)] * M
     dec_masks = noise['dec_masks'] if (train and noise is not None) else [(None, None)] * M
     eps = noise['eps'] if (train and noise is not None) else None
-    hs = [encode(P, Bf, i, X[i], train, p, enc_masks[i]) for i in range(M)]
-    zs, mus, logvar = refactor(P, hs, train, eps)
+    hs = [encode(P, Bf, i, X[i], train, p, enc_masks[i], emulate) for i in range(M)]
+    zs, mus, logvar = refactor(P, hs, train, eps, emulate=emulate)
     combined = combine(P, zs, corr)
-    X_hat = [decode(P, Bf, i, combined[i], train, p, dec_masks[i]) for i in range(M)]
+    X_hat = [decode(P, Bf, i, combined[i], train, p, dec_masks[i], emulate) for i in range(M)]
     return zs, combined, X_hat, mus, logvar
 
 
@@ -338,10 +395,13 @@ class Adam:
 # one training step and the full loop
 # --------------------------------------------------------------------------------------------
 def train_step(P, Bf, opt, X, corr, Fblk, noise, p, anneal, loss_weights=None,
-               dist_method='euclidean', do_step=True, return_grads=False):
+               dist_method='euclidean', do_step=True, return_grads=False, emulate=None, grad_bf16=False):
     """One iteration of the inner loop of project_jamie (jamie.py:611-741): forward, four losses,
-    backward, clip, Adam.  `P` values must be leaf tensors with requires_grad=True."""
-    zs, comb, X_hat, mus, logvars = forward(P, Bf, X, corr, train=True, p=p, noise=noise)
+    backward, clip, Adam.  `P` values must be leaf tensors with requires_grad=True.
+    `emulate` (see `linear`): bf16-operand emulation of the HIP path's bf16 compute mode; `grad_bf16`: every gradient is
+    rounded to bf16 once before the optimiser reads it while the clip norm is taken from the unrounded values (the HIP
+    path's bf16 weight-gradient buffer)."""
+    zs, comb, X_hat, mus, logvars = forward(P, Bf, X, corr, train=True, p=p, noise=noise, emulate=emulate)
     ls = losses(X, zs, comb, X_hat, mus, logvars, Fblk, anneal, dist_method)
     if loss_weights is not None:
         total = sum(lo * wt for lo, wt in zip(ls, loss_weights))
@@ -359,7 +419,13 @@ def train_step(P, Bf, opt, X, corr, Fblk, noise, p, anneal, loss_weights=None,
         out['grads'] = OrderedDict((k, g.clone()) for k, g in zip(names, grads))
     if do_step:
         with torch.no_grad():
-            out['grad_norm'] = float(clip_grad_norm(grads))
+            if grad_bf16:
+                total_norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2.0)), 2.0)
+                coef = torch.clamp(CLIP_NORM / (total_norm + 1e-6), max=1.0)
+                grads = [bf16_round(g) * coef for g in grads]
+                out['grad_norm'] = float(total_norm)
+            else:
+                out['grad_norm'] = float(clip_grad_norm(grads))
             opt.step(grads)
     return out
 

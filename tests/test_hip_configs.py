@@ -54,18 +54,74 @@ def _grad(eng, model, ref):
     return (g if sl is None else g[sl]).cpu().numpy()
 
 
-def _check_first_adam_step(eng, model, init_flat, lr=1e-3):
+def _check_first_adam_step(eng, model, init_flat, lr=1e-3, norm=None):
     """clip_grad_norm_(1) + the FIRST Adam step restated on the engine's own gradient (jamie.py:739-741):
     coef = min(1, 1 / (||g|| + 1e-6)); m_hat = g c, v_hat = (g c)^2  ->  p = p0 - lr g c / (|g c| + 1e-8).
     Against the oracle's post-step weights only the bulk can agree: an element whose gradient is rounding noise
     (|g| <~ 1e-8: ~1 % of the BatchNorm shifts at these sizes, where gradients are O(1e-6)) moves by anything in
     [-lr, lr] in two correct fp32 implementations.  This check has no such freedom."""
     g = eng.grad_flat().double()
-    coef = min(1.0, 1.0 / (float(g.norm()) + 1e-6))
+    # (`norm`: the clip norm the engine itself used -- with bf16 weight gradients it is the norm of the fp32 accumulators, not
+    #  of the rounded values the optimiser reads)
+    coef = min(1.0, 1.0 / ((float(g.norm()) if norm is None else norm) + 1e-6))
     gc = g * coef
     want = init_flat.double() - lr * gc / (gc.abs() + 1e-8)
     err = (model.flat.double() - want).abs() - 1.2e-7 * want.abs()          # fp32 rounding of the stored parameter
     assert float(err.max()) < 2e-9 + 2e-6 * lr, float(err.max())
+
+
+def _clone_state(P, Bf):
+    P2 = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    return P2, {k: v.clone() for k, v in Bf.items()}
+
+
+def _bf16_step_vs_emulating_oracle(eng, model, P, Bf, X, corr, noise, p, anneal, init_flat):
+    """The TIGHT parity check of the benchmarked arithmetic (bf16 GEMM operands, fp32 accumulation, bf16 weight
+    gradients): the oracle restates the step with THE SAME roundings (`orc.train_step(emulate=, grad_bf16=)`: the operands of
+    every product the engine reports as bf16 are rounded to nearest even where the HIP kernels store them; everything else
+    fp32), so what is left between the two is fp32 summation order, a handful of LeakyReLU-kink / bf16-tie crossings, and
+    nothing a wrong scale or a mis-rounded slab could hide behind.  Called after `eng.forward_backward` on the same batch
+    and noise, BEFORE the optimiser step.  Losses 2e-3 (measured ~1e-5), every gradient tensor 1e-2 in relative L2 (measured
+    ~1e-3 and below), the clip norm 1e-3, then the first Adam step exactly (restated on the engine's own gradient and norm)
+    and its direction against the oracle's update."""
+    prec, gbf = eng.operand_precision(None if corr is None or torch.equal(corr, torch.eye(corr.shape[0])) else corr)
+    assert prec is not None and gbf == bool(eng.grad_bf16)
+    init = {k: v.detach().clone() for k, v in P.items()}
+    st = orc.train_step(P, Bf, orc.Adam(P.values(), 1e-3), X, corr, None, noise, p, anneal, return_grads=True,
+                        emulate=prec, grad_bf16=gbf)
+    ls = eng.read_losses()[0]
+    np.testing.assert_allclose(ls, st['losses'], rtol=2e-3, atol=1e-6)
+    for i in range(len(X)):
+        assert_mostly_close(eng.ws[i]['mu'].cpu().numpy(), st['mus'][i].numpy(), rtol=0, atol=0, max_bad_frac=1.0,
+                            rel_l2=2e-3, msg=f'mu{i}')
+    worst = 0.0
+    for ref in P:
+        if orc.is_dead_bias(ref):
+            continue
+        want = st['grads'][ref]
+        if gbf and want.dim() == 2:          # the large matrices live in the bf16 gradient buffer: rounded once
+            want = orc.bf16_round(want)
+        got = _grad(eng, model, ref)
+        assert_mostly_close(got, want.numpy(), rtol=0, atol=0, max_bad_frac=1.0, rel_l2=1e-2, msg=ref)
+        worst = max(worst, float(np.linalg.norm(got - want.numpy()) / max(1e-30, np.linalg.norm(want.numpy()))))
+    eng.optimizer_step()
+    if eng.fused_norm:
+        n_live = eng.n_dw_partials + eng.sq_ranges.blocks
+        norm = float(torch.sqrt(eng.norm_partials[:n_live].double().sum()))
+    else:
+        norm = float(eng.grad_flat().double().norm())
+    assert abs(norm - st['grad_norm']) < 1e-3 * st['grad_norm'], (norm, st['grad_norm'])
+    _check_first_adam_step(eng, model, init_flat, norm=norm)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if orc.is_dead_bias(k) or v.dim() != 2:
+            continue
+        du, dr = sd[k].cpu() - init[k], v.detach() - init[k]
+        # Adam's first step is lr * sign(g) wherever |g| >> 1e-8: the same direction as the oracle's except where a gradient
+        # element is rounding noise around zero
+        agree = float((torch.sign(du) == torch.sign(dr)).float().mean())
+        assert agree > 0.995, (k, agree)
+    return worst
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -86,12 +142,14 @@ def test_config2_bf16_full_size_step_vs_oracle(jam):
     torch.manual_seed(42)
     noise = orc.draw_noise(dims, L, B, p)
     init = {k: v.detach().clone() for k, v in P.items()}
+    P_e, Bf_e = _clone_state(P, Bf)
+    init_flat = model.flat.clone()
     st = orc.train_step(P, Bf, opt, X, torch.eye(B), torch.zeros(B, B), noise, p, 0.5, return_grads=True)
     eng.set_batch([x.cuda() for x in X])
     eng.set_kl_anneal(0.5)
     eng.forward_backward(None, None, _noise_to_dev(noise, p))
     ls, total, _ = eng.read_losses()
-    np.testing.assert_allclose(ls, st['losses'], rtol=2e-2, atol=1e-5)
+    np.testing.assert_allclose(ls, st['losses'], rtol=2e-2, atol=1e-5)          # (how far bf16 operands are from fp32)
     for i in range(2):        # latents behind three bf16 products
         assert_mostly_close(eng.ws[i]['mu'].cpu().numpy(), st['mus'][i].numpy(), rtol=0, atol=0, max_bad_frac=1.0,
                             rel_l2=3e-2, msg=f'mu{i}')
@@ -101,7 +159,8 @@ def test_config2_bf16_full_size_step_vs_oracle(jam):
         assert_mostly_close(_grad(eng, model, ref), st['grads'][ref].numpy(), rtol=0, atol=0, max_bad_frac=1.0,
                             rel_l2=1e-1, msg=ref)
     want = float(eng.grad_flat().double().norm())
-    eng.optimizer_step()
+    # ... and the tight check: the oracle with the same operand roundings (optimiser step included)
+    _bf16_step_vs_emulating_oracle(eng, model, P_e, Bf_e, X, torch.eye(B), noise, p, 0.5, init_flat)
     n_live = eng.n_dw_partials + eng.sq_ranges.blocks
     got = float(torch.sqrt(eng.norm_partials[:n_live].double().sum()))
     assert abs(got - want) < 5e-6 * want, (got, want)
@@ -150,6 +209,89 @@ def test_config2_plan_replay_equals_eager_at_full_size(jam, mode):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# C1 at its own workload: 5k cells x (200, 100), latent 16, B = 512 > min(features) => sampling WITH replacement
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_config1_own_workload_step_vs_oracle(jam, mode):
+    """BASELINE config 1 as the reference would run it: (200, 100) features, latent 16, B = 512.  `replace = min(features) <
+    batch_size` (jamie.py:553, sic) is TRUE here, so the batch holds duplicate cells and the correspondence block
+    `P[idx][:, idx]` row-normalised (jamie.py:586-589) is a general [B, B] matrix: the general latent kernels
+    (`small_mm` on the exact-fp32 MFMA), not the fused identity path.  fp32: one step against the oracle (latents, losses,
+    every gradient, post-step weights).  bf16 (100 features padded to 104): against the oracle with the same operand
+    roundings -- here decoder layer 0 and the heads' input gradient are bf16 products too."""
+    B, dims, L, N = 512, (200, 100), 16, 5000
+    model, eng, P, Bf = _pair(jam, dims, L, B, mode, seed=13)
+    p = model.dropout
+    assert p == 0.6 and model.num_parameters() == 420166
+    data = _synth(N, dims, seed=1)
+    idx = np.random.default_rng(7).integers(0, N, B)                 # with replacement
+    assert len(np.unique(idx)) < B
+    corr = orc.p_block(None, idx, idx)
+    assert not torch.equal(corr, torch.eye(B)) and float(corr.sum(1).min()) > 0.999
+    X = [d[idx] for d in data]
+    torch.manual_seed(5)
+    noise = orc.draw_noise(dims, L, B, p)
+    init_flat = model.flat.clone()
+    eng.set_batch([x.cuda() for x in X])
+    eng.set_kl_anneal(0.5)
+    eng.forward_backward(corr.cuda().contiguous(), None, _noise_to_dev(noise, p))
+    if mode == 'bf16':
+        prec, _ = eng.operand_precision(corr)
+        assert prec['dec0'][0] and prec['head'][1]                   # general correspondence: no fused fp32 products
+        _bf16_step_vs_emulating_oracle(eng, model, P, Bf, X, corr, noise, p, 0.5, init_flat)
+        return
+    st = orc.train_step(P, Bf, orc.Adam(P.values(), 1e-3), X, corr, None, noise, p, 0.5, return_grads=True)
+    for i in range(2):
+        np.testing.assert_allclose(eng.ws[i]['z'].cpu().numpy(), st['zs'][i].numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(eng.ws[i]['comb'].cpu().numpy(), st['combined'][i].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(eng.read_losses()[0], st['losses'], rtol=2e-4, atol=1e-6)
+    for ref in P:
+        if not orc.is_dead_bias(ref):
+            assert_mostly_close(_grad(eng, model, ref), st['grads'][ref].numpy(), rtol=0, atol=0, max_bad_frac=1.0,
+                                rel_l2=2e-3, msg=ref)
+    eng.optimizer_step()
+    _check_first_adam_step(eng, model, init_flat)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not orc.is_dead_bias(k):
+            assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=2e-2,
+                                rel_l2=1e-2 if v.dim() == 1 else 5e-4, msg=k)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_config1_own_workload_plan_replay_equals_eager(jam, mode):
+    """The recorded plan bench.py --config c1 replays (device sampler WITH replacement, correspondence block from the
+    indices, general latent kernels) equals eager stepping bit for bit, and the drawn batches do contain duplicates."""
+    from jamie_amd import _native as nv
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    dims, L, B, N = (200, 100), 16, 512, 5000
+    flats, losses = [], []
+    for use_plan in (False, True):
+        torch.manual_seed(9)
+        model = edModelVar(dims, L, pad_features=8 if mode == 'bf16' else 1)
+        eng = TrainEngine(model, B, compute_dtype=mode, seed=21)
+        data = eng.pad_cells([x.cuda().contiguous() for x in _synth(N, dims, seed=3)])
+        eng.set_kl_anneal(0.5)
+        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+        if use_plan:
+            plan = eng.make_plan(data, idx, N, replace=True)
+            for _ in range(3):
+                eng.run_plan(plan)
+        else:
+            for _ in range(4):
+                nv.sample_indices(idx, N, 0, True, eng.state, 200)
+                eng.load_batch(data, [idx, idx])
+                nv.corr_from_indices(idx, idx, eng.corr)
+                eng.step(eng.corr)
+        assert len(torch.unique(idx)) < B and int(idx.min()) >= 0 and int(idx.max()) < N
+        flats.append(model.flat.clone())
+        losses.append(eng.read_losses()[0])
+    assert torch.equal(flats[0], flats[1])
+    assert losses[0] == losses[1] and np.isfinite(losses[0]).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
 # C4: three modalities at (2000, 1000, 500), latent 64
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
@@ -166,6 +308,7 @@ def test_config4_full_size_step_vs_generalised_oracle(jam, mode):
     X = _synth(B, dims, seed=4)
     torch.manual_seed(77)
     noise = orc.draw_noise(dims, L, B, p)
+    P_e, Bf_e = _clone_state(P, Bf)
     st = orc.train_step(P, Bf, opt, X, None, None, noise, p, 0.6, return_grads=True)
     init_flat = model.flat.clone()
     eng.set_batch([x.cuda() for x in X])
@@ -179,7 +322,10 @@ def test_config4_full_size_step_vs_generalised_oracle(jam, mode):
             continue
         assert_mostly_close(_grad(eng, model, ref), st['grads'][ref].numpy(), rtol=0, atol=0, max_bad_frac=1.0,
                             rel_l2=1e-1 if bf else 2e-3, msg=ref)
-    eng.optimizer_step()
+    if bf:        # the tight check against the oracle with the same operand roundings (runs the optimiser step)
+        _bf16_step_vs_emulating_oracle(eng, model, P_e, Bf_e, X, None, noise, p, 0.6, init_flat)
+    else:
+        eng.optimizer_step()
     gnorm = float(eng.grad_flat().double().norm())
     # 2e-3 like the gradients: an activation within rounding of the LeakyReLU kink takes the other branch in two correct fp32
     # implementations (profiles/r02_c5_grad_error_vs_fp64.log: the HIP step and the fp32 CPU oracle each differ from an
@@ -314,27 +460,126 @@ def test_config5_dims_step_vs_oracle(jam):
                                 rel_l2=1e-2 if v.dim() == 1 else 5e-4, msg=k)
 
 
-def test_config5_dims_bf16_step_runs_and_tracks_oracle_losses(jam):
+def test_config5_dims_bf16_step_vs_emulating_oracle(jam):
     """Config 5's dimensions in bf16 compute (DESIGN quotes its throughput): the losses of one step within 2 % of the
-    fp32 oracle's, and the fused gradient norm equals ||g||."""
+    fp32 oracle's (the distance of bf16 operands from fp32), then losses / every gradient tensor / clip norm / first Adam
+    step against the oracle WITH THE SAME OPERAND ROUNDINGS, and the fused gradient norm equals ||g||."""
     B, dims, L, p = 512, (5000, 2000), 64, 0.6
     model, eng, P, Bf = _pair(jam, dims, L, B, 'bf16')
     X = _synth(B, dims, seed=5)
     torch.manual_seed(43)
     noise = orc.draw_noise(dims, L, B, p)
+    P_e, Bf_e = _clone_state(P, Bf)
     with torch.no_grad():
         zs, comb, X_hat, mus, lv = orc.forward(P, Bf, X, torch.eye(B), train=True, p=p, noise=noise)
         want = [float(v) for v in orc.losses(X, zs, comb, X_hat, mus, lv, None, 0.5)]
+    del P, Bf
+    init_flat = model.flat.clone()
     eng.set_batch([x.cuda() for x in X])
     eng.set_kl_anneal(0.5)
     eng.forward_backward(None, None, _noise_to_dev(noise, p))
     ls = eng.read_losses()[0]
     np.testing.assert_allclose(ls, want, rtol=2e-2, atol=1e-5)
     gn = float(eng.grad_flat().double().norm())
-    eng.optimizer_step()
+    _bf16_step_vs_emulating_oracle(eng, model, P_e, Bf_e, X, torch.eye(B), noise, p, 0.5, init_flat)
     if eng.fused_norm:
         n_live = eng.n_dw_partials + eng.sq_ranges.blocks
         assert abs(float(torch.sqrt(eng.norm_partials[:n_live].double().sum())) - gn) < 5e-6 * gn
+
+
+# ------------------------------------------------------------------------------------------------------------
+# C5's ROW count: 1 000 000 cells x (5000, 2000) resident on one GPU (28 GB of fp32 + the raw copy): the 64-bit index paths
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def million_cells(jam):
+    """Raw and device-standardised [1 000 000, 5000] / [1 000 000, 2000] fp32 matrices (56 GB of the 288 GB in all),
+    generated on the GPU chunk by chunk; freed when the module's tests are done."""
+    from jamie_amd import _native as nv
+    N, dims = 1_000_000, (5000, 2000)
+    gen = torch.Generator(device='cuda').manual_seed(17)
+    raw, std, stats = [], [], []
+    for d in dims:
+        x = torch.empty(N, d, device='cuda', dtype=torch.float32)
+        scale = 0.5 + torch.rand(d, device='cuda', generator=gen)
+        shift = torch.randn(d, device='cuda', generator=gen)
+        for r0 in range(0, N, 100_000):
+            x[r0:r0 + 100_000].normal_(generator=gen).mul_(scale).add_(shift)
+        out, mean, sd = nv.standardise_columns(x)
+        raw.append(x); std.append(out); stats.append((mean, sd, scale, shift))
+    torch.cuda.synchronize()
+    yield N, dims, raw, std, stats
+    del raw, std, stats
+    torch.cuda.empty_cache()
+
+
+def test_million_cells_device_standardise(jam, million_cells):
+    """`jamie_col_stats` / `jamie_standardise` (preclass(axis=0), utilities.py:654-678) over 5e9 elements: element offsets pass
+    2^31 at row 429 497 of the 5000-feature matrix and byte offsets pass 2^32 at row 214 749.  Statistics against torch in
+    float64 on a set of columns, the standardised values against (x - mean) / std on rows on both sides of those marks."""
+    N, dims, raw, std, stats = million_cells
+    for i, d in enumerate(dims):
+        mean, sd, scale, shift = stats[i]
+        cols = torch.tensor([0, 1, d // 3, d - 2, d - 1], device='cuda')
+        sub = raw[i][:, cols].double()
+        np.testing.assert_allclose(mean[cols].cpu().numpy(), sub.mean(0).cpu().numpy(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(sd[cols].cpu().numpy(), sub.std(0, unbiased=False).cpu().numpy(), rtol=1e-9)
+        assert float((mean.float() - shift).abs().max()) < 0.02 and float((sd.float() / scale - 1).abs().max()) < 0.01
+        rows = torch.tensor([0, 214_748, 214_749, 429_496, 429_497, 429_498, 858_993, N - 2, N - 1], device='cuda')
+        want = ((raw[i][rows].double() - mean) / sd).float()
+        assert torch.equal(std[i][rows], want) or float((std[i][rows] - want).abs().max()) < 1e-6
+        # a full pass: every standardised column has mean 0 and population std 1
+        m = std[i].mean(0, dtype=torch.float64)
+        assert float(m.abs().max()) < 1e-5
+        q = torch.zeros(d, device='cuda', dtype=torch.float64)
+        for r0 in range(0, N, 100_000):
+            q += std[i][r0:r0 + 100_000].double().square().sum(0)
+        assert float((q / N - 1).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_million_cells_sampler_gather_and_steps(jam, million_cells, mode):
+    """BASELINE config 5's row count on one GPU: the device sampler draws B = 512 DISTINCT rows of 1 000 000 without
+    replacement (jamie.py:553-556: min(features) = 2000 >= 512), the gather (fp32 rows; bf16 mode: + the bf16 copy) returns
+    exactly `data[idx]` -- also for hand-picked rows beyond element offset 2^31 and byte offset 2^32 and the last row --, and three
+    recorded-plan steps at (5000, 2000), latent 64 stay finite and keep drawing from the whole range."""
+    from jamie_amd import _native as nv
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    N, dims, raw, std, stats = million_cells
+    B, L = 512, 64
+    torch.manual_seed(3)
+    model = edModelVar(dims, L)
+    eng = TrainEngine(model, B, compute_dtype=mode, seed=5)
+    idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+    picked = torch.tensor([0, 214_748, 214_749, 429_496, 429_497, 429_498, 536_871, 858_993, 999_998, N - 1], dtype=torch.int32)
+    idx[:picked.numel()] = picked.cuda()
+    idx[picked.numel():] = torch.arange(600_000, 600_000 + B - picked.numel(), dtype=torch.int32, device='cuda') * 1
+    eng.load_batch(std, [idx, idx])
+    for i in range(2):
+        assert torch.equal(eng.ws[i]['x'], std[i][idx.long()])
+        if mode == 'bf16':
+            assert torch.equal(eng.ws[i]['x_bf'], std[i][idx.long()].to(torch.bfloat16))
+    seen_hi = 0
+    for _ in range(3):
+        nv.sample_indices(idx, N, 0, False, eng.state, 200)
+        eng.load_batch(std, [idx, idx])
+        assert len(torch.unique(idx)) == B and int(idx.min()) >= 0 and int(idx.max()) < N
+        seen_hi += int((idx > 429_497).sum())
+        for i in range(2):
+            assert torch.equal(eng.ws[i]['x'], std[i][idx.long()])
+        eng.step()
+    assert seen_hi > 3 * B // 4                                   # (57 % of the rows lie beyond 2^31 elements)
+    plan = eng.make_plan(std, idx, N)
+    for _ in range(3):
+        eng.run_plan(plan)
+    ls, total, _ = eng.read_losses()
+    assert np.isfinite(ls).all() and np.isfinite(total)
+    assert len(torch.unique(idx)) == B and int(idx.max()) < N and int(idx.max()) > 429_497
+    if eng._plan_keep[1] is not None:      # the plan's gather rode in clip + Adam: the batch in the workspace is the NEXT one
+        for i in range(2):
+            assert torch.equal(eng.ws[i]['x'], std[i][idx.long()])
+    del eng, model, plan
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -415,7 +660,7 @@ def test_eval_more_rows_than_one_chunk_vs_oracle(jam):
 # the loop users call, against the reference's fixtures
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('name', ['g3_multistep', 'g4_replace', 'g5_F_pfratio', 'g6_zeros', 'g7_cosine', 'g8_klquirk',
-                                  'g9_earlystop'])
+                                  'g9_earlystop', 'g10_midsize'])
 def test_facade_loop_replays_reference_fixture(jam, name):
     """`JAMIE.fit_transform` itself (not the engine driven by the test) under `np.random.seed(meta.np_seed)` with the
     fixture's dropout masks / eps fed through the facade's noise seam, against the reference run that produced the fixture

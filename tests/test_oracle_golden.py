@@ -195,3 +195,54 @@ def test_prime_dual_oracle_vs_reference_golden(name):
         np.testing.assert_allclose(Ky, g['dist1'], rtol=0, atol=1e-12)
     F = orc.prime_dual(Kx, Ky, m['dx'], m['dy'], m['epoch_pd'], m['rho'], m['epsilon'], m['delay'])
     np.testing.assert_allclose(F, g['F'], rtol=1e-6, atol=1e-9)
+
+
+# ---- bf16-operand emulation (the checker of the HIP path's bf16 compute mode; not a feature of the reference) ----
+def test_emulation_switched_off_is_the_plain_oracle_and_linear_rounds_operands_only():
+    torch.manual_seed(4)
+    dims, L, B, p = (40, 24), 8, 32, 0.6
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    X = [torch.randn(B, d) for d in dims]
+    noise = orc.draw_noise(dims, L, B, p)
+    P2 = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
+    Bf2 = OrderedDict((k, v.clone()) for k, v in Bf.items())
+    a = orc.train_step(P, Bf, None, X, torch.eye(B), None, noise, p, .5, do_step=False, return_grads=True)
+    off = {k: (False, False, False) for k in orc.EMULATE_HIP_BF16_FUSED}
+    b = orc.train_step(P2, Bf2, None, X, torch.eye(B), None, noise, p, .5, do_step=False, return_grads=True, emulate=off)
+    assert a['losses'] == b['losses'] and all(torch.equal(a['grads'][k], b['grads'][k]) for k in a['grads'])
+    # one layer by hand: y = bf(a) bf(W)^T + b;  da = bf(dy) bf(W);  dW = bf(dy)^T bf(a);  db = sum(dy) in fp32
+    bf = orc.bf16_round
+    h = torch.randn(B, 40, requires_grad=True)
+    Pl = {'encoders.0.4.weight': torch.randn(24, 40, requires_grad=True), 'encoders.0.4.bias': torch.randn(24, requires_grad=True)}
+    y = orc.linear(Pl, 'encoders.0.4', h, {'enc1': (True, True, True)})
+    W, bb = Pl['encoders.0.4.weight'], Pl['encoders.0.4.bias']
+    assert torch.equal(y, torch.nn.functional.linear(bf(h), bf(W), bb))
+    dy = torch.randn(B, 24)
+    gh, gW, gb = torch.autograd.grad(y, [h, W, bb], dy)
+    assert torch.equal(gh, bf(dy) @ bf(W)) and torch.equal(gW, bf(dy).t() @ bf(h)) and torch.equal(gb, dy.sum(0))
+    # a product left in fp32 is the plain one
+    y2 = orc.linear(Pl, 'encoders.0.4', h, {'enc1': (True, False, True)})
+    gh2, = torch.autograd.grad(y2, [h], dy)
+    assert torch.equal(gh2, dy @ W)
+
+
+def test_emulated_step_rounds_gradients_once_and_clips_by_the_unrounded_norm():
+    torch.manual_seed(5)
+    dims, L, B, p = (40, 24), 8, 32, 0.0
+    P, Bf = orc.init_state(dims, L)
+    for v in P.values():
+        v.requires_grad_(True)
+    init = {k: v.detach().clone() for k, v in P.items()}
+    X = [torch.randn(B, d) for d in dims]
+    noise = orc.draw_noise(dims, L, B, p)
+    st = orc.train_step(P, Bf, orc.Adam(P.values(), 1e-3), X, torch.eye(B), None, noise, p, .5, return_grads=True,
+                        emulate=orc.EMULATE_HIP_BF16_FUSED, grad_bf16=True)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in st['grads'].values())))
+    assert abs(gn - st['grad_norm']) < 1e-5 * gn
+    coef = min(1.0, 1.0 / (st['grad_norm'] + 1e-6))
+    for k, g in st['grads'].items():
+        gc = (orc.bf16_round(g) * coef).double()
+        want = init[k].double() - 1e-3 * gc / (gc.abs() + 1e-8)
+        assert float(((P[k].detach().double() - want).abs() - 1.2e-7 * want.abs()).max()) < 1e-8, k    # (fp32 storage)
