@@ -61,6 +61,8 @@ def _check_first_adam_step(eng, model, init_flat, lr=1e-3, norm=None):
     (|g| <~ 1e-8: ~1 % of the BatchNorm shifts at these sizes, where gradients are O(1e-6)) moves by anything in
     [-lr, lr] in two correct fp32 implementations.  This check has no such freedom."""
     g = eng.grad_flat().double()
+    if getattr(eng, '_g16_last', False) and not eng._direct_now:
+        g = eng.grad16.double()           # bf16 weight-gradient buffer: the optimiser read EVERY range from it (rounded once)
     # (`norm`: the clip norm the engine itself used -- with bf16 weight gradients it is the norm of the fp32 accumulators, not
     #  of the rounded values the optimiser reads)
     coef = min(1.0, 1.0 / ((float(g.norm()) if norm is None else norm) + 1e-6))
@@ -75,15 +77,86 @@ def _clone_state(P, Bf):
     return P2, {k: v.clone() for k, v in Bf.items()}
 
 
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _check_products_against_stored_operands(eng, model, noise, p):
+    """LOCAL consistency of the bf16 step at full size, from the engine's own buffers after forward_backward: every
+    GEMM launch's result equals the fp32-accumulated product of the bf16 operands the producing kernels stored (forward sums of
+    the split-K slabs + bias; input gradients; all six weight gradients per modality, rounded once where the bf16 gradient
+    buffer holds them), and every BatchNorm launch's bf16 output is the rounding of BN + LeakyReLU + dropout of the summed
+    pre-activation it was given.  Tolerance 5e-5 in relative L2 (fp32 summation order only; measured 2e-5 .. 5e-5): a wrong
+    scale, a dropped K slice or slab, or a mis-rounded operand is O(1e-2) or more.  The checker is torch on the GPU."""
+    from jamie_amd.model import BN_EPS, LRELU_SLOPE
+    bfl = lambda t: t.float()      # noqa: E731
+    dn = _noise_to_dev(noise, p)
+    for i in range(eng.M):
+        w, wb, P_ = eng.ws[i], eng.wbf, model.p
+        for a, lin, h in (('x', 'enc0', 'h1'), ('a1', 'enc1', 'h2'), ('e1', 'dec1', 'g2')):
+            want = bfl(w[a + '_bf']) @ bfl(wb[f'm{i}.{lin}.W']).t() + P_[f'm{i}.{lin}.b']
+            assert _rel(w[h][0], want) < 5e-5, (i, lin, 'forward', _rel(w[h][0], want))
+        assert _rel(w['ml'].sum(0), bfl(w['a2_bf']) @ bfl(wb[f'm{i}.head.W']).t()) < 5e-5, (i, 'head forward')
+        if 'xh' in w:
+            want = bfl(w['e2_bf']) @ bfl(wb[f'm{i}.dec2.W']).t() + P_[f'm{i}.dec2.b']
+            assert _rel(w['xh'].sum(0), want) < 5e-5, (i, 'dec2 forward')
+        # the two products inside the fused latent launches are exact fp32: decoder layer 0 forward, the heads' input gradient
+        assert _rel(w['g1'][0], w['comb'] @ P_[f'm{i}.dec0.W'].t() + P_[f'm{i}.dec0.b']) < 1e-5, (i, 'dec0 forward (fp32)')
+        assert _rel(w['da2'][0], w['dml'] @ P_[f'm{i}.head.W']) < 1e-5, (i, 'heads input gradient (fp32)')
+        nd = w['sk']['d_comb']
+        for dy, lin, out in (('dxhat', 'dec2', w['de2'].sum(0)), ('de2', 'dec1', w['de1'].sum(0)),
+                             ('de1', 'dec0', w['dcomb'][:nd].sum(0)), ('da2', 'enc1', w['da1'].sum(0))):
+            want = bfl(w[dy + '_bf']) @ bfl(wb[f'm{i}.{lin}.W'])
+            assert _rel(out, want) < 5e-5, (i, lin, 'input gradient', _rel(out, want))
+        for dy, a, lin in (('dxhat', 'e2', 'dec2'), ('de2', 'e1', 'dec1'), ('de1', 'comb', 'dec0'), ('dml', 'a2', 'head'),
+                           ('da2', 'a1', 'enc1'), ('da1', 'x', 'enc0')):
+            k = f'm{i}.{lin}.W'
+            want = bfl(w[dy + '_bf']).t() @ bfl(w[a + '_bf'])
+            g16 = eng._g16_last and k[:-2] in eng.dw_partial
+            got = bfl(eng.g16[k]) if g16 else eng.g[k]
+            # (rounded to bf16 on both sides: an accumulator within ~1e-6 of a rounding boundary may land on the other side)
+            assert _rel(got, want.to(torch.bfloat16).float() if g16 else want) < (2e-4 if g16 else 5e-5), (i, lin, 'weight gradient')
+        # BatchNorm + LeakyReLU + dropout outputs from the summed pre-activations (slab 0 after the forward launch)
+        for bn, h, a, kind, j in (('bn0', 'h1', 'a1', 'enc_masks', 0), ('bn1', 'h2', 'a2', 'enc_masks', 1),
+                                  ('bn2', 'g1', 'e1', 'dec_masks', 0), ('bn3', 'g2', 'e2', 'dec_masks', 1)):
+            hv = w[h][0]
+            mean, var = hv.mean(0), hv.var(0, unbiased=False)
+            y = (hv - mean) * torch.rsqrt(var + BN_EPS) * P_[f'm{i}.{bn}.g'] + P_[f'm{i}.{bn}.b']
+            y = torch.where(y > 0, y, LRELU_SLOPE * y)
+            if p > 0:
+                mk = dn[kind][i][j]
+                y = y * torch.nn.functional.pad(mk, (0, y.shape[1] - mk.shape[1])).float() / (1 - p)
+            got, want = w[a + '_bf'], y.to(torch.bfloat16)
+            # (statistics summed in another order: a value within ~1e-7 of a rounding boundary may land on the other side)
+            off = got != want
+            assert float(off.float().mean()) < 2e-3 and _rel(bfl(got), bfl(want)) < 3e-4, (i, bn, float(off.float().mean()))
+            np.testing.assert_allclose(w[bn + '.mean'].cpu().numpy(), mean.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# gradients of the decoder's first two layers and the BatchNorm between them: the reconstruction loss's gradient reaches them
+# through BatchNorm backward passes that subtract its column mean and its projection on the normalised activation (dh = gamma
+# invstd (dy - mean(dy) - xn mean(dy xn))): what is left is 6-13 x smaller than dy, so a relative difference in dy comes out
+# 6-13 x larger (measured on both sides, profiles/r03_bf16_emulation_*.log: hip-vs-emulated 1.8e-3 -> 1.2e-2 and
+# emulated-vs-fp32 3e-3 -> 3.9e-2 from decoders.i.8.weight to decoders.i.4.weight)
+_AMPLIFIED = ('decoders.{}.0.weight', 'decoders.{}.1.weight', 'decoders.{}.1.bias', 'decoders.{}.4.weight')
+
+
 def _bf16_step_vs_emulating_oracle(eng, model, P, Bf, X, corr, noise, p, anneal, init_flat):
     """The TIGHT parity check of the benchmarked arithmetic (bf16 GEMM operands, fp32 accumulation, bf16 weight
     gradients): the oracle restates the step with THE SAME roundings (`orc.train_step(emulate=, grad_bf16=)`: the operands of
     every product the engine reports as bf16 are rounded to nearest even where the HIP kernels store them; everything else
     fp32), so what is left between the two is fp32 summation order, a handful of LeakyReLU-kink / bf16-tie crossings, and
     nothing a wrong scale or a mis-rounded slab could hide behind.  Called after `eng.forward_backward` on the same batch
-    and noise, BEFORE the optimiser step.  Losses 2e-3 (measured ~1e-5), every gradient tensor 1e-2 in relative L2 (measured
-    ~1e-3 and below), the clip norm 1e-3, then the first Adam step exactly (restated on the engine's own gradient and norm)
-    and its direction against the oracle's update."""
+    and noise, BEFORE the optimiser step.  Losses 2e-3 (measured 3e-5); every gradient tensor 1e-2 in relative L2 (measured
+    1e-5 .. 5e-3: bf16 rounding is chaotic -- two runs whose fp32 values differ by 1e-7 round a fraction of the operands to
+    different neighbours, 4e-3 apart, and the noise settles at ~1e-3 per tensor whatever its origin), 3e-2 for the four
+    tensors per modality behind an amplifying BatchNorm backward (`_AMPLIFIED`), the whole gradient 5e-3; the clip norm 1e-3;
+    then the first Adam step exactly (restated on the engine's own gradient and norm) and its direction against the oracle's
+    update.  What this end-to-end comparison cannot resolve below ~1e-3, `_check_products_against_stored_operands` does
+    product by product at 5e-5."""
+    if eng.fuse_bf16 and eng._fused_latent(None, None) and (corr is None or torch.equal(corr, torch.eye(corr.shape[0]))):
+        _check_products_against_stored_operands(eng, model, noise, p)
+    amplified = {t.format(i) for t in _AMPLIFIED for i in range(len(X))}
     prec, gbf = eng.operand_precision(None if corr is None or torch.equal(corr, torch.eye(corr.shape[0])) else corr)
     assert prec is not None and gbf == bool(eng.grad_bf16)
     init = {k: v.detach().clone() for k, v in P.items()}
@@ -94,7 +167,7 @@ def _bf16_step_vs_emulating_oracle(eng, model, P, Bf, X, corr, noise, p, anneal,
     for i in range(len(X)):
         assert_mostly_close(eng.ws[i]['mu'].cpu().numpy(), st['mus'][i].numpy(), rtol=0, atol=0, max_bad_frac=1.0,
                             rel_l2=2e-3, msg=f'mu{i}')
-    worst = 0.0
+    worst, num, den = 0.0, 0.0, 0.0
     for ref in P:
         if orc.is_dead_bias(ref):
             continue
@@ -102,8 +175,12 @@ def _bf16_step_vs_emulating_oracle(eng, model, P, Bf, X, corr, noise, p, anneal,
         if gbf and want.dim() == 2:          # the large matrices live in the bf16 gradient buffer: rounded once
             want = orc.bf16_round(want)
         got = _grad(eng, model, ref)
-        assert_mostly_close(got, want.numpy(), rtol=0, atol=0, max_bad_frac=1.0, rel_l2=1e-2, msg=ref)
+        assert_mostly_close(got, want.numpy(), rtol=0, atol=0, max_bad_frac=1.0, rel_l2=3e-2 if ref in amplified else 1e-2,
+                            msg=ref)
         worst = max(worst, float(np.linalg.norm(got - want.numpy()) / max(1e-30, np.linalg.norm(want.numpy()))))
+        num += float(np.square(got.astype(np.float64) - want.numpy()).sum())
+        den += float(np.square(want.double().numpy()).sum())
+    assert (num / den) ** 0.5 < 5e-3, ('whole gradient', (num / den) ** 0.5)
     eng.optimizer_step()
     if eng.fused_norm:
         n_live = eng.n_dw_partials + eng.sq_ranges.blocks
@@ -120,7 +197,7 @@ def _bf16_step_vs_emulating_oracle(eng, model, P, Bf, X, corr, noise, p, anneal,
         # Adam's first step is lr * sign(g) wherever |g| >> 1e-8: the same direction as the oracle's except where a gradient
         # element is rounding noise around zero
         agree = float((torch.sign(du) == torch.sign(dr)).float().mean())
-        assert agree > 0.995, (k, agree)
+        assert agree > (0.985 if k in amplified else 0.995), (k, agree)     # (against the fp32 oracle: 0.93-0.97)
     return worst
 
 
