@@ -95,11 +95,12 @@ int jamie_gemm_f32_cfg(const jamie_gemm_problem* problems /*host*/, int count, i
 int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm /*host*/, int* bn /*host*/);
 
 /* ---------------------------------------------------------------------------------------------
- * bf16 compute mode (BASELINE config 2: bf16 compute / fp32 master weights).  Same products as jamie_gemm_f32,
- * every one expressed as C[M,N] (fp32) = A[M,K] * B[N,K]^T with both operands K-contiguous bf16 (A, B of the
- * problem struct point to bf16; lda/ldb in elements; K, lda, ldb multiples of 8; epilogues STORE and MSE):
- *   forward A = a [B,in], B = W [out,in];  dX: A = dy [B,out], B = W^T [in,out];  dW: A = dy^T [out,B], B = a^T [in,B].
- * jamie_cast_transpose produces the bf16 / bf16-transposed copies from fp32 (optionally summing split-K slabs).
+ * bf16 compute mode (BASELINE config 2: bf16 compute / fp32 master weights).  Same products as jamie_gemm_f32 as
+ * C[M,N] (fp32, or bf16 with c_bf16) = A[M,K] * B[N,K]^T on bf16 operands (A, B of the problem struct point to bf16;
+ * lda/ldb in elements; K, lda, ldb multiples of 8; epilogues STORE and MSE), K-contiguous unless a_tr / b_tr say the operand is
+ * stored k-row-major (large-tile configurations: the operands are read as their producers stored them, no transposed copies):
+ *   forward A = a [B,in], B = W [out,in];  dX: A = dy [B,out], B = W [out,in] with b_tr;  dW: A = dy [B,out] with a_tr,
+ *   B = a [B,in] with b_tr.  Small-tile configurations need K-contiguous (transposed) copies: jamie_cast_transpose.
  * ------------------------------------------------------------------------------------------- */
 int jamie_gemm_bf16(const jamie_gemm_problem* problems /*host*/, int count, int cfg, void* stream);
 int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm /*host*/, int* bn /*host*/);
@@ -153,6 +154,19 @@ typedef struct {
 
 int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* problems /*host*/, int count, float p_drop,
                      float momentum, float eps, float slope, const uint64_t* rng, void* stream);
+
+/* Linear forward + BatchNorm1d(train) + LeakyReLU + Dropout in ONE launch (model.py:151-154 and the three sibling blocks; bf16
+ * compute mode, large-tile configurations 31 / 32): jamie_gemm_bf16 on `problems` (plain stores of `splitk` fp32 slabs, bias in
+ * slab 0) whose workgroups hand their slabs over INSIDE the launch -- write-through stores, one ticket per 128-column strip -- and
+ * then run jamie_bn_act_fwd's strip code on `bn[i]` (whose `h`, `nslab`, `slab_stride`, `B`, `N` must describe problem i's own
+ * slab buffer; `outT_bf16` must be NULL; batch <= 512, N a multiple of 4): the same bits as the two launches.
+ * mode 1: the LAST workgroup of a strip to arrive reduces the whole strip; mode 2: EVERY workgroup of a strip waits (bounded) for
+ * the strip's arrivals and takes a share of its eight 16-column sub-strips by arrival order (needs the strip's tiles_m x splitk
+ * workgroups co-resident: they are adjacent in dispatch order).  `tickets`: device uint32 [n_tickets >= 4 + 2 * sum_i
+ * ceil(N_i / 128)], zero before the first call; the launch leaves it zero; word 0 != 0 afterwards = a bounded wait gave up. */
+int jamie_gemm_bf16_bn(const jamie_gemm_problem* problems /*host*/, const jamie_bnact_fwd_problem* bn /*host*/, int count /* <= 4 */,
+                       int cfg, float p_drop, float momentum, float eps, float slope, const uint64_t* rng, unsigned* tickets,
+                       int n_tickets, int mode, void* stream);
 
 typedef struct {
     float* da; int nslab; long long slab_stride;     /* grad wrt activation out; dh is written to slab 0 */

@@ -130,6 +130,8 @@ EXPORTS = {
     'jamie_gemm_bf16_ranges': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
     'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'jamie_gemm_bf16_bn': (C.c_int, [C.POINTER(GemmProblem), C.POINTER(BnFwdProblem), C.c_int, C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'jamie_cast_transpose': (C.c_int, [C.POINTER(CastProblem), C.c_int, C.c_void_p]),
     'jamie_mse_cast': (C.c_int, [C.POINTER(MseProblem), C.c_int, C.c_void_p]),
     'jamie_bn_act_fwd': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float,
@@ -348,6 +350,15 @@ def gemm_bf16(problems, cfg=-1, ranges=None):
               partials.numel(), ptr(state), C.pointer(fin) if fin is not None else None, _stream())
         return
     _call('jamie_gemm_bf16', arr, len(problems), cfg, _stream())
+
+
+def gemm_bf16_bn(problems, bn_problems, cfg, p_drop, rng, tickets, mode=2, momentum=0.1, eps=1e-5, slope=0.01):
+    """Linear forward + BatchNorm + LeakyReLU + dropout in one launch (jamie_gemm_bf16_bn): the workgroups of a column strip
+    hand their split-K slabs to each other inside the launch; `tickets`: zeroed int32 device tensor (4 + 2 per 128-column strip)."""
+    arr = (GemmProblem * len(problems))(*problems)
+    barr = (BnFwdProblem * len(bn_problems))(*bn_problems)
+    _call('jamie_gemm_bf16_bn', arr, barr, len(problems), cfg, p_drop, momentum, eps, slope, ptr(rng), ptr(tickets),
+          tickets.numel(), int(mode), _stream())
 
 
 def gemm_bf16_tile(max_m, max_n, cfg=-1):

@@ -16,13 +16,8 @@
 #include "common.h"
 #include "colsum.h"
 
-// diagnostic ablations of the float4 forward kernel (timing only): 1 = no global loads, 2 = no global stores,
-// 3 = neither (launch + reductions only)
-#ifndef JAMIE_BN_ABL
-#define JAMIE_BN_ABL 0
-#endif
+#include "bn_fwd_strip.h"
 
-#define BN_CW 16
 // Strip order: a problem gets 8 * ceil(strips / 8) workgroups and workgroup lb handles strip (lb & 7) * q + (lb >> 3),
 // q = ceil(strips / 8): blocks are dealt round-robin over the 8 XCDs (lb & 7), so every XCD owns a CONTIGUOUS range of
 // strips.  Neighbouring strips share 128-byte lines (a strip is 64 bytes of an fp32 row, 32 bytes of a bf16 row): the
@@ -33,15 +28,7 @@ __device__ __forceinline__ int bn_strip(int lb, int n_cols) {
 }
 #define BN_RP 16
 #define BN_MAXR 32
-#define BN_OOB 0xFFFFFFF0u
 
-struct BnFwdDev {
-    float* h; const float* gamma; const float* beta; float* rmean; float* rvar;
-    float* smean; float* sinvstd; float* out; const uint8_t* mask;
-    unsigned short* out_bf; unsigned short* outT_bf;
-    long long slab_stride;
-    int nslab, B, N, rng_stream, blk_begin;
-};
 struct BnFwdGroup { BnFwdDev p[JAMIE_MAX_GROUP]; int count; };
 
 struct BnBwdDev {
@@ -69,22 +56,6 @@ __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned off)
 }
 __device__ __forceinline__ unsigned buf_u8(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
-}
-
-// Keep decision of element (row, col): 16 random bits against a 16-bit threshold.  One Philox call serves the 4
-// consecutive columns of a quad (word e = col % 4) in the two rows r and r + 128 (low / high half of the word): counter =
-// (col / 4, row % 128 + 128 * (row / 256)), half = (row / 128) % 2 -- the 8 elements a thread of the float4 kernels owns
-// in rows rp + 256 q and rp + 256 q + 128.  Halves the Philox work (3.7 us per launch at one call per 4 elements).
-__device__ __forceinline__ Philox4 drop_rand4(const uint64_t* rng, int stream, int col, int row) {
-    const uint32_t rk = (uint32_t)(row & 127) | ((uint32_t)(row >> 8) << 7);
-    return jamie_rand4(rng, (uint32_t)stream, ((uint64_t)(uint32_t)(col >> 2) << 32) | (uint64_t)rk);
-}
-__device__ __forceinline__ uint32_t drop_threshold16(float p) {
-    const float t = p * 65536.f;
-    return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
-}
-__device__ __forceinline__ bool drop_keep(const uint64_t* rng, int stream, int col, int row, uint32_t thr16) {
-    return ((drop_rand4(rng, stream, col, row).v[col & 3] >> (16 * ((row >> 7) & 1))) & 0xFFFFu) >= thr16;
 }
 
 // bf16 outputs of a cached strip (thread (c, rp) holds rows rp + 16 j of column c in val[j]):
@@ -383,34 +354,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
 // columns x 4 rows (rows rp + 128 j, rp = 0..127; 512 threads): 16-byte loads / stores (1 KiB per wave-instruction = 16 rows x 64 B),
 // two slabs in flight at a time, column sums by xor-shuffles over the 16 row phases of a wave + a 4-wave LDS step.
 // ------------------------------------------------------------------------------------------------
-#define BN4_RP 128
-#define BN4_MAXR 4      // rows per thread of the default instance (B <= 512); the kernels are templates on R (4 or 8: B <= 1024)
-#define BN4_NW 8          // waves per workgroup (512 threads)
-typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const bn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ unsigned buf_u32(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
-}
-__device__ __forceinline__ float4 col_reduce4(float4 v, float (*sh)[BN_CW], int tid) {
-#pragma unroll
-    for (int m = 4; m < 64; m <<= 1) {
-        v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
-    }
-    const int lane = tid & 63, wid = tid >> 6, cq = tid & 3;
-    __syncthreads();
-    if (lane < 4) { sh[wid][4 * lane] = v.x; sh[wid][4 * lane + 1] = v.y; sh[wid][4 * lane + 2] = v.z; sh[wid][4 * lane + 3] = v.w; }
-    __syncthreads();
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < BN4_NW; ++w)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] += sh[w][4 * cq + e];
-    return make_float4(t[0], t[1], t[2], t[3]);
-}
 // two column sums at once (one pair of barriers): sh2 is [4][2 * BN_CW]
 __device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)[2 * BN_CW], int tid) {
 #pragma unroll
@@ -435,44 +378,6 @@ __device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)
     a = make_float4(t[0], t[1], t[2], t[3]);
     b = make_float4(t[4], t[5], t[6], t[7]);
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
-}
-// bf16 outputs of a strip held as val[j] = 4 columns of row rp + 64 j
-template <int R>
-__device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigned short* out_bf, unsigned short* outT_bf,
-                                                 unsigned short* tl, int B, int N, int col0, int cq, int rp, bool cok) {
-    const int col = col0 + 4 * cq;
-    if (out_bf && cok) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int row = rp + j * BN4_RP;
-            if (row < B)
-                *reinterpret_cast<uint2*>(out_bf + (long long)row * N + col) =
-                    make_uint2(pack_bf16x2(val[j].x, val[j].y), pack_bf16x2(val[j].z, val[j].w));
-        }
-    }
-    if (!outT_bf) return;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int row = rp + j * BN4_RP;
-        tl[(4 * cq) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].x);
-        tl[(4 * cq + 1) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].y);
-        tl[(4 * cq + 2) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].z);
-        tl[(4 * cq + 3) * (128 * R + 2) + row] = __builtin_bit_cast(unsigned short, (__bf16)val[j].w);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < R / 2; ++i) {
-        const int q = threadIdx.x + 512 * i, cc = q / (16 * R), r8 = (q % (16 * R)) * 8;
-        if (col0 + cc < N && r8 < B) {        // B is a multiple of 8 in bf16 mode
-            const unsigned* sp = reinterpret_cast<const unsigned*>(tl + cc * (128 * R + 2) + r8);
-            *reinterpret_cast<uint4*>(outT_bf + (long long)(col0 + cc) * B + r8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        }
-    }
-}
-
 template <int R>
 __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                           float slope, const uint64_t* rng) {
@@ -483,136 +388,8 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnFwdDev& P = g.p[pi];
-    const int tid = threadIdx.x, cq = tid & 3, rp = tid >> 2;
-    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW, col = col0 + 4 * cq;
-    const bool cok = col < P.N;                       // N % 4 == 0: a quad is wholly in or out
-    const int B = P.B, N = P.N, nslab = P.nslab;
-    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
-    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)P.h, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
-    unsigned roff[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int row = rp + j * BN4_RP;
-        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
-    }
-    // latency order: parameter loads and the first two slabs are issued first; the Philox keep words (pure VALU,
-    // ~100 instructions per call) are computed while those loads are in flight (they cost 3.7 us per launch when they
-    // sat behind the statistics: rocprofv3, tools/trace_bn.sh)
-    float ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, rm_old[4] = {0.f, 0.f, 0.f, 0.f}, rv_old[4] = {0.f, 0.f, 0.f, 0.f};
-    if (cok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ga[e] = P.gamma[col + e]; be[e] = P.beta[col + e]; }
-        if (rp == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { rm_old[e] = P.rmean[col + e]; rv_old[e] = P.rvar[col + e]; }
-        }
-    }
-    const bool drop = p_drop > 0.f;
-    const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    const uint32_t thr = drop_threshold16(p_drop);
-    unsigned mk[R];
-    if (drop && P.mask) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
-    }
-    float4 v[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned keepbits = 0xFFFFFFFFu;              // bit 4 j + e: element (row j, column e) of this thread is kept
-    // (R == 4: THREE slabs per round trip -- the forward launches of config 2 have (3, 2) K slices, and a third slab in a second
-    //  trip was one more memory latency for every workgroup of the larger modality; R == 8 keeps two: registers)
-#ifdef JAMIE_BN_TRIP2      // (A/B build: two slabs per trip as before)
-    constexpr int TRIP = 2;
-#else
-    constexpr int TRIP = R <= 4 ? 3 : 2;
-#endif
-    for (int s = 0; s < nslab; s += TRIP) {
-        float4 a[R], b[R], c[TRIP > 2 ? R : 1];
-        const bool two = s + 1 < nslab, three = TRIP > 2 && s + 2 < nslab;
-#pragma unroll
-        for (int j = 0; j < R; ++j) a[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
-#pragma unroll
-        for (int j = 0; j < R; ++j) b[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !two || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 1) * slab_bytes);
-        if constexpr (TRIP > 2) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) c[j] = buf_f32x4(h_rs, (roff[j] == BN_OOB || !three || (JAMIE_BN_ABL & 1)) ? BN_OOB : roff[j] + (unsigned)(s + 2) * slab_bytes);
-        }
-        if (s == 0 && drop) {                     // VALU work under the loads just issued
-            keepbits = 0u;
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (P.mask) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) keepbits |= (((mk[j] >> (8 * e)) & 0xFFu) != 0 ? 1u : 0u) << (4 * j + e);
-                } else if ((j & 1) == 0) {        // rows rp + 128 j and rp + 128 (j + 1): low / high halves of one call
-                    const Philox4 r = drop_rand4(rng, P.rng_stream, col, rp + j * BN4_RP);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        keepbits |= ((r.v[e] & 0xFFFFu) >= thr ? 1u : 0u) << (4 * j + e);
-                        keepbits |= ((r.v[e] >> 16) >= thr ? 1u : 0u) << (4 * (j + 1) + e);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            v[j].x += a[j].x; v[j].y += a[j].y; v[j].z += a[j].z; v[j].w += a[j].w;
-            v[j].x += b[j].x; v[j].y += b[j].y; v[j].z += b[j].z; v[j].w += b[j].w;
-            if constexpr (TRIP > 2) { v[j].x += c[j].x; v[j].y += c[j].y; v[j].z += c[j].z; v[j].w += c[j].w; }
-        }
-    }
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < R; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
-    float4 mean = col_reduce4(sum, sh, tid);
-    const float fB = (float)B;
-    mean.x /= fB; mean.y /= fB; mean.z /= fB; mean.w /= fB;
-    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        if (rp + j * BN4_RP < B) {
-            const float dx = v[j].x - mean.x, dy = v[j].y - mean.y, dz = v[j].z - mean.z, dw = v[j].w - mean.w;
-            sq.x += dx * dx; sq.y += dy * dy; sq.z += dz * dz; sq.w += dw * dw;
-        }
-    }
-    float4 var = col_reduce4(sq, sh, tid);
-    var.x /= fB; var.y /= fB; var.z /= fB; var.w /= fB;
-    const float4 invstd = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
-    if (cok && rp == 0) {
-        const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, vv[4] = {var.x, var.y, var.z, var.w};
-        const float iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            P.smean[col + e] = mv[e];
-            P.sinvstd[col + e] = iv[e];
-            const float unb = B > 1 ? vv[e] * ((float)B / (float)(B - 1)) : vv[e];
-            P.rmean[col + e] = (1.f - momentum) * rm_old[e] + momentum * mv[e];
-            P.rvar[col + e] = (1.f - momentum) * rv_old[e] + momentum * unb;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int row = rp + j * BN4_RP;
-        float y[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < B && cok) {
-            const long long o = (long long)row * N + col;
-            if (nslab > 1) *reinterpret_cast<float4*>(P.h + o) = v[j];
-            const float hv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-            const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = (hv[e] - mv[e]) * iv[e] * ga[e] + be[e];
-                t = t > 0.f ? t : slope * t;
-                if (drop) t = ((keepbits >> (4 * j + e)) & 1u) ? t * keep_scale : 0.f;
-                y[e] = t;
-            }
-            if (P.out && (!(JAMIE_BN_ABL & 2) || y[0] == 123.456f)) *reinterpret_cast<float4*>(P.out + o) = make_float4(y[0], y[1], y[2], y[3]);
-        }
-        v[j] = make_float4(y[0], y[1], y[2], y[3]);
-    }
-    if ((P.out_bf || P.outT_bf) && (!(JAMIE_BN_ABL & 2) || v[0].x == 123.456f)) strip_out_bf16x4(v, P.out_bf, P.outT_bf, tl, B, N, col0, cq, rp, cok);
+    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW;
+    bn_fwd4_strip<R, 0>(P, col0, (int)threadIdx.x, true, sh, tl, p_drop, momentum, eps, slope, rng);      // (bn_fwd_strip.h)
 }
 
 // `cs` / `cs_begin`: workgroups cs_begin .. are EXTRA ones that compute column sums (jamie_bn_act_bwd_cs: the decoder's
@@ -735,7 +512,7 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     // the bias-gradient column sums come BEFORE the bf16 stores: col_reduce4's barriers are `__syncthreads()`, which drain
     // vmcnt(0) -- behind the stores they made every wave wait for its stores to be acknowledged
     const float4 dbias = col_reduce4(s3, sh, tid);
-    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, cq, rp, cok);
+    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4<R>(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, tid, cok);
     if (cok && rp == 0) {
         const float dg[4] = {dgamma.x, dgamma.y, dgamma.z, dgamma.w}, db[4] = {dbeta.x, dbeta.y, dbeta.z, dbeta.w};
         const float dl[4] = {dbias.x, dbias.y, dbias.z, dbias.w};

@@ -1,19 +1,22 @@
 // bf16 GEMM on v_mfma_f32_32x32x16_bf16 with fp32 accumulation/output for JAMIE's Linear layers, gfx950.
 //
 // bf16 compute mode of the training step (BASELINE config 2: "bf16 compute / fp32 master"): the same
-// products as gemm_f32.hip (reference model.py:151,161,180,185,192,197,207; jamie.py:734), but every product is
-// expressed as C[M,N] = A[M,K] * B[N,K]^T with BOTH operands K-contiguous bf16:
-//     forward   y  = a   W^T      A = a    [B, in]     B = W    [out, in]
-//     dX        dx = dy  W        A = dy   [B, out]    B = W^T  [in, out]     (bf16 transposed weight copy)
-//     dW        dW = dy^T a       A = dy^T [out, B]    B = a^T  [in, B]       (bf16 transposed activations)
-// The producers (cast_transpose / bn_act kernels) write the bf16 and bf16-transposed copies, so ONE kernel
-// shape serves all three and each MFMA lane fetches its 8 k-values with a single ds_read_b128.
+// products as gemm_f32.hip (reference model.py:151,161,180,185,192,197,207; jamie.py:734).  Every operand exists ONCE, bf16,
+// row-major as its producer stored it (activations / gradients [B, features], weights [out, in]); the three products of a
+// Linear layer differ in which operand is k-row-major:
+//     forward   y  = a   W^T      A = a  [B, in]  (K contiguous)     B = W [out, in] (K contiguous)
+//     dX        dx = dy  W        A = dy [B, out] (K contiguous)     B = W [out, in] = [K, N] as stored        (b_tr)
+//     dW        dW = dy^T a       A = dy [B, out] = [K, M] as stored  B = a [B, in]  = [K, N] as stored  (a_tr + b_tr)
+// A K-contiguous operand is staged as [rows][64 k] (one ds_read_b128 per fragment), a k-row-major one as [64 k][128] read
+// with ds_read_b64_tr_b16 (gemm_bf16_dma2_body); only launches that fall back to the small-tile kernels below (skinny or
+// ragged problems of small models) still read transposed copies made by the cast / BatchNorm kernels.
 //
-// Tile BM x BN x BK, WM x WN waves, each wave TM x TN tiles of 32x32 (C/D map as in gemm_f32.hip).  LDS rows
-// are padded to BK*2 + 16 bytes (16 * odd): conflict-free ds_read_b128.  Staging, double buffering, fragment
-// prefetch, grouped launch, XCD mapping, split-K slabs and epilogues are those of gemm_f32.hip.
+// Three kernels: gemm_bf16_kernel (register-staged, padded LDS rows: fallback), gemm_bf16_dma_kernel (LDS-DMA, 64x64 tiles)
+// and gemm_bf16_dma2_kernel (LDS-DMA, 256x128 / 128x128 tiles, hand-counted vmcnt; optional riders; optional in-launch split-K
+// reduction + BatchNorm forward: jamie_gemm_bf16_bn).  Grouped launch, XCD mapping, split-K slabs as in gemm_f32.hip.
 #include "common.h"
 #include "range_norm.h"
+#include "bn_fwd_strip.h"
 #include <type_traits>
 
 // diagnostic ablations (timing only, wrong results): 1 = no global loads in the k-loop, 2 = no MFMAs,
@@ -42,6 +45,20 @@ struct GemmBDev {
     float scale, pscale;
 };
 struct GemmBGroup { GemmBDev p[JAMIE_MAX_GEMM_GROUP]; int count; };
+
+// In-launch split-K reduction + BatchNorm forward (jamie_gemm_bf16_bn): per problem the BatchNorm strip descriptor whose `h` is
+// the GEMM's slab buffer, and the hand-off state: tickets[0..3] = error block (word 0: a bounded wait gave up), then TWO words
+// per column strip of every problem (arrivals, departures), zero at allocation and zero again when a launch ends.
+#define JB_FUSE_MAX 4
+struct BnFuse {
+    BnFwdDev p[JB_FUSE_MAX];
+    int ticket_base[JB_FUSE_MAX];
+    unsigned* tickets;
+    const uint64_t* rng;
+    float p_drop, momentum, eps, slope;
+    int mode;                 // 1: the LAST workgroup of a strip to arrive reduces the strip; 2: EVERY workgroup waits for its
+                              // strip's arrivals and takes a share of the 16-column sub-strips (by arrival order)
+};
 
 #define JB_OOB 0xFFFFFFF0u
 
@@ -485,8 +502,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
 // CONSECUTIVE n for one m, stored as one 16-byte access (4x fewer store instructions).
 // TRM = 0: no problem of the launch has a k-row-major operand (forward launches): the a_tr / b_tr paths are compiled out,
 // TRM = 1: per-problem flags (backward launches: dX reads W as stored, dW reads dy and a as stored)
-template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
-__device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g) {
+template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM, bool FUSE = false>
+__device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const BnFuse* fz = nullptr) {
     constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_SZ = BM * 128, B_SZ = BN * 128, T_SZ = A_SZ + B_SZ;
@@ -520,9 +537,12 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g) {
         }
     }
     const GemmBDev& P = g.p[pi];
-    const int tm_i = t % P.tiles_m;
-    const int tn_i = (t / P.tiles_m) % P.tiles_n;
-    const int ks = t / (P.tiles_m * P.tiles_n);
+    // FUSE: the tiles_m x splitk workgroups of one column strip are adjacent in the tile list (same XCD chunk, dispatched
+    // together): they hand their slabs to each other inside the launch
+    const int pn = P.tiles_m * P.splitk;
+    const int tm_i = FUSE ? (t % pn) % P.tiles_m : t % P.tiles_m;
+    const int tn_i = FUSE ? t / pn : (t / P.tiles_m) % P.tiles_n;
+    const int ks = FUSE ? (t % pn) / P.tiles_m : t / (P.tiles_m * P.tiles_n);
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int kbeg = ks * P.kchunk;
     const int kend = min(P.K, kbeg + P.kchunk);
@@ -799,6 +819,14 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g) {
                                       // L2 / Infinity Cache, whose write-back ran into the optimiser kernel (229 -> 208 us)
                     __builtin_nontemporal_store(v[0], cp); __builtin_nontemporal_store(v[1], cp + 1);
                     __builtin_nontemporal_store(v[2], cp + 2); __builtin_nontemporal_store(v[3], cp + 3);
+                } else if constexpr (FUSE) {
+                    // write-through (sc1): the slab is read by another workgroup of THIS launch (publish-large: no release
+                    // fence, no dirty lines to write back before the ticket)
+                    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)Cout, 0, (int)((unsigned)P.M * (unsigned)P.ldc * 4u), 0x00020000);
+                    u32x4 pk;
+                    pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]); pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, c_rs, (int)(((unsigned)m * (unsigned)P.ldc + (unsigned)nc) * 4u), 0, 16);
                 } else {
                     *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -830,11 +858,75 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g) {
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
     }
+    if constexpr (FUSE) {
+        // ---- hand-off (cdna_hip_programming.md, 'In-launch split-K reduction', sc1 form): every storing wave drains its
+        // write-through stores, workgroup barrier, ONE lane takes the strip's ticket (relaxed, agent scope); the reducing
+        // workgroup's lane 0 acquires at agent scope (drops this CU's L1 lines), drains, barrier, then the slab loads (sc1) ----
+        const BnFuse& F = *fz;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        JB_STAMP(3);
+        typedef __attribute__((address_space(1))) unsigned gu32;        // (global, never flat: the polled words)
+        gu32* cnt = (gu32*)(F.tickets + 4 + 2 * (F.ticket_base[pi] + tn_i));
+        int* sflag = reinterpret_cast<int*>(smem + 4096);
+        if (tid == 0) *sflag = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = *sflag;
+        constexpr int TEAMS = NT / 512;
+        constexpr int UNITS = (BN / 16) / TEAMS;          // passes over the strip's 16-column sub-strips, TEAMS at a time
+        static_assert(NT % 512 == 0 && (BN / 16) % TEAMS == 0, "teams of 512 threads");
+        const bool every = F.mode == 2 && pn > 1;
+        int u0 = 0, ustep = 1;
+        if (every) {
+            u0 = ticket; ustep = pn;
+            if (u0 < UNITS && tid == 0) {                 // wait for the strip's other slices (bounded; co-resident by dispatch order)
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)pn) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22)) { __hip_atomic_store((gu32*)F.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+        } else if (ticket != pn - 1) {
+            return;                                       // (uniform) not the last arriver: done
+        }
+        JB_STAMP(6);
+        if (u0 < UNITS) {
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            const int team = tid >> 9, tl_ = tid & 511;
+            float (*sh)[BN_CW] = reinterpret_cast<float (*)[BN_CW]>(smem + team * 512);
+            for (int u = u0; u < UNITS; u += ustep) {
+                const int col0 = n0 + 16 * (u * TEAMS + team);
+                bn_fwd4_strip<4, 16>(F.p[pi], col0, tl_, col0 < P.N, sh, nullptr, F.p_drop, F.momentum, F.eps, F.slope, F.rng);
+            }
+        }
+        // leave the counters zero for the next launch: the last arriver (mode 1) / the last to depart (mode 2: nobody is
+        // still polling the arrivals word then)
+        if (tid == 0) {
+            if (!every) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (__hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(pn - 1)) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        JB_STAMP(7);
+        return;
+    }
 #ifdef JAMIE_GEMMB_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     JB_STAMP(3);
 #endif
+}
+
+// the large-tile kernel with the in-launch split-K reduction + BatchNorm forward (forward launches: no k-row-major operands)
+template <int BM, int BN, int WM, int WN, int TAG, int NB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_bn_kernel(GemmBGroup g, BnFuse f) {
+    gemm_bf16_dma2_body<BM, BN, WM, WN, TAG, NB, 0, true>(g, &f);
 }
 
 template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
@@ -974,6 +1066,66 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, c
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
+template <int BM, int BN, int WM, int WN, int NB>
+static int launch_dma_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_problem* bn, int count, float p_drop, float momentum,
+                         float eps, float slope, const uint64_t* rng, unsigned* tickets, int n_tickets, int mode, hipStream_t st) {
+    constexpr int BK = 64;
+    GemmBGroup g;
+    BnFuse f;
+    memset(&g, 0, sizeof(g));
+    memset(&f, 0, sizeof(f));
+    g.count = count;
+    int tiles = 0, strips = 0;
+    bool need_rng = false;
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        const jamie_bnact_fwd_problem& b = bn[i];
+        GemmBDev& d = g.p[i];
+        d.A = (const unsigned short*)s.A; d.B = (const unsigned short*)s.B; d.C = s.C; d.bias = s.bias;
+        d.slab_stride = s.slab_stride;
+        d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc;
+        d.splitk = s.splitk < 1 ? 1 : s.splitk;
+        int kc = (s.K + d.splitk - 1) / d.splitk;
+        d.kchunk = ((kc + BK - 1) / BK) * BK;
+        d.tiles_m = (s.M + BM - 1) / BM;
+        d.tiles_n = (s.N + BN - 1) / BN;
+        d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        tiles += d.n_tiles;
+        d.epi = JAMIE_EPI_STORE; d.scale = 1.f; d.pscale = 1.f; d.vec = 1;
+        JAMIE_ARG(s.epi == JAMIE_EPI_STORE && !s.accumulate && !s.a_tr && !s.b_tr && !s.c_bf16 && !s.partial,
+                  "fused BatchNorm: a plain forward product (K-contiguous operands, fp32 slabs, no partial sums)");
+        JAMIE_ARG(s.M <= BN4_MAXR * BN4_RP && s.N % 4 == 0 && s.ldc == s.N && (uintptr_t)s.C % 16 == 0 && s.slab_stride % 4 == 0 &&
+                      (!s.bias || (uintptr_t)s.bias % 16 == 0),
+                  "fused BatchNorm: batch <= 512, N a multiple of 4, dense 16-byte aligned slabs");
+        JAMIE_ARG((long long)s.M * s.ldc * 4 < 0x7FFFFFF0LL, "fused BatchNorm: a slab must stay below 2 GiB");
+        JAMIE_ARG(b.h == s.C && b.B == s.M && b.N == s.N && b.nslab == d.splitk &&
+                      (d.splitk == 1 || b.slab_stride == s.slab_stride),
+                  "fused BatchNorm: the BatchNorm problem must describe the product's own slab buffer");
+        JAMIE_ARG(b.gamma && b.beta && b.running_mean && b.running_var && b.save_mean && b.save_invstd, "null pointer");
+        JAMIE_ARG((b.out || b.out_bf16) && !b.outT_bf16 && (uintptr_t)b.out % 16 == 0 && (uintptr_t)b.out_bf16 % 8 == 0 &&
+                      (uintptr_t)b.mask % 4 == 0,
+                  "fused BatchNorm: fp32 and / or row-major bf16 output, aligned; no transposed copy");
+        JAMIE_ARG(((long long)(b.nslab - 1) * b.slab_stride + (long long)b.B * b.N) * 4 < 0xFFFFFFF0LL,
+                  "activation slabs must stay below 4 GiB");
+        BnFwdDev& q = f.p[i];
+        q.h = b.h; q.gamma = b.gamma; q.beta = b.beta; q.rmean = b.running_mean; q.rvar = b.running_var;
+        q.smean = b.save_mean; q.sinvstd = b.save_invstd; q.out = b.out; q.mask = b.mask;
+        q.out_bf = (unsigned short*)b.out_bf16; q.outT_bf = nullptr;
+        q.slab_stride = b.slab_stride; q.nslab = b.nslab; q.B = b.B; q.N = b.N; q.rng_stream = b.rng_stream;
+        f.ticket_base[i] = strips;
+        strips += d.tiles_n;
+        if (!b.mask && p_drop > 0.f) need_rng = true;
+        d.a_bytes = (unsigned)(((long long)(s.M - 1) * s.lda + s.K) * 2);
+        d.b_bytes = (unsigned)(((long long)(s.N - 1) * s.ldb + s.K) * 2);
+    }
+    JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
+    JAMIE_ARG(tickets != nullptr && n_tickets >= 4 + 2 * strips, "tickets: 4 + 2 words per 128-column strip, zero-initialised");
+    if (tiles == 0) return 0;
+    f.tickets = tickets; f.rng = rng; f.p_drop = p_drop; f.momentum = momentum; f.eps = eps; f.slope = slope; f.mode = mode;
+    hipLaunchKernelGGL((gemm_bf16_dma2_bn_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g, f);
+    return jamie_launch_status("jamie_gemm_bf16_bn");
+}
+
 static const int BT[33][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
                               {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128},
                               {64, 64}, {128, 128}, {256, 128}, {256, 128}, {64, 64},
@@ -1063,6 +1215,32 @@ extern "C" int jamie_gemm_bf16_ranges(const jamie_gemm_problem* pr, int count, i
     const int rc = jamie_range_ride_fill(g, g_bf16, offsets, lengths, n_ranges, partials, n_partials, state, fin, &rr, &blocks);
     if (rc) return rc;
     return gemm_bf16_impl(pr, count, cfg, stream, &rr, blocks);
+}
+
+extern "C" int jamie_gemm_bf16_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_problem* bn, int count, int cfg,
+                                  float p_drop, float momentum, float eps, float slope, const uint64_t* rng, unsigned* tickets,
+                                  int n_tickets, int mode, void* stream) {
+    JAMIE_ARG(pr != nullptr && bn != nullptr && count >= 1 && count <= JB_FUSE_MAX, "1 <= count <= 4");
+    JAMIE_ARG(p_drop >= 0.f && p_drop < 1.f, "0 <= p < 1");
+    JAMIE_ARG(mode == 1 || mode == 2, "mode: 1 (last arriver reduces) or 2 (every slice takes a share)");
+    for (int i = 0; i < count; ++i) {
+        const jamie_gemm_problem& s = pr[i];
+        JAMIE_ARG(s.A && s.B && s.C, "null operand");
+        JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
+        JAMIE_ARG(s.ldc >= s.N && s.lda >= s.K && s.ldb >= s.K, "leading dimensions");
+        JAMIE_ARG(s.K % 8 == 0 && s.lda % 8 == 0 && s.ldb % 8 == 0, "bf16 operands need K, lda, ldb multiples of 8");
+        JAMIE_ARG(((uintptr_t)s.A % 16) == 0 && ((uintptr_t)s.B % 16) == 0, "bf16 operands must be 16-byte aligned");
+        JAMIE_ARG(((long long)(s.M - 1) * s.lda + s.K) * 2 < 0xFFFFFFF0LL && ((long long)(s.N - 1) * s.ldb + s.K) * 2 < 0xFFFFFFF0LL,
+                  "operands must stay below 4 GiB");
+        JAMIE_ARG(s.splitk <= 1 || s.slab_stride >= (long long)s.M * s.ldc, "slab_stride too small");
+        JAMIE_ARG(s.a_rows == nullptr, "row gather is not supported in the bf16 GEMM");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (cfg) {
+        case 31: return launch_dma_bn<256, 128, 4, 4, 3>(pr, bn, count, p_drop, momentum, eps, slope, rng, tickets, n_tickets, mode, st);
+        case 32: return launch_dma_bn<128, 128, 2, 4, 3>(pr, bn, count, p_drop, momentum, eps, slope, rng, tickets, n_tickets, mode, st);
+        default: return jamie_fail(-1, "%s: tile configuration 31 or 32 [%lld %lld]", "jamie_gemm_bf16_bn", cfg, 0);
+    }
 }
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {

@@ -355,6 +355,7 @@ class TrainEngine:
         self.rsum = torch.empty(B, **f32); self.qsum = torch.empty(B, **f32)
         self.fc1 = torch.empty(B, L, **f32); self.fte = torch.empty(B, L, **f32)
         self.corr = torch.empty(B, B, **f32)
+        self._bn_tickets = {}            # per fused Linear + BatchNorm launch: the hand-off counters (_fwd_block)
         self.accumulate = False          # True: gradients add to the buffer (batch_step=False, jamie.py:736-749)
         self._dsig_tmp = torch.zeros(self.M, **f32)
         self._timing = None
@@ -557,6 +558,54 @@ class TrainEngine:
                 pr.dhT_bf16 = nv.ptr(w[da_key + '_T']) if da_key in self.need_T else None
             probs.append(pr)
         nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE, colsums)
+
+    # ---- Linear forward + BatchNorm + LeakyReLU + dropout as ONE launch (jamie_gemm_bf16_bn): the split-K slices of a column
+    # strip hand their fp32 slabs to each other inside the launch and run the BatchNorm strip code themselves -- no BatchNorm
+    # launch, no kernel boundary.  Built, bit-identical to the two launches (tests), measured, and OFF by default: on one box,
+    # interleaved, the step takes 638 us with the launch pairs, 676 us with the hand-off in which every slice takes a share of the
+    # strip (JAMIE_FUSED_BN_MODE=2) and 759 us when the last slice to arrive reduces the strip (mode 1)
+    # (profiles/r03_ab_fused_bn_rejected.log).  In-kernel stamps (profiles/r03_stamps_fused_bn_v1.log, 256 x 128 tiles): write-through slab
+    # stores 5.5 us instead of 3.6, the wait for the strip's other slices 2-6 us, the strip phase itself 17.5 us (7.7 us on the
+    # 128 x 128 launches) against 11.4 us for the whole BatchNorm launch: the slabs cross the fabric either way (another CU wrote
+    # them), and inside the launch that traffic is serialised behind the slowest slice of every strip instead of overlapping
+    # nothing at all.  JAMIE_FUSED_BN=1 switches it on (tools/ab.sh).
+    def _fused_bn_ok(self, sk_key, out_key):
+        return (self.bf16 and self.fuse_bf16 and self.B <= 512 and self.M <= 4 and self.gcfg.get(sk_key, -1) in (31, 32)
+                and all(n % 4 == 0 for n in self.dims) and out_key not in self.need_T and not self.pipeline
+                and os.environ.get('JAMIE_FUSED_BN', '0') == '1')
+
+    def _fwd_block(self, a_key, lin, h_key, sk_key, layer, out_key, stream_base, noise, kind, j):
+        """out = Dropout(LeakyReLU(BatchNorm(a W^T + b)))  (model.py:151-154 and siblings): one launch where the large-tile
+        bf16 plan applies, else the product and the BatchNorm launch."""
+        if not self._fused_bn_ok(sk_key, out_key):
+            self._fwd_gemm(a_key, lin, h_key, sk_key)
+            self._bn_fwd(layer, h_key, out_key, stream_base, noise, kind, j)
+            self._cast(out_key)
+            return
+        probs, bns = [], []
+        for i, d in enumerate(self.dims):
+            w, P, bn = self.ws[i], self.m.p, self.m.bn
+            W, h = P[f'm{i}.{lin}.W'], w[h_key]
+            nout, nin = W.shape
+            probs.append(nv.gemm_problem(w[a_key + '_bf'], self.wbf[f'm{i}.{lin}.W'], h, self.B, nout, nin, nin, nin, nout,
+                                         bias=P[f'm{i}.{lin}.b'], splitk=w['sk'][sk_key], slab_stride=self.B * nout))
+            pr = nv.BnFwdProblem()
+            pr.h, pr.nslab, pr.slab_stride = nv.ptr(h), h.shape[0], h.shape[1] * h.shape[2]
+            pr.gamma, pr.beta = nv.ptr(P[f'm{i}.{layer}.g']), nv.ptr(P[f'm{i}.{layer}.b'])
+            pr.running_mean, pr.running_var = nv.ptr(bn[f'm{i}.{layer}.mean']), nv.ptr(bn[f'm{i}.{layer}.var'])
+            pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
+            pr.out, pr.mask = None, nv.ptr(self._mask(noise, kind, i, j))
+            pr.out_bf16, pr.outT_bf16 = nv.ptr(w[out_key + '_bf']), None
+            pr.B, pr.N, pr.rng_stream = self.B, h.shape[2], stream_base + 8 * i
+            bns.append(pr)
+        tk = self._bn_tickets.get(lin)
+        if tk is None:
+            tk = self._bn_tickets[lin] = torch.zeros(4 + 2 * sum((2 * d + 127) // 128 for d in self.dims), dtype=torch.int32,
+                                                     device=self.dev)
+        mode = int(os.environ.get('JAMIE_FUSED_BN_MODE', '2'))
+        cfg = self.gcfg[sk_key]
+        self._launch('enc_gemm', lambda: nv.gemm_bf16_bn(probs, bns, cfg, self.p_drop, self.state, tk, mode,
+                                                          BN_MOMENTUM, BN_EPS, LRELU_SLOPE))
 
     def _fwd_gemm(self, a_key, lin, out_key, sk_key, with_bias=True):
         """out[B, out_f] (slabs) = a[B, in_f] W^T (+ b)."""
@@ -892,12 +941,8 @@ class TrainEngine:
     def _forward(self, corr, Fblk, noise, fused_losses):
         B, L = self.B, self.L
         # ---------------- forward ----------------
-        self._fwd_gemm('x', 'enc0', 'h1', 'enc0')
-        self._bn_fwd('bn0', 'h1', 'a1', 10, noise, 'enc_masks', 0)
-        self._cast('a1')
-        self._fwd_gemm('a1', 'enc1', 'h2', 'enc1')
-        self._bn_fwd('bn1', 'h2', 'a2', 11, noise, 'enc_masks', 1)
-        self._cast('a2')
+        self._fwd_block('x', 'enc0', 'h1', 'enc0', 'bn0', 'a1', 10, noise, 'enc_masks', 0)
+        self._fwd_block('a1', 'enc1', 'h2', 'enc1', 'bn1', 'a2', 11, noise, 'enc_masks', 1)
         self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)      # bias added in the latent kernel
         fused = fused_losses and self._fused_latent(corr, Fblk)
         lat = self._latent_desc(corr, Fblk, noise, fused)
@@ -907,9 +952,7 @@ class TrainEngine:
             self._fwd_gemm('comb', 'dec0', 'g1', 'dec0')
         self._bn_fwd('bn2', 'g1', 'e1', 12, noise, 'dec_masks', 0)
         self._cast('e1')
-        self._fwd_gemm('e1', 'dec1', 'g2', 'dec1')
-        self._bn_fwd('bn3', 'g2', 'e2', 13, noise, 'dec_masks', 1)
-        self._cast('e2')
+        self._fwd_block('e1', 'dec1', 'g2', 'dec1', 'bn3', 'e2', 13, noise, 'dec_masks', 1)
         if not fused_losses:                                              # plain x_hat (autograd seam)
             for w, d in zip(self.ws, self.dims):
                 if w['xhat'] is None:
@@ -1291,4 +1334,7 @@ class TrainEngine:
     def read_losses(self):
         """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""
         v = self.losses.tolist()
+        for lin, tk in self._bn_tickets.items():      # (a bounded in-launch wait that gave up leaves word 0 set)
+            if int(tk[0].item()) != 0:
+                raise nv.JamieHipError(f'fused Linear + BatchNorm launch of layer {lin}: a split-K hand-off wait timed out')
         return v[:4], v[4], v[5]
