@@ -31,7 +31,11 @@ CONFIGS = {
     'c2': (100000, (2000, 1000), 32),
     'c4': (100000, (2000, 1000, 500), 64),       # 3 modalities (build-defined generalisation; no reference oracle)
     'c5dims': (100000, (5000, 2000), 64),
+    # BASELINE config 5 at its own size: 1 M cells (28 GB of fp32 over the job; one rank holds 28 / world GB), fp32 by default
+    'c5': (1_000_000, (5000, 2000), 64),
 }
+DEFAULT_DTYPE = {'c5': 'f32'}
+ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the exposure model (dp_model): stated, not measured
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -47,13 +51,58 @@ def synth_shard(n_cells, lo, hi, dims, rank, world, device):
     A = [rng.standard_normal((16, d), dtype=np.float32) for d in dims]
     erng = rng if world == 1 else np.random.default_rng([0, 1 + rank])
     Zd = torch.from_numpy(Z).to(device)
+    # beyond 1e9 noise values per rank (config 5: 7e9 at one rank) the E_i are drawn ON THE DEVICE (torch Philox generator
+    # seeded per rank, 100 000 rows at a time into the output) -- numpy would spend minutes and 28 GB of host memory on
+    # them; Z and the A_i still come from default_rng(0), so the factor structure is the same for every world size
+    on_device = (hi - lo) * sum(dims) > 1_000_000_000
+    gen = torch.Generator(device=device).manual_seed(1000 + rank) if on_device else None
     out = []
     for a in A:
-        E = torch.from_numpy(erng.standard_normal((hi - lo, a.shape[1]), dtype=np.float32)).to(device)
-        x = Zd @ torch.from_numpy(a).to(device) + 0.1 * E
-        del E
-        x = (x - x.mean(0)) / x.std(0, unbiased=False)
+        ad = torch.from_numpy(a).to(device)
+        if on_device:
+            x = torch.empty(hi - lo, a.shape[1], device=device, dtype=torch.float32)
+            for r0 in range(0, hi - lo, 100_000):
+                blk = x[r0:r0 + 100_000]
+                blk.normal_(generator=gen).mul_(0.1).addmm_(Zd[r0:r0 + 100_000], ad)
+            mean = x.mean(0)
+            var = torch.zeros_like(mean)
+            for r0 in range(0, hi - lo, 100_000):
+                var += (x[r0:r0 + 100_000] - mean).square().sum(0)
+            std = (var / (hi - lo)).sqrt()
+            for r0 in range(0, hi - lo, 100_000):
+                x[r0:r0 + 100_000].sub_(mean).div_(std)
+        else:
+            E = torch.from_numpy(erng.standard_normal((hi - lo, a.shape[1]), dtype=np.float32)).to(device)
+            x = Zd @ ad + 0.1 * E
+            del E
+            x = (x - x.mean(0)) / x.std(0, unbiased=False)
         out.append(x.contiguous())
+    return out
+
+
+def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_f32):
+    """Exposure model of the gradient exchange for `world` GPUs from ONE GPU's timeline (bench.py --dry-run-world): the
+    messages (bytes, time after the step's first launch at which the backward pass announces them: HIP events of the dry
+    run) go over one wire, in order, at the all-reduce algorithm bandwidth algbw = busbw * n / (2 (n - 1)) for an ASSUMED bus
+    bandwidth (ASSUMED_BUS_GBS; a ring over xGMI is per-link bound: tools/rccl_probe.py measures the real figure); whatever
+    is still on the wire when the backward pass ends is exposed in front of the norm kernel.  Collectives and backward kernels
+    are assumed not to slow each other down (they will, somewhat: both use HBM).  Returns the block printed as `dp_model`."""
+    algbw = ASSUMED_BUS_GBS * world / (2.0 * (world - 1))
+    msgs = [(b, t) for k, b, t in trace_ms if k == 'message']
+    fin = [t for k, b, t in trace_ms if k == 'finish']
+    bwd_end = fin[0] if fin else max(t for _, t in msgs)
+    out = {'world': world, 'assumed_bus_bandwidth_GBps': ASSUMED_BUS_GBS, 'algorithm_bandwidth_GBps': algbw,
+           'messages': [{'bytes': int(b), 'announced_us': 1e3 * t} for b, t in msgs],
+           'backward_end_us': 1e3 * bwd_end, 'step_us_dry_run': 1e3 * step_ms_dry, 'step_us_one_gpu': 1e3 * step_ms_one}
+    for name, scale in (('as_run', 1.0), ('fp32_messages' if msg_scale_f32 == 2.0 else 'bf16_messages', msg_scale_f32)):
+        wire = 0.0
+        for b, t in msgs:
+            wire = max(wire, t) + 1e3 * (b * scale / 1e9) / algbw        # ms
+        exposed = max(0.0, wire - bwd_end)
+        pred = step_ms_dry + exposed
+        out[name] = {'message_bytes_total': int(sum(b for b, _ in msgs) * scale), 'exposed_us': 1e3 * exposed,
+                     'predicted_step_us': 1e3 * pred, 'predicted_scaling_efficiency': step_ms_one / pred,
+                     'predicted_speedup': world * step_ms_one / pred}
     return out
 
 
@@ -231,8 +280,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=512)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'],
-                    help='GEMM operand type: bf16 (BASELINE config 2; fp32 accumulate/master) or f32 (parity config)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'],
+                    help='GEMM operand type: bf16 (BASELINE config 2; fp32 accumulate/master; the default except for c5) or f32 '
+                         '(the parity configuration; BASELINE config 5 is quoted in fp32)')
     ap.add_argument('--grad-comm', default='auto', choices=['auto', 'f32', 'bf16'],
                     help='dtype of the gradient all-reduce messages (auto: the compute dtype; tests/test_host_cpu.py::test_bf16_message_sum_keeps_the_clip_norm)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -254,6 +304,8 @@ def main():
     ap.add_argument('--opt-priority', type=int, default=0, help='HIP stream priority of the optimiser stream')
     ap.add_argument('--cpu-budget', type=float, default=24.0)
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = DEFAULT_DTYPE.get(args.config, 'bf16')
 
     # RCCL's own account of the communicator it builds (read back into the JSON line at N > 1): init-time log only
     log_dir = None
@@ -350,6 +402,36 @@ def main():
     if not np.isfinite(total):
         raise SystemExit('non-finite loss in benchmark')
     cells_s = world * B * args.steps / dt
+    dp = None
+    if args.dry_run_world > 1 and world == 1:
+        # the exchange's timeline: events where the backward pass announces each message and where it starts waiting
+        traces = []
+        for _ in range(12):
+            allreduce.enable_trace()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(nv.current_stream())
+            step()
+            torch.cuda.synchronize()
+            traces.append([(k, b, e0.elapsed_time(ev)) for k, b, ev in allreduce.trace])
+        allreduce.enable_trace(False)
+        med = [(traces[0][i][0], traces[0][i][1], float(np.median([t[i][2] for t in traces]))) for i in range(len(traces[0]))]
+        # the one-GPU step on the same box, for the efficiency the model predicts
+        torch.manual_seed(666)
+        m1 = edModelVar(dims, L, device=dev, pad_features=pad)
+        e1 = TrainEngine(m1, B, lr=1e-3, seed=666, compute_dtype=args.dtype, grad_bf16=False if args.grad_fp32 else None)
+        e1.set_kl_anneal(0.5)
+        idx1 = torch.zeros(B, dtype=torch.int32, device=dev)
+        p1 = e1.make_plan(data, idx1, hi - lo, rep, None)
+        for _ in range(30):
+            e1.run_plan(p1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            e1.run_plan(p1)
+        torch.cuda.synchronize()
+        one_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        dp = dp_model(med, 1e3 * dt / args.steps, one_ms, args.dry_run_world, 2.0 if comm is not None else 0.5)
+        del p1, e1, m1
 
     if rank == 0:
         # roofline of the dominant kernel:
@@ -414,6 +496,7 @@ def main():
         }
         if args.dry_run_world > 1:
             out['dry_run_world'] = args.dry_run_world
+            out['dp_model'] = dp
             out['metric'] += f' [DRY RUN: per-rank compute path of a {args.dry_run_world}-rank step, collectives skipped; not a benchmark line]'
         if world > 1:
             out['rccl'] = rccl_record(world, log_dir) if log_dir else {'backend': torch.distributed.get_backend(),

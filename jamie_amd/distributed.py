@@ -92,14 +92,21 @@ class OverlappedGradAllReduce:
         self.comm = None             # persistent low-precision exchange buffer (same offsets as the flat gradient)
         self.works = []
         self.stream = None           # side stream of the cast + collective (low-precision messages on the GPU)
-        self.pending = None          # (flat, lo, hi) not yet issued
-        self._casts = {}             # (lo, hi) -> prepared fp32 -> bf16 cast launch of that region (jamie_cast_transpose)
+        self.pending = None          # (flat, lo, hi, precast) not yet issued
+        self._casts = {}             # (flat ptr, message-buffer ptr, lo, hi) -> prepared fp32 -> bf16 cast launch of that region
+        self.trace = None            # enable_trace(): [(kind, bytes, HIP event)] of one step (bench.py's exposure model)
+
+    def enable_trace(self, on=True):
+        """Record a HIP event on the launch stream wherever a message is issued and where `finish()` starts waiting: the
+        timeline bench.py's `dp_model` block prices the exchange against (dry runs and real ones alike)."""
+        self.trace = [] if on else None
 
     def message_buffer(self, flat):
         """The persistent low-precision exchange buffer (same offsets as the flat gradient): a producer that writes its
         gradients into it directly (the bf16 dW epilogues, TrainEngine) announces its regions with `precast=True`."""
         if self.comm is None or self.comm.numel() != flat.numel() or self.comm.device != flat.device:
             self.comm = torch.zeros(flat.numel(), dtype=self.comm_dtype, device=flat.device)
+            self._casts.clear()          # (the prepared cast launches hold raw pointers into the old buffer)
         return self.comm
 
     def region_done(self, flat, lo, hi, precast=False):
@@ -107,20 +114,29 @@ class OverlappedGradAllReduce:
         no side stream -- the collective is issued where it stands (RCCL orders it behind the launches before it)."""
         if self.world == 1:
             return
-        self._precast = bool(precast)
-        if self.pending is not None and self.pending[2] == lo:       # forward-adjacent
-            lo = self.pending[1]
-        elif self.pending is not None and self.pending[1] == hi:     # backward-adjacent (the usual case)
-            hi = self.pending[2]
-        elif self.pending is not None:
-            self._issue(*self.pending)
-        self.pending = (flat, lo, hi)
+        precast = bool(precast)
+        pend = self.pending
+        if pend is not None and (pend[0] is not flat or pend[3] != precast):      # another buffer / another path: no merging
+            self._issue(*pend)
+            pend = None
+        if pend is not None and pend[2] == lo:       # forward-adjacent
+            lo = pend[1]
+        elif pend is not None and pend[1] == hi:     # backward-adjacent (the usual case)
+            hi = pend[2]
+        elif pend is not None:
+            self._issue(*pend)
+        self.pending = (flat, lo, hi, precast)
         if (hi - lo) * (flat.element_size() if self.comm_dtype is None else 2) >= self.min_bytes:
             self._issue(*self.pending)
             self.pending = None
 
-    def _issue(self, flat, lo, hi):
-        if self.comm_dtype is not None and getattr(self, '_precast', False):
+    def _issue(self, flat, lo, hi, precast=False):
+        if self.trace is not None and flat.is_cuda:
+            from . import _native as nv
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(nv.current_stream())
+            self.trace.append(('message', (hi - lo) * (flat.element_size() if self.comm_dtype is None else 2), ev))
+        if self.comm_dtype is not None and precast:
             buf = self.message_buffer(flat)[lo:hi]
             self.works.append((None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
                                None, None, None))
@@ -138,10 +154,11 @@ class OverlappedGradAllReduce:
                 self.stream = torch.cuda.Stream(device=flat.device)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            cast = self._casts.get((lo, hi))
+            key = (flat.data_ptr(), buf.data_ptr(), lo, hi)
+            cast = self._casts.get(key)
             if cast is None:
                 from . import _native as nv
-                cast = self._casts[(lo, hi)] = nv.FlatCast(flat[lo:hi], buf)
+                cast = self._casts[key] = nv.FlatCast(flat[lo:hi], buf)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 cast.run(self.stream)                     # fp32 region -> bf16 message buffer (HIP launch, no ATen op)
@@ -158,6 +175,11 @@ class OverlappedGradAllReduce:
         if self.pending is not None:
             self._issue(*self.pending)
             self.pending = None
+        if self.trace is not None and torch.cuda.is_available() and self.works:
+            from . import _native as nv
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(nv.current_stream())
+            self.trace.append(('finish', 0, ev))
         for w, flat, lo, hi in self.works:
             if w is not None:
                 w.wait()
