@@ -54,7 +54,7 @@ def synth_shard(n_cells, lo, hi, dims, rank, world, device):
     # beyond 1e9 noise values per rank (config 5: 7e9 at one rank) the E_i are drawn ON THE DEVICE (torch Philox generator
     # seeded per rank, 100 000 rows at a time into the output) -- numpy would spend minutes and 28 GB of host memory on
     # them; Z and the A_i still come from default_rng(0), so the factor structure is the same for every world size
-    on_device = (hi - lo) * sum(dims) > 1_000_000_000
+    on_device = (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1'
     gen = torch.Generator(device=device).manual_seed(1000 + rank) if on_device else None
     out = []
     for a in A:
@@ -280,6 +280,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--cells', type=int, default=0, help='override the configuration\'s cell count (tests: config c5\'s code path at a '
+                    'reduced N; the JSON line names the count it ran)')
     ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'],
                     help='GEMM operand type: bf16 (BASELINE config 2; fp32 accumulate/master; the default except for c5) or f32 '
                          '(the parity configuration; BASELINE config 5 is quoted in fp32)')
@@ -326,6 +328,8 @@ def main():
     from jamie_amd.model import edModelVar
 
     n_cells, dims, L = CONFIGS[args.config]
+    if args.cells > 0:
+        n_cells = args.cells
     B = args.batch
     if args.dtype == 'bf16' and any(v % 8 for v in [L, B]):
         args.dtype = 'f32'          # bf16 operands need a latent size and a batch that are multiples of 8
@@ -485,7 +489,8 @@ def main():
                                    f'latent={L}, B={B}/GPU, dropout={model.dropout}, '
                                    + (('bf16 MFMA GEMMs, fp32 accumulate/master/optimiser, ' + ('bf16 weight gradients (autocast semantics), ' if eng.grad_bf16 else 'fp32 weight gradients, ')) if args.dtype == 'bf16' else 'fp32 MFMA, ')
                                    + 'identity P (diag sampling), F=0, KL anneal per epoch',
-                       'generator': 'SURVEY.md 8(d): numpy default_rng(0), 16-dim latent factor model + 0.1 noise, standardised per feature',
+                       'generator': 'SURVEY.md 8(d): numpy default_rng(0), 16-dim latent factor model + 0.1 noise, standardised per feature'
+                                    + ('; the noise term drawn on the device (torch generator per rank)' if (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1' else ''),
                        'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
                        'parallelism': f'dp{world}', 'grad_allreduce': ('none' if world == 1 else ('bf16' if comm is not None else 'f32')),
                        'parameters': model.num_parameters(),

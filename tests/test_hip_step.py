@@ -327,6 +327,28 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert np.isfinite(out['final_loss'])
 
 
+def test_bench_config5_path_two_ranks_at_reduced_cells(tmp_path):
+    """BASELINE config 5's bench path -- `--config c5` (fp32 by default, (5000, 2000) features, latent 64, the noise term of the
+    generator drawn on the device) -- at a reduced cell count, two ranks sharing cuda:0 over gloo: contiguous row shards, the
+    fp32 gradient all-reduce of 233 M parameters in overlapped regions, one JSON line naming what ran."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JAMIE_DIST_BACKEND='gloo', JAMIE_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', JAMIE_BENCH_DEVICE_NOISE='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29579', os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--steps', '3', '--warmup', '1', '--config', 'c5', '--cells', '6001'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['dtype'] == 'f32' and out['config']['cells'] == 6001
+    assert out['config']['features'] == [5000, 2000] and out['config']['parameters'] == 233477258
+    assert 'drawn on the device' in out['config']['generator'] and out['config']['grad_allreduce'] == 'f32'
+    assert np.isfinite(out['final_loss']) and out['value'] > 0
+
+
 @pytest.mark.parametrize('mode', ['f32_buckets', 'bf16_overlapped_plan'])
 def test_data_parallel_ranks_stay_identical(tmp_path, mode):
     """Two ranks (sharing cuda:0, gloo) training on different shards keep bit-identical parameters after
