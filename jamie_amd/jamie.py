@@ -42,8 +42,12 @@ class JAMIE:
 
     Constructor keywords are the reference's (jamie.py:38-63) plus the UnionCom keywords it forwards
     (jamie.py:99-111; defaults from unioncom==0.4.0).  Extra, MI355X-only keywords:
-      sampler      'numpy' (default; the reference's `np.random.choice` index stream) or 'device'
-                   (Philox sampler on the GPU, no host work per step)
+      sampler      'auto' (default): 'device' -- Philox batch sampler on the GPU, the step replayed from a recorded launch
+                   plan, no host work per step -- unless an explicit-noise seam is installed (`_noise_source`, the fixture
+                   replays), then 'numpy'; 'numpy': the reference's `np.random.choice` index stream under `np.random.seed`
+                   (drawn on the host every step: ~1 ms at 100k cells); 'device'.  Dropout masks and the reparameterisation noise
+                   come from device Philox streams either way, so a production run does not replay the reference's numbers
+                   whichever sampler draws the rows: the numpy stream matters to the fixture replays only
       distributed  True -> one process per GPU under torchrun; cells are sharded by rows and the flat
                    gradient is all-reduced once per step over RCCL
       compute_dtype 'f32' (default: exact-fp32 MFMA, the parity configuration) or 'bf16' (bf16 MFMA GEMMs with
@@ -58,7 +62,7 @@ class JAMIE:
                  dropout=None, pca_dim=2 * [512], batch_step=True, use_f_tilde=True, use_early_stop=True,
                  min_epochs=2500, min_increment=1e-8, max_steps_without_increment=500, debug=False,
                  log_debug=100, record_loss=True, enable_memory_logging=False, device='cuda',
-                 sampler='numpy', distributed=False, compute_dtype='f32', grad_comm_dtype='auto',
+                 sampler='auto', distributed=False, compute_dtype='f32', grad_comm_dtype='auto',
                  preprocess='host', checkpoint_path=None, checkpoint_every=0, **kwargs):
         self.match_result = match_result
         self.PF_Ratio = PF_Ratio
@@ -84,6 +88,8 @@ class JAMIE:
         if device == 'cpu':
             raise nv.JamieHipError("jamie_amd runs on the MI355X only; use device='cuda' (no CPU fallback)")
         self.device = device
+        if sampler not in ('auto', 'numpy', 'device'):
+            raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
         self.sampler = sampler
         self.distributed = distributed
         self.compute_dtype = compute_dtype
@@ -376,13 +382,14 @@ class JAMIE:
         # fast path: device sampler, 'diag' sampling, no dense P/F blocks -> the step is a fixed launch sequence on
         # static buffers: record it once and replay it (one foreign call per launch, nothing rebuilt per step)
         plan = None
-        use_plan = (self.sampler == 'device' and method == 'diag' and P_dense is None and F_dense is None
+        sampler = self.sampler if self.sampler != 'auto' else ('numpy' if self._noise_source is not None else 'device')
+        use_plan = (sampler == 'device' and method == 'diag' and P_dense is None and F_dense is None
                     and P_csr is None and self.PF_Ratio == 1 and self.batch_step)
         # partial correspondence from a sparse P with the device sampler: pair / rest candidates from jamie_sample_indices,
         # jamie_hybrid_assemble picks per slot, jamie_csr_block builds the [B,B] block -- the whole step stays on the GPU and
         # is recorded as a plan too (the numpy sampler costs 2 ms of host time per step at 100k cells: np.random.choice without
         # replacement permutes all N rows)
-        plan_hybrid = (self.sampler == 'device' and method == 'hybrid' and P_csr is not None and F_dense is None
+        plan_hybrid = (sampler == 'device' and method == 'hybrid' and P_csr is not None and F_dense is None
                        and self.PF_Ratio == 1 and self.batch_step and world == 1 and B <= 2048)
         if plan_hybrid:
             pairs_dev = torch.from_numpy(np.ascontiguousarray(self.corr_samples.astype(np.int32))).to(dev)
@@ -434,15 +441,16 @@ class JAMIE:
                         rest = np.random.choice(rows[i], B - corr_sample_num, replace=rep)
                         s = np.concatenate([pairs[:, i], rest], axis=0)
                         idx_dev[i].copy_(torch.from_numpy(s.astype(np.int32)))
-                elif self.sampler == 'numpy':
+                elif sampler == 'numpy':
                     if method == 'diag':
-                        s = np.random.choice(range(rows[0]), B, replace=rep)
+                        s = np.random.choice(rows[0], B, replace=rep)      # (= choice(range(N), ...): the same stream
+                                                                           #  without the 100k-element list conversion)
                         idx_dev[0].copy_(torch.from_numpy(s.astype(np.int32)))
                         for j in range(1, self.dataset_num):
                             idx_dev[j].copy_(idx_dev[0])
                     else:
                         for i in range(2):
-                            s = np.random.choice(range(rows[i]), B, replace=rep)
+                            s = np.random.choice(rows[i], B, replace=rep)
                             idx_dev[i].copy_(torch.from_numpy(s.astype(np.int32)))
                 else:
                     nv.sample_indices(idx_dev[0], rows[0], 0, rep, eng.state, 200)

@@ -907,7 +907,7 @@ def test_facade_sparse_P_equals_dense_P(jam):
     for Pm in (P, sp.coo_matrix(P)):
         np.random.seed(11)
         jm = jam.JAMIE(output_dim=4, batch_size=64, epoch_DNN=6, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9,
-                       dropout=0.0)
+                       dropout=0.0, sampler='numpy')       # (the default sampler would draw the sparse case's rows on the device)
         embs.append(_quiet(lambda: jm.fit_transform(dataset=data, P=Pm)))
         assert jm.sampling_method == 'hybrid' and jm.num_corr == N // 3
     for a, b in zip(*embs):
