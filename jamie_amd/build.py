@@ -59,7 +59,14 @@ def build_library(force=False, verbose=False, jobs=None):
     extra = os.environ.get('JAMIE_HIPCC_FLAGS', '').split()
     os.makedirs(OBJ, exist_ok=True)
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in srcs]
-    todo = [(s, o) for s, o in zip(srcs, objs) if force or extra or _mtime(o) < max(_mtime(s), hnew)]
+    # the flag string the objects were built with is recorded: a build with other flags (a diagnostic JAMIE_HIPCC_FLAGS build, or
+    # the plain build after one) recompiles everything instead of trusting the time stamps -- otherwise a later plain build would
+    # keep serving the instrumented library
+    stamp = os.path.join(OBJ, 'FLAGS')
+    flags_now = ' '.join(FLAGS + extra)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or _mtime(o) < max(_mtime(s), hnew)]
     if not todo and _mtime(LIB) >= max(_mtime(o) for o in objs):
         return LIB
 
@@ -71,6 +78,8 @@ def build_library(force=False, verbose=False, jobs=None):
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(cc, todo))
+    with open(stamp, 'w') as f:
+        f.write(flags_now)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -109,7 +109,9 @@ def _whiten(Y, rounds=1, cond_limit=1e5):
     for _ in range(rounds):
         G = mm_tn(Y, Y).double().cpu().numpy()
         w, V = np.linalg.eigh((G + G.T) * 0.5)
-        if w.min() * cond_limit < w.max():
+        # (w.max() <= 0: an all-zero sketch -- a constant modality / zero-variance features after centring -- would give
+        #  V / sqrt(0) = inf / NaN scores; the host QR returns a finite basis, as sklearn does)
+        if w.max() <= 0 or not np.isfinite(w).all() or w.min() * cond_limit < w.max():
             return _host_qr(Y)
         T = torch.from_numpy((V / np.sqrt(w)).astype(np.float32)).to(Y.device)
         Y = mm_nn(Y, T)

@@ -137,3 +137,16 @@ def test_facade_device_pca_preprocessing(jam):
     jm2.load_model(buf)
     np.testing.assert_array_equal(jm2.transform(data)[0], tr[0])
     np.testing.assert_allclose(jm2.modal_predict(data[0], 0), imp, rtol=1e-12)
+
+
+def test_device_pca_constant_matrix_gives_finite_zero_scores(jam):
+    """A constant modality (zero variance after centring): the sketch's Gram matrix is all zero; the scores are finite zeros
+    like sklearn's, not V / sqrt(0)."""
+    from jamie_amd.pca import DevicePCA
+    X = np.full((600, 120), 3.25, dtype=np.float32)
+    dp = DevicePCA(8, random_state=0)
+    scores = dp.fit_transform_device(torch.from_numpy(X)).cpu().numpy()
+    assert scores.shape == (600, 8) and np.isfinite(scores).all() and np.abs(scores).max() < 1e-4
+    assert np.isfinite(dp.components_).all() and np.isfinite(dp.explained_variance_).all()
+    assert np.abs(dp.explained_variance_).max() < 1e-8
+    np.testing.assert_allclose(dp.mean_, 3.25)
