@@ -61,6 +61,13 @@ struct BnFuse {
 };
 
 #define JB_OOB 0xFFFFFFF0u
+// cache policy of the large-tile kernel's B-operand LDS-DMA where B is the WEIGHTS (read once per pass, HBM-cold behind the
+// optimiser): JB_W_NT = 0 default policy; 1 non-temporal (aux = 2) in the forward launches; 2 in the forward and dX launches
+// (MI355X_MICROARCH.md row nt-weights; A/B builds with -DJB_W_NT=.., tools/ab.sh + JAMIE_LIB).  Never for dW (B = activations,
+// re-read by every tile row): on ALL launches the step took 681 instead of 635 us (profiles/r03_ab_nt_weights_rejected.log).
+#ifndef JB_W_NT
+#define JB_W_NT 0
+#endif
 
 // Diagnostic build only (-DJAMIE_GEMMB_STAMP, tools/stamp_gemm_bf16.sh): thread 0 of every workgroup of the large-tile
 // kernel writes s_memrealtime (100 MHz) at entry / tile 0 published / k-loop done / stores issued into a buffer of its
@@ -575,6 +582,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     // both DMA fills and the 32x32x16 transposed reads are conflict-free (cdna_hip_programming.md T10 (b)).
     const bool b_tr = TRM != 0 && P.b_tr != 0;
     const long long b_kstep = b_tr ? (long long)P.ldb : 1;
+    const bool w_nt = JB_W_NT >= 1 && !a_tr && (JB_W_NT >= 2 || !b_tr) && (TRM == 0 || b_tr);
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         if (b_tr) {
@@ -596,9 +604,15 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
 #pragma unroll
             for (int i = 0; i < PA; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0 * a_kstep), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
+            if (w_nt) {          // (wave-uniform) the weights of a forward / dX product: streamed, see JB_W_NT
 #pragma unroll
-            for (int i = 0; i < PB; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
+                for (int i = 0; i < PB; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
+            }
         } else {   // partial k-tile: masked loads through registers into the same swizzled image
 #pragma unroll
             for (int j = 0; j < LA; ++j) {

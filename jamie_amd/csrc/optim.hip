@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 //   * one workgroup (if smp.idx): the next batch's sampler (state[1] already holds the next step's number), and / or
 //   * the next batch's row gather + bf16 cast (jamie_cast_transpose's 64 x 64 tiles; the batch buffers are free once the last dW
 //     product of this step has run).  Sampler and gather never ride together here: the gather needs the sampler's output.
+// Cache policy of the optimiser's streams (A/B switches: tools/ab.sh + JAMIE_LIB builds).  Round 3: the fp32 stores of p, m, v
+// (484 MB per step, next read a whole step later) go out NON-TEMPORALLY: through the caches they stayed behind as dirty lines
+// whose write-back ran into the next step's first launches -- the forward GEMMs took 31.5 instead of 28.8 us each and the kernel
+// itself 196 instead of 191 us: 638 -> 622 us per step on one box, interleaved (profiles/r03_ab_adam_cache_policy.log; the
+// stand-alone microbenchmark, tools/bench_adam.py, had said "2 % slower" in round 1: what the stores cost shows in the kernels
+// AFTER them).  Loading p and g non-temporally as well: the step another -4 us, the kernel +7 us: not adopted (LD_NT).  The
+// bf16 weight copy non-temporal or not: no difference once the fp32 stores are (W16_NT stays 1).
+#ifndef JAMIE_ADAM_W16_NT
+#define JAMIE_ADAM_W16_NT 1
+#endif
+#ifndef JAMIE_ADAM_ST_NT
+#define JAMIE_ADAM_ST_NT 1
+#endif
+#ifndef JAMIE_ADAM_LD_NT
+#define JAMIE_ADAM_LD_NT 0
+#endif
 template <int U, int T, bool RIDE>
 __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
@@ -102,13 +118,23 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
             if (i < n4) {
                 // the moments are read once per step: non-temporal loads (in the step -2..-4 us; the master weights and the
                 // stores of all three measured no better streamed)
+#if JAMIE_ADAM_LD_NT      // (A/B build: master weights and gradient loaded non-temporally as well)
+                pp[u] = make_float4(__builtin_nontemporal_load(&p[4 * i]), __builtin_nontemporal_load(&p[4 * i + 1]),
+                                    __builtin_nontemporal_load(&p[4 * i + 2]), __builtin_nontemporal_load(&p[4 * i + 3]));
+#else
                 pp[u] = p4[i];
+#endif
                 mm[u] = make_float4(__builtin_nontemporal_load(&m[4 * i]), __builtin_nontemporal_load(&m[4 * i + 1]),
                                     __builtin_nontemporal_load(&m[4 * i + 2]), __builtin_nontemporal_load(&m[4 * i + 3]));
                 vv[u] = make_float4(__builtin_nontemporal_load(&v[4 * i]), __builtin_nontemporal_load(&v[4 * i + 1]),
                                     __builtin_nontemporal_load(&v[4 * i + 2]), __builtin_nontemporal_load(&v[4 * i + 3]));
                 if (g_bf16) {      // reduced gradient read straight from the bf16 message buffer (no fp32 copy-back pass)
+#if JAMIE_ADAM_LD_NT
+                    const unsigned long long q64 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(g_bf16) + i);
+                    const uint2 q = make_uint2((unsigned)q64, (unsigned)(q64 >> 32));
+#else
                     const uint2 q = reinterpret_cast<const uint2*>(g_bf16)[i];
+#endif
                     gg[u] = make_float4(bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y));
                 } else {
                     gg[u] = g4[i];
@@ -161,7 +187,16 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
             upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
             upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z);
             upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
+#if JAMIE_ADAM_ST_NT      // (A/B build: the fp32 streams stored non-temporally, so that only the bf16 weights allocate in the caches)
+            __builtin_nontemporal_store(pp[u].x, &p[4 * i]); __builtin_nontemporal_store(pp[u].y, &p[4 * i + 1]);
+            __builtin_nontemporal_store(pp[u].z, &p[4 * i + 2]); __builtin_nontemporal_store(pp[u].w, &p[4 * i + 3]);
+            __builtin_nontemporal_store(mm[u].x, &m[4 * i]); __builtin_nontemporal_store(mm[u].y, &m[4 * i + 1]);
+            __builtin_nontemporal_store(mm[u].z, &m[4 * i + 2]); __builtin_nontemporal_store(mm[u].w, &m[4 * i + 3]);
+            __builtin_nontemporal_store(vv[u].x, &v[4 * i]); __builtin_nontemporal_store(vv[u].y, &v[4 * i + 1]);
+            __builtin_nontemporal_store(vv[u].z, &v[4 * i + 2]); __builtin_nontemporal_store(vv[u].w, &v[4 * i + 3]);
+#else
             p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
+#endif
             if (p_bf16) {   // bf16 copy of the updated master weights for the bf16-compute GEMMs (+2 B/parameter)
                 const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].x), b1 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].y);
                 const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].z), b3 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].w);
@@ -170,7 +205,11 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
                 // measured no better with nt)
                 const unsigned long long pk = (unsigned long long)((unsigned)b0 | ((unsigned)b1 << 16)) |
                                               ((unsigned long long)((unsigned)b2 | ((unsigned)b3 << 16)) << 32);
+#if JAMIE_ADAM_W16_NT
                 __builtin_nontemporal_store(pk, reinterpret_cast<unsigned long long*>(p_bf16) + i);
+#else
+                reinterpret_cast<unsigned long long*>(p_bf16)[i] = pk;
+#endif
             }
         }
         i0 += nwg * (T * U);
