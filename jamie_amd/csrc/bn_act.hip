@@ -18,6 +18,13 @@
 
 #include "bn_fwd_strip.h"
 
+// cache policy bits of the float4 kernels' once-read loads (split-K slabs, saved pre-activations, upstream gradients): 2 = nt
+// (they are dead once read; default policy, 0: the step 602.6 instead of 599.4 us on one box, three interleaved rounds,
+// profiles/r03_ab_bn_nt_loads.log)
+#ifndef JAMIE_BN_LD_AUX
+#define JAMIE_BN_LD_AUX 2
+#endif
+
 // Strip order: a problem gets 8 * ceil(strips / 8) workgroups and workgroup lb handles strip (lb & 7) * q + (lb >> 3),
 // q = ceil(strips / 8): blocks are dealt round-robin over the 8 XCDs (lb & 7), so every XCD owns a CONTIGUOUS range of
 // strips.  Neighbouring strips share 128-byte lines (a strip is 64 bytes of an fp32 row, 32 bytes of a bf16 row): the
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnFwdDev& P = g.p[pi];
     const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW;
-    bn_fwd4_strip<R, 0>(P, col0, (int)threadIdx.x, true, sh, tl, p_drop, momentum, eps, slope, rng);      // (bn_fwd_strip.h)
+    bn_fwd4_strip<R, JAMIE_BN_LD_AUX>(P, col0, (int)threadIdx.x, true, sh, tl, p_drop, momentum, eps, slope, rng);      // (bn_fwd_strip.h)
 }
 
 // `cs` / `cs_begin`: workgroups cs_begin .. are EXTRA ones that compute column sums (jamie_bn_act_bwd_cs: the decoder's
@@ -437,9 +444,9 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     }
     float4 dyv[R], xnv[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) xnv[j] = buf_f32x4(h_rs, roff[j]);
+    for (int j = 0; j < R; ++j) xnv[j] = buf_f32x4<JAMIE_BN_LD_AUX>(h_rs, roff[j]);
 #pragma unroll
-    for (int j = 0; j < R; ++j) dyv[j] = buf_f32x4(d_rs, roff[j]);
+    for (int j = 0; j < R; ++j) dyv[j] = buf_f32x4<JAMIE_BN_LD_AUX>(d_rs, roff[j]);
     unsigned mk[R];
     if (drop && P.mask) {
 #pragma unroll
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     for (int s = 1; s < nslab; ++s) {
         float4 a[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) a[j] = buf_f32x4(d_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
+        for (int j = 0; j < R; ++j) a[j] = buf_f32x4<JAMIE_BN_LD_AUX>(d_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] + (unsigned)s * slab_bytes);
 #pragma unroll
         for (int j = 0; j < R; ++j) { dyv[j].x += a[j].x; dyv[j].y += a[j].y; dyv[j].z += a[j].z; dyv[j].w += a[j].w; }
     }
