@@ -104,6 +104,12 @@ int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* b
  * ------------------------------------------------------------------------------------------- */
 int jamie_gemm_bf16(const jamie_gemm_problem* problems /*host*/, int count, int cfg, void* stream);
 int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm /*host*/, int* bn /*host*/);
+/* Skinny products C[M, N <= 128] (fp32, written once: no slabs) = A[M, K] B[N, K]^T, both operands K-contiguous bf16, long K:
+ * the heads' forward product (fc_mus | fc_vars, model.py:180,185) and the decoder-layer-0 input gradient (autograd of
+ * model.py:192) on the transposed bf16 weight copy (jamie_latent_m.dec0_WT_bf16).  One workgroup per 32 x 32 output tile, its
+ * 16 waves a K slice each, MFMA fragments loaded straight from global memory, partial tiles added in wave order.  Problems:
+ * EPI_STORE, splitk <= 1, no transposed-operand flags; bias optional. */
+int jamie_gemm_bf16_skinny(const jamie_gemm_problem* problems /*host*/, int count, void* stream);
 
 typedef struct {
     const float* src;           /* [R, C] fp32, leading dimension ld, nslab slabs slab_stride apart (summed)   */
@@ -266,6 +272,10 @@ typedef struct {
      * -- the heads' input gradient (dx of nn.Linear(d, 2L), model.py:141-143) computed by extra workgroups of the same launch
      * in exact fp32; d[i] a multiple of 4.  NULL: the caller runs that product as a GEMM. */
     const float* head_W[4]; float* da2[4];
+    /* optional by-product of jamie_latent_m_fwd's fused tail (g1 given): the K-contiguous bf16 copy dec0_WT_bf16[i] [L, d[i]] of
+     * W_dec0 [d[i], L], written by the workgroups that stage the weight chunks anyway; what jamie_gemm_bf16_skinny multiplies
+     * d g1 by for the decoder-layer-0 input gradient (d[i] a multiple of 8).  NULL: not written. */
+    void* dec0_WT_bf16[4];
 } jamie_latent_m;
 /* What a riding sampler draws: idx[B] = jamie_sample_indices(B, N, offset, replace, {seed, step + step_add}, rng_stream)
  * (np.random.choice of jamie/jamie.py:556).  step_add = 1 in a launch that runs before the norm kernel has advanced the step. */

@@ -103,7 +103,7 @@ class LatentM(C.Structure):
                 ('comb_alias', C.c_void_p * 4), ('comb_bf16', C.c_void_p * 4), ('combT_bf16', C.c_void_p * 4),
                 ('dml_bf16', C.c_void_p * 4), ('dmlT_bf16', C.c_void_p * 4),
                 ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p),
-                ('defer_final', C.c_int), ('head_W', C.c_void_p * 4), ('da2', C.c_void_p * 4)]
+                ('defer_final', C.c_int), ('head_W', C.c_void_p * 4), ('da2', C.c_void_p * 4), ('dec0_WT_bf16', C.c_void_p * 4)]
 
 
 class SampleArgs(C.Structure):
@@ -130,6 +130,7 @@ EXPORTS = {
     'jamie_gemm_bf16_ranges': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
     'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'jamie_gemm_bf16_skinny': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p]),
     'jamie_gemm_bf16_bn': (C.c_int, [C.POINTER(GemmProblem), C.POINTER(BnFwdProblem), C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'jamie_cast_transpose': (C.c_int, [C.POINTER(CastProblem), C.c_int, C.c_void_p]),
@@ -359,6 +360,12 @@ def gemm_bf16_bn(problems, bn_problems, cfg, p_drop, rng, tickets, mode=2, momen
     barr = (BnFwdProblem * len(bn_problems))(*bn_problems)
     _call('jamie_gemm_bf16_bn', arr, barr, len(problems), cfg, p_drop, momentum, eps, slope, ptr(rng), ptr(tickets),
           tickets.numel(), int(mode), _stream())
+
+
+def gemm_bf16_skinny(problems):
+    """C[M, N <= 128] = A B^T on K-contiguous bf16 operands, fp32 written once (jamie_gemm_bf16_skinny)."""
+    arr = (GemmProblem * len(problems))(*problems)
+    _call('jamie_gemm_bf16_skinny', arr, len(problems), _stream())
 
 
 def gemm_bf16_tile(max_m, max_n, cfg=-1):

@@ -530,6 +530,7 @@ struct LatMDev {
     int chunk_begin[LM + 1];      // column chunks of the decoder product, per modality (prefix sums)
     // fused tail of the backward launch: da2_i [B, d_i] = d(mu | logvar)_i [B, 2L] head_W_i [2L, d_i] (the heads' input gradient)
     const float* head_W[LM]; float* da2[LM];
+    unsigned short* dec0_WT[LM];  // optional: bf16 [L, d] transposed copy of W_dec0 (written by the forward launch's row-block-0 chunks)
     int bchunk_begin[LM + 1];     // column chunks of that product (chunk 0: the owner workgroups), prefix sums
 };
 
@@ -706,6 +707,20 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         }
     }
     lds_barrier();
+    // by-product: the K-contiguous bf16 copy WT[k][c0 + c] of this chunk of W_dec0 (what the skinny d comb product of the backward
+    // pass multiplies by): the chunk sits in LDS anyway; row block 0's workgroups write it, 8 consecutive c per thread
+    if (rb == 0 && a.dec0_WT[mi]) {
+        constexpr int SEGS = COLS / 8;                     // LMAX * SEGS == LF_NT
+        static_assert(LMAX * (COLS / 8) == LF_NT, "one (k, 8-column segment) per thread");
+        const int k = tid / SEGS, c8 = (tid % SEGS) * 8;
+        if (k < L && c0 + c8 < a.d[mi]) {                  // (d is a multiple of 8: a segment is inside the row or outside)
+            unsigned pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pk[q] = (unsigned)to_bf16(Ws[c8 + 2 * q][k]) | ((unsigned)to_bf16(Ws[c8 + 2 * q + 1][k]) << 16);
+            *reinterpret_cast<uint4*>(a.dec0_WT[mi] + (long long)k * a.d[mi] + c0 + c8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
     // exact-fp32 MFMA (32x32x2): wave w < COLS / 32 owns the 32-column tile w (waves are dealt round-robin to the SIMDs; the
     // matrix pipe's time is the same however the K = L steps are split over a SIMD's waves, so the other waves just leave).
     // One column x RPT rows per thread on the vector ALU was bound by its LDS reads: 2.3 us for this phase.
@@ -1023,6 +1038,9 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
     int bchunks = 1;
     for (int i = 0; i < a->M; ++i) {
         d.head_W[i] = a->head_W[i]; d.da2[i] = a->da2[i];
+        d.dec0_WT[i] = (unsigned short*)a->dec0_WT_bf16[i];
+        JAMIE_ARG(!a->dec0_WT_bf16[i] || (a->g1[i] && a->d[i] % 8 == 0 && ((uintptr_t)a->dec0_WT_bf16[i] % 16) == 0),
+                  "dec0_WT_bf16: needs the fused decoder tail (g1), d a multiple of 8, 16-byte aligned");
         JAMIE_ARG(!a->da2[i] || (a->head_W[i] && a->d[i] > 0 && a->d[i] % 4 == 0 && ((uintptr_t)a->head_W[i] % 16) == 0),
                   "heads' input gradient: head_W (16-byte aligned), d a multiple of 4");
         d.bchunk_begin[i] = bchunks;

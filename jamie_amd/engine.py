@@ -179,6 +179,19 @@ class TrainEngine:
         sk_dcomb = min(choose_splitk(B, L, d) for d in self.dims)
         if os.environ.get('JAMIE_SK_SKINNY'):          # tuning knob (tools/ab.sh): slab count of the skinny head / latent products
             sk_head = sk_dcomb = int(os.environ['JAMIE_SK_SKINNY'])
+        # bf16: the two skinny products with K = features -- the heads' forward [B, d] x [2L, d]^T and the decoder-layer-0 input
+        # gradient [B, d] x [d, L] -- CAN take the register-fed kernel (jamie_gemm_bf16_skinny: a 32 x 32 output tile per workgroup,
+        # a K slice per wave, no LDS staging, NO slabs; d comb on the K-contiguous bf16 copy of W_dec0 that the fused latent forward
+        # launch then leaves behind, dec0_WT_bf16) instead of the tiled GEMM with 8 K slices.  Built and tested (VERDICT r2 item 6
+        # asked for it), measured, OFF by default: 11.3 us per launch against 9.8 us for the tiled launch, the step 618.6 against
+        # 616.3 us (profiles/r03_ab_skinny_rejected.log, r03_stats_skinny.txt): MFMA-fragment-shaped loads (32 rows x 32 bytes per
+        # wave-instruction) are bound by the texture addresser, as cdna_hip_programming.md's "x operand through LDS in full lines"
+        # row says.  JAMIE_SKINNY=1 switches it on (tools/ab.sh).
+        skinny = self.bf16 and os.environ.get('JAMIE_SKINNY') == '1'
+        self._skinny_head = skinny and 2 * L <= 128
+        self._skinny_dcomb = skinny and L <= 128
+        if self._skinny_head:
+            sk_head = 1
         # bf16: tile configuration of every large launch + per-modality slab counts (plan_bf16_*)
         self.gcfg, plan_sk = {}, {}
         if self.bf16:
@@ -257,6 +270,8 @@ class TrainEngine:
                 w['comb'] = self.ws[0]['comb']          # M > 2 (identity corr): one combined embedding for all
             if self.bf16:
                 bf = dict(device=self.dev, dtype=torch.bfloat16)
+                if self._skinny_dcomb:
+                    w['dec0_WT'] = torch.zeros(L, d, **bf)
                 for k, nf in (('x', d), ('a1', 2 * d), ('a2', d), ('comb', L), ('e1', d), ('e2', 2 * d), ('dxhat', d),
                               ('de2', 2 * d), ('de1', d), ('dml', 2 * L), ('da2', d), ('da1', 2 * d)):
                     w[k + '_bf'] = torch.empty(B, nf, **bf)
@@ -778,6 +793,8 @@ class TrainEngine:
             d.dbias_head[i] = nv.ptr(self.g[f'm{i}.head.b'])
             if self._fuse_da2():
                 d.head_W[i], d.da2[i] = nv.ptr(self.m.p[f'm{i}.head.W']), nv.ptr(w['da2'])
+                if self._skinny_dcomb:      # (the backward pass then multiplies d g1 by this copy: _backward)
+                    d.dec0_WT_bf16[i] = nv.ptr(w['dec0_WT'])
             if self.bf16:
                 d.dml_bf16[i] = nv.ptr(w['dml_bf'])
                 d.dmlT_bf16[i] = nv.ptr(w['dml_T']) if 'dml' in self.need_T else None
@@ -788,6 +805,8 @@ class TrainEngine:
         d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
         d.sigma, d.hyper, d.partials = nv.ptr(self.m.p['sigma']), nv.ptr(self.hyper), nv.ptr(self.lat_partials)
         d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
+        if self._skinny_dcomb and self._fuse_da2():
+            d.dcomb_nslab = 1               # (written once by the skinny launch)
         d.dsigma = nv.ptr(self._dsig_tmp if self.accumulate else self.g['sigma'])
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses, d.rng_stream = nv.ptr(self.losses), 100
@@ -943,7 +962,11 @@ class TrainEngine:
         # ---------------- forward ----------------
         self._fwd_block('x', 'enc0', 'h1', 'enc0', 'bn0', 'a1', 10, noise, 'enc_masks', 0)
         self._fwd_block('a1', 'enc1', 'h2', 'enc1', 'bn1', 'a2', 11, noise, 'enc_masks', 1)
-        self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)      # bias added in the latent kernel
+        if self._skinny_head:                                             # (bias added in the latent kernel)
+            nv.gemm_bf16_skinny([nv.gemm_problem(w['a2_bf'], self.wbf[f'm{i}.head.W'], w['ml'], B, 2 * L, d, d, d, 2 * L)
+                                 for i, (w, d) in enumerate(zip(self.ws, self.dims))])
+        else:
+            self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)
         fused = fused_losses and self._fused_latent(corr, Fblk)
         lat = self._latent_desc(corr, Fblk, noise, fused)
         nv.latent_fwd(lat, self.state)
@@ -1082,7 +1105,12 @@ class TrainEngine:
         # launch, and what is left here is the short d comb product alone
         late_dw = []
         fused_tail = isinstance(lat, nv.LatentM) and bool(lat.da2[0])
-        if fused_tail and (self._direct_now or os.environ.get('JAMIE_NO_LATE_DEC0_DW') != '1'):
+        if fused_tail and self._skinny_dcomb and bool(lat.dec0_WT_bf16[0]):
+            probs = [nv.gemm_problem(w['de1_bf'], w['dec0_WT'], w['dcomb'][0], B, L, d, d, d, L)
+                     for w, d in zip(self.ws, self.dims)]
+            nv.gemm_bf16_skinny(probs)
+            late_dw.append(('de1', 'comb', 'dec0'))
+        elif fused_tail and (self._direct_now or os.environ.get('JAMIE_NO_LATE_DEC0_DW') != '1'):
             self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
             late_dw.append(('de1', 'comb', 'dec0'))
         else:

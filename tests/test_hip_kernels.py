@@ -1087,3 +1087,32 @@ def _fused_bn_case(nv, B, shapes, cfg, sks, p, mode, explicit_mask, rounds=3, se
 ])
 def test_gemm_bf16_fused_batchnorm_equals_two_launches(nv, B, shapes, cfg, sks, p, explicit, mode):
     _fused_bn_case(nv, B, shapes, cfg, sks, p, mode, explicit, seed=B + cfg)
+
+
+@pytest.mark.parametrize('shapes', [[(512, 64, 2000), (512, 64, 1000)],         # config 2's heads forward (mu | logvar), both modalities
+                                    [(512, 32, 2000), (512, 32, 1000)],         # ... and its d comb product
+                                    [(200, 40, 264)], [(512, 128, 5000)], [(37, 8, 104), (64, 128, 8)], [(512, 32, 2000)] * 4])
+def test_gemm_bf16_skinny(nv, shapes):
+    """jamie_gemm_bf16_skinny (a 32 x 32 output tile per workgroup, a K slice per wave, fragments straight from global memory):
+    against fp32 torch on the same bf16 operands; ragged M / N / K (K a multiple of 8 only), grouped problems, with and
+    without bias; integer-valued operands are reproduced exactly."""
+    g = torch.Generator().manual_seed(len(shapes) + shapes[0][2])
+    probs, keep = [], []
+    for j, (M, N, K) in enumerate(shapes):
+        A = _bf16(torch.randn(M, K, generator=g)).cuda()
+        Bm = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        bias = torch.randn(N, generator=g).cuda() if j % 2 == 0 else None
+        Cm = torch.full((M, N), 7.0, device='cuda')
+        probs.append(nv.gemm_problem(A, Bm, Cm, M, N, K, K, K, N, bias=bias))
+        keep.append((A, Bm, bias, Cm))
+    nv.gemm_bf16_skinny(probs)
+    for A, Bm, bias, Cm in keep:
+        want = A.float() @ Bm.float().t() + (bias if bias is not None else 0)
+        close(Cm, want.cpu(), rtol=2e-5, atol=2e-5)
+    # exact integers, asymmetric operands (a swapped row / column map or a dropped K slice shows)
+    M, N, K = 96, 64, 272
+    A = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+    Bm = (torch.arange(N * K).reshape(N, K) % 5 - 2).float()
+    Cm = torch.zeros(M, N, device='cuda')
+    nv.gemm_bf16_skinny([nv.gemm_problem(A.to(torch.bfloat16).cuda(), Bm.to(torch.bfloat16).cuda(), Cm, M, N, K, K, K, N)])
+    assert torch.equal(Cm.cpu(), A @ Bm.t())

