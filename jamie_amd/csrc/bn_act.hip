@@ -385,9 +385,40 @@ __device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)
     a = make_float4(t[0], t[1], t[2], t[3]);
     b = make_float4(t[4], t[5], t[6], t[7]);
 }
+// PREFETCH RIDER (jamie_bn_act_fwd_pf / jamie_bn_act_bwd_pf): extra workgroups of a BatchNorm launch -- a latency-bound
+// launch with memory bandwidth to spare -- read the weights the NEXT launch's product streams (default cache policy: the lines
+// land in the Infinity Cache), so that GEMM starts on warm weights instead of HBM-cold ones.  Loads only; nothing is written.
+#define BN_PF_BLOCKS 64
+#ifndef BN_PF_UNROLL
+#define BN_PF_UNROLL 4
+#endif
+static int bn_pf_blocks() {         // (tuning knob: JAMIE_PF_BLOCKS)
+    static int n = -1;
+    if (n < 0) { const char* e = getenv("JAMIE_PF_BLOCKS"); n = e ? atoi(e) : BN_PF_BLOCKS; if (n < 1) n = 1; }
+    return n;
+}
+__device__ __forceinline__ void prefetch_block(const char* p, long long bytes, int blk, int nblk) {
+    const long long stride = (long long)nblk * 512 * 16;
+    for (long long off = ((long long)blk * 512 + threadIdx.x) * 16; off < bytes; off += BN_PF_UNROLL * stride) {
+        bn_u32x4 v[BN_PF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_PF_UNROLL; ++u) {
+            const long long o = off + u * stride;
+            v[u] = o + 16 <= bytes ? *reinterpret_cast<const bn_u32x4*>(p + o) : bn_u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < BN_PF_UNROLL; ++u) asm volatile("" ::"v"(v[u]));
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
-                                                          float slope, const uint64_t* rng) {
+                                                          float slope, const uint64_t* rng, const char* pf, long long pf_bytes,
+                                                          int n_main) {
+    if ((int)blockIdx.x >= n_main) {
+        prefetch_block(pf, pf_bytes, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);
+        return;
+    }
     __shared__ float sh[BN4_NW][BN_CW];
     __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * (128 * R + 2)];
     int pi = 0;
@@ -404,7 +435,12 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
 // launch of its own at the head of the backward pass; 47 short workgroups beside 375 long ones)
 template <int R>
 __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng,
-                                                          ColsumGroup cs, int cs_begin) {
+                                                          ColsumGroup cs, int cs_begin, const char* pf, long long pf_bytes,
+                                                          int pf_begin) {
+    if ((int)blockIdx.x >= pf_begin) {
+        prefetch_block(pf, pf_bytes, (int)blockIdx.x - pf_begin, (int)gridDim.x - pf_begin);
+        return;
+    }
     if ((int)blockIdx.x >= cs_begin) {
         __shared__ float4 csh[32][17];
         float* o;
@@ -538,8 +574,22 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     }
 }
 
+static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
+                           const uint64_t* rng, const void* pf, long long pf_bytes, void* stream);
+
 extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum,
                                 float eps, float slope, const uint64_t* rng, void* stream) {
+    return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, nullptr, 0, stream);
+}
+
+extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps,
+                                   float slope, const uint64_t* rng, const void* prefetch, long long prefetch_bytes, void* stream) {
+    JAMIE_ARG(prefetch_bytes >= 0 && (prefetch_bytes == 0 || (prefetch && (uintptr_t)prefetch % 16 == 0)), "prefetch range: 16-byte aligned");
+    return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, prefetch, prefetch_bytes, stream);
+}
+
+static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
+                           const uint64_t* rng, const void* pf, long long pf_bytes, void* stream) {
     JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
     JAMIE_ARG(p_drop >= 0.f && p_drop < 1.f, "0 <= p < 1");
     BnFwdGroup g;
@@ -575,10 +625,13 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
+    const int pfb = (pf && pf_bytes > 0) ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel<4>, dim3(blocks), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel<4>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng,
+                           (const char*)pf, pf_bytes, blocks);
     else if (wide && maxB <= 8 * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel<8>, dim3(blocks), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel<8>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng,
+                           (const char*)pf, pf_bytes, blocks);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
     else
@@ -587,7 +640,7 @@ extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, fl
 }
 
 static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
-                           const jamie_colsum_problem* csp, int cs_count, void* stream);
+                           const jamie_colsum_problem* csp, int cs_count, void* stream, const void* pf = nullptr, long long pf_bytes = 0);
 
 extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope,
                                 const uint64_t* rng, void* stream) {
@@ -600,8 +653,16 @@ extern "C" int jamie_bn_act_bwd_cs(const jamie_bnact_bwd_problem* pr, int count,
     return bn_act_bwd_impl(pr, count, p_drop, slope, rng, colsums, n_colsums, stream);
 }
 
+extern "C" int jamie_bn_act_bwd_pf(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
+                                   const jamie_colsum_problem* colsums, int n_colsums, const void* prefetch, long long prefetch_bytes,
+                                   void* stream) {
+    JAMIE_ARG(n_colsums >= 0 && n_colsums <= JAMIE_MAX_GROUP && (n_colsums == 0 || colsums), "0 <= column-sum problems <= JAMIE_MAX_GROUP");
+    JAMIE_ARG(prefetch_bytes >= 0 && (prefetch_bytes == 0 || (prefetch && (uintptr_t)prefetch % 16 == 0)), "prefetch range: 16-byte aligned");
+    return bn_act_bwd_impl(pr, count, p_drop, slope, rng, colsums, n_colsums, stream, prefetch, prefetch_bytes);
+}
+
 static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
-                           const jamie_colsum_problem* csp, int cs_count, void* stream) {
+                           const jamie_colsum_problem* csp, int cs_count, void* stream, const void* pf, long long pf_bytes) {
     JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
     JAMIE_ARG(p_drop >= 0.f && p_drop < 1.f, "0 <= p < 1");
     BnBwdGroup g;
@@ -651,10 +712,13 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     cs.count = cs_count;
     const bool wide4 = wide && maxB <= 8 * BN4_RP;
     const int extra = wide4 ? cs_blocks : 0;            // the float4 kernels take the column sums as extra workgroups
+    const int pfb = (pf && pf_bytes > 0) ? bn_pf_blocks() : 0;
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks + extra), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks);
+        hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
+                           (const char*)pf, pf_bytes, blocks + extra);
     else if (wide4)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks + extra), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks);
+        hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
+                           (const char*)pf, pf_bytes, blocks + extra);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
     else

@@ -685,9 +685,9 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
 
 // NT launches through the LDS-DMA kernel when every problem qualifies (16-byte aligned operands, lda / ldb multiples
 // of 4, no row gather, < 4 GiB); otherwise the register-staged kernel with the same 64x64 tile.
-template <int NB>
+template <int NB, int BM = 64, int BN = 64, int WM = 2, int WN = 2>
 static int launch_dma_nt(const jamie_gemm_problem* pr, int count, hipStream_t st) {
-    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int BK = 32;
     GemmGroup g;
     memset(&g, 0, sizeof(g));
     g.count = count;
@@ -717,12 +717,12 @@ static int launch_dma_nt(const jamie_gemm_problem* pr, int count, hipStream_t st
             ok = false;
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
-    if (!ok) return launch_cfg<64, 64, 32, 2, 2, true, true>(pr, count, st);
+    if (!ok) return launch_cfg<BM, BN, 32, WM, WN, true, true>(pr, count, st);
     if (tiles == 0) return 0;
     if (big)
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, 2, 2, 1, NB>), dim3(tiles), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, 2, 2, 0, NB>), dim3(tiles), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, WM, WN, 0, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
     return jamie_launch_status("jamie_gemm_f32");
 }
 
@@ -747,6 +747,12 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
                 return cfg == 7 ? launch_dma_nt<3>(pr, count, st) : cfg == 8 ? launch_dma_nt<2>(pr, count, st) : launch_dma_nt<4>(pr, count, st);
             } else {
                 return launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC>(pr, count, st);
+            }
+        case 13: case 14:      // 128x128x32 LDS-DMA on 16 waves, 2 / 3 buffers (NT only; other layouts: configuration 12)
+            if constexpr (A_KC && B_KC) {
+                return cfg == 13 ? launch_dma_nt<2, 128, 128, 4, 4>(pr, count, st) : launch_dma_nt<3, 128, 128, 4, 4>(pr, count, st);
+            } else {
+                return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC>(pr, count, st);
             }
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
@@ -799,10 +805,10 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[13][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
-                                 {64, 128}, {128, 64}, {128, 128}};
+    static const int T[15][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
+                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 12 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 14 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

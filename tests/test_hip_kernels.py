@@ -1116,3 +1116,38 @@ def test_gemm_bf16_skinny(nv, shapes):
     Cm = torch.zeros(M, N, device='cuda')
     nv.gemm_bf16_skinny([nv.gemm_problem(A.to(torch.bfloat16).cuda(), Bm.to(torch.bfloat16).cuda(), Cm, M, N, K, K, K, N)])
     assert torch.equal(Cm.cpu(), A @ Bm.t())
+
+
+def test_bn_prefetch_rider_changes_nothing(nv):
+    """jamie_bn_act_fwd_pf / jamie_bn_act_bwd_pf: the extra workgroups only read the range they are given; outputs are those of
+    the plain launches, bit for bit; an unaligned range is refused."""
+    g = torch.Generator().manual_seed(3)
+    B, N, p = 512, 2000, 0.6
+    hs = dev(torch.randn(2, B, N, generator=g))
+    gamma, beta = dev(torch.rand(N, generator=g) + .5), dev(torch.randn(N, generator=g))
+    da = dev(torch.randn(1, B, N, generator=g))
+    state = torch.tensor([5, 1, 0, 0], dtype=torch.int64, device='cuda')
+    weights = torch.randn(3_000_001, device='cuda').to(torch.bfloat16)
+    outs = []
+    for pf in (None, weights[8:]):
+        h = hs.clone()
+        out = torch.zeros(B, N, dtype=torch.bfloat16, device='cuda')
+        rm, rv, sm, si = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda'), torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+        pr = nv.BnFwdProblem()
+        pr.h, pr.nslab, pr.slab_stride, pr.gamma, pr.beta = nv.ptr(h), 2, B * N, nv.ptr(gamma), nv.ptr(beta)
+        pr.running_mean, pr.running_var, pr.save_mean, pr.save_invstd = nv.ptr(rm), nv.ptr(rv), nv.ptr(sm), nv.ptr(si)
+        pr.out, pr.mask, pr.out_bf16, pr.B, pr.N, pr.rng_stream = None, None, nv.ptr(out), B, N, 3
+        nv.bn_act_fwd([pr], p, state, prefetch=pf)
+        d = da.clone()
+        dh = torch.zeros(B, N, dtype=torch.bfloat16, device='cuda')
+        dg, db, dl = (torch.zeros(N, device='cuda') for _ in range(3))
+        pb = nv.BnBwdProblem()
+        pb.da, pb.nslab, pb.slab_stride, pb.h, pb.gamma, pb.beta = nv.ptr(d), 1, B * N, nv.ptr(h), nv.ptr(gamma), nv.ptr(beta)
+        pb.save_mean, pb.save_invstd, pb.dgamma, pb.dbeta, pb.dbias_lin = nv.ptr(sm), nv.ptr(si), nv.ptr(dg), nv.ptr(db), nv.ptr(dl)
+        pb.mask, pb.B, pb.N, pb.rng_stream, pb.accumulate, pb.dh_bf16, pb.skip_f32 = None, B, N, 3, 0, nv.ptr(dh), 1
+        nv.bn_act_bwd([pb], p, state, prefetch=pf)
+        outs.append((out, rm, rv, sm, si, h[0].clone(), dh, dg, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    with pytest.raises(nv.JamieHipError):
+        nv.bn_act_fwd([pr], p, state, prefetch=weights[1:])        # 2-byte aligned only
