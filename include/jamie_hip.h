@@ -162,10 +162,12 @@ int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* problems /*host*/, int count
                      float momentum, float eps, float slope, const uint64_t* rng, void* stream);
 
 /* jamie_bn_act_fwd / jamie_bn_act_bwd_cs with a PREFETCH RIDER: 64 extra workgroups (float4 kernels only; ignored otherwise) read
- * `prefetch_bytes` from `prefetch` (16-byte aligned) with the default cache policy and discard them -- the weights the NEXT
- * launch's product streams (model.py:151 etc.) are then in the Infinity Cache instead of HBM-cold.  n_colsums may be 0. */
+ * up to 8 device ranges (prefetch[i], prefetch_bytes[i]; 16-byte aligned; host arrays) with the default cache policy and discard
+ * them -- what the NEXT launches stream (the weights of the next product, model.py:151 etc.; saved activations of the backward
+ * pass) is then in the Infinity Cache instead of HBM-cold.  n_colsums may be 0. */
 int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* problems /*host*/, int count, float p_drop, float momentum, float eps,
-                        float slope, const uint64_t* rng, const void* prefetch, long long prefetch_bytes, void* stream);
+                        float slope, const uint64_t* rng, const void* const* prefetch /*host*/, const long long* prefetch_bytes /*host*/,
+                        int n_prefetch, void* stream);
 
 /* Linear forward + BatchNorm1d(train) + LeakyReLU + Dropout in ONE launch (model.py:151-154 and the three sibling blocks; bf16
  * compute mode, large-tile configurations 31 / 32): jamie_gemm_bf16 on `problems` (plain stores of `splitk` fp32 slabs, bias in
@@ -200,8 +202,8 @@ int jamie_bn_act_bwd_cs(const jamie_bnact_bwd_problem* problems /*host*/, int co
                         const uint64_t* rng, const jamie_colsum_problem* colsums /*host*/, int n_colsums, void* stream);
 /* ... and with the prefetch rider of jamie_bn_act_fwd_pf (n_colsums may be 0) */
 int jamie_bn_act_bwd_pf(const jamie_bnact_bwd_problem* problems /*host*/, int count, float p_drop, float slope, const uint64_t* rng,
-                        const jamie_colsum_problem* colsums /*host*/, int n_colsums, const void* prefetch, long long prefetch_bytes,
-                        void* stream);
+                        const jamie_colsum_problem* colsums /*host*/, int n_colsums, const void* const* prefetch /*host*/,
+                        const long long* prefetch_bytes /*host*/, int n_prefetch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Latent block: reparameterisation (model.py:225-243), sigma-weighted combine (model.py:245-259),

@@ -142,9 +142,9 @@ EXPORTS = {
     'jamie_bn_act_bwd_cs': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p]),
     'jamie_bn_act_fwd_pf': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
-                                      C.c_void_p, C.c_longlong, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'jamie_bn_act_bwd_pf': (C.c_int, [C.POINTER(BnBwdProblem), C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
-                                      C.c_void_p, C.c_longlong, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'jamie_latent_fwd': (C.c_int, [C.POINTER(Latent), C.c_void_p, C.c_void_p]),
     'jamie_latent_bwd': (C.c_int, [C.POINTER(Latent), C.c_void_p]),
     'jamie_latent_m_fwd': (C.c_int, [C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
@@ -442,13 +442,21 @@ class FlatCast:
         _check(self.fn(self.arr, self.n, C.c_void_p(stream.cuda_stream)))
 
 
+def _pf_arrays(tensors):
+    """Host arrays (device pointers, byte counts rounded down to 16) of up to 8 contiguous tensors for a prefetch rider."""
+    pp = (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    pb = (C.c_longlong * len(tensors))(*[t.numel() * t.element_size() // 16 * 16 for t in tensors])
+    return pp, pb
+
+
 def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01, prefetch=None):
-    """`prefetch` (a contiguous tensor): extra workgroups read it into the caches for the next launch (jamie_bn_act_fwd_pf)."""
+    """`prefetch` (list of <= 8 contiguous tensors): extra workgroups read them into the caches for the next launches
+    (jamie_bn_act_fwd_pf)."""
     arr = (BnFwdProblem * len(problems))(*problems)
-    if prefetch is not None:
-        arr._keep = prefetch
-        _call('jamie_bn_act_fwd_pf', arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), ptr(prefetch),
-              prefetch.numel() * prefetch.element_size() // 16 * 16, _stream())
+    if prefetch:
+        pp, pb = _pf_arrays(prefetch)
+        arr._keep = (prefetch, pp, pb)
+        _call('jamie_bn_act_fwd_pf', arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), pp, pb, len(prefetch), _stream())
         return
     _call('jamie_bn_act_fwd', arr, len(problems), p_drop, momentum, eps, slope, ptr(rng), _stream())
 
@@ -456,10 +464,11 @@ def bn_act_fwd(problems, p_drop, rng, momentum=0.1, eps=1e-5, slope=0.01, prefet
 def bn_act_bwd(problems, p_drop, rng, slope=0.01, colsums=None, prefetch=None):
     """`colsums` (from colsum_problems): column sums computed by extra workgroups of the same launch; `prefetch`: as bn_act_fwd."""
     arr = (BnBwdProblem * len(problems))(*problems)
-    if prefetch is not None:
-        arr._keep = prefetch
+    if prefetch:
+        pp, pb = _pf_arrays(prefetch)
+        arr._keep = (prefetch, pp, pb)
         _call('jamie_bn_act_bwd_pf', arr, len(problems), p_drop, slope, ptr(rng), colsums[0] if colsums is not None else None,
-              colsums[1] if colsums is not None else 0, ptr(prefetch), prefetch.numel() * prefetch.element_size() // 16 * 16, _stream())
+              colsums[1] if colsums is not None else 0, pp, pb, len(prefetch), _stream())
         return
     if colsums is not None:
         _call('jamie_bn_act_bwd_cs', arr, len(problems), p_drop, slope, ptr(rng), colsums[0], colsums[1], _stream())

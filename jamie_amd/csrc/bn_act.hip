@@ -397,7 +397,9 @@ static int bn_pf_blocks() {         // (tuning knob: JAMIE_PF_BLOCKS)
     if (n < 0) { const char* e = getenv("JAMIE_PF_BLOCKS"); n = e ? atoi(e) : BN_PF_BLOCKS; if (n < 1) n = 1; }
     return n;
 }
-__device__ __forceinline__ void prefetch_block(const char* p, long long bytes, int blk, int nblk) {
+#define BN_PF_MAX 8
+struct PfRanges { const char* p[BN_PF_MAX]; long long bytes[BN_PF_MAX]; int n; };
+__device__ __forceinline__ void prefetch_range(const char* p, long long bytes, int blk, int nblk) {
     const long long stride = (long long)nblk * 512 * 16;
     for (long long off = ((long long)blk * 512 + threadIdx.x) * 16; off < bytes; off += BN_PF_UNROLL * stride) {
         bn_u32x4 v[BN_PF_UNROLL];
@@ -411,12 +413,17 @@ __device__ __forceinline__ void prefetch_block(const char* p, long long bytes, i
     }
 }
 
+__device__ __forceinline__ void prefetch_block(const PfRanges& r, int blk, int nblk) {
+#pragma unroll
+    for (int i = 0; i < BN_PF_MAX; ++i)
+        if (i < r.n) prefetch_range(r.p[i], r.bytes[i], blk, nblk);
+}
+
 template <int R>
 __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
-                                                          float slope, const uint64_t* rng, const char* pf, long long pf_bytes,
-                                                          int n_main) {
+                                                          float slope, const uint64_t* rng, PfRanges pf, int n_main) {
     if ((int)blockIdx.x >= n_main) {
-        prefetch_block(pf, pf_bytes, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);
+        prefetch_block(pf, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);
         return;
     }
     __shared__ float sh[BN4_NW][BN_CW];
@@ -435,10 +442,9 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
 // launch of its own at the head of the backward pass; 47 short workgroups beside 375 long ones)
 template <int R>
 __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng,
-                                                          ColsumGroup cs, int cs_begin, const char* pf, long long pf_bytes,
-                                                          int pf_begin) {
+                                                          ColsumGroup cs, int cs_begin, PfRanges pf, int pf_begin) {
     if ((int)blockIdx.x >= pf_begin) {
-        prefetch_block(pf, pf_bytes, (int)blockIdx.x - pf_begin, (int)gridDim.x - pf_begin);
+        prefetch_block(pf, (int)blockIdx.x - pf_begin, (int)gridDim.x - pf_begin);
         return;
     }
     if ((int)blockIdx.x >= cs_begin) {
@@ -575,21 +581,32 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
 }
 
 static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
-                           const uint64_t* rng, const void* pf, long long pf_bytes, void* stream);
+                           const uint64_t* rng, const void* const* pf, const long long* pf_bytes, int n_pf, void* stream);
+static int pf_fill(const void* const* pf, const long long* pf_bytes, int n_pf, PfRanges& r) {
+    memset(&r, 0, sizeof(r));
+    JAMIE_ARG(n_pf >= 0 && n_pf <= BN_PF_MAX && (n_pf == 0 || (pf && pf_bytes)), "0 <= prefetch ranges <= 8");
+    for (int i = 0; i < n_pf; ++i) {
+        JAMIE_ARG(pf_bytes[i] >= 0 && (pf_bytes[i] == 0 || (pf[i] && (uintptr_t)pf[i] % 16 == 0)), "prefetch range: 16-byte aligned");
+        if (pf_bytes[i] > 0) { r.p[r.n] = (const char*)pf[i]; r.bytes[r.n] = pf_bytes[i]; ++r.n; }
+    }
+    return 0;
+}
 
 extern "C" int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum,
                                 float eps, float slope, const uint64_t* rng, void* stream) {
-    return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, nullptr, 0, stream);
+    return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps,
-                                   float slope, const uint64_t* rng, const void* prefetch, long long prefetch_bytes, void* stream) {
-    JAMIE_ARG(prefetch_bytes >= 0 && (prefetch_bytes == 0 || (prefetch && (uintptr_t)prefetch % 16 == 0)), "prefetch range: 16-byte aligned");
-    return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, prefetch, prefetch_bytes, stream);
+                                   float slope, const uint64_t* rng, const void* const* prefetch, const long long* prefetch_bytes,
+                                   int n_prefetch, void* stream) {
+    return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, prefetch, prefetch_bytes, n_prefetch, stream);
 }
 
 static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
-                           const uint64_t* rng, const void* pf, long long pf_bytes, void* stream) {
+                           const uint64_t* rng, const void* const* pf, const long long* pf_bytes, int n_pf, void* stream) {
+    PfRanges pfr;
+    { const int rc = pf_fill(pf, pf_bytes, n_pf, pfr); if (rc) return rc; }
     JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
     JAMIE_ARG(p_drop >= 0.f && p_drop < 1.f, "0 <= p < 1");
     BnFwdGroup g;
@@ -625,13 +642,11 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
-    const int pfb = (pf && pf_bytes > 0) ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
+    const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
     if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel<4>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng,
-                           (const char*)pf, pf_bytes, blocks);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel<4>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
     else if (wide && maxB <= 8 * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel<8>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng,
-                           (const char*)pf, pf_bytes, blocks);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel<8>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
     else
@@ -640,7 +655,8 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
 }
 
 static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
-                           const jamie_colsum_problem* csp, int cs_count, void* stream, const void* pf = nullptr, long long pf_bytes = 0);
+                           const jamie_colsum_problem* csp, int cs_count, void* stream, const void* const* pf = nullptr,
+                           const long long* pf_bytes = nullptr, int n_pf = 0);
 
 extern "C" int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope,
                                 const uint64_t* rng, void* stream) {
@@ -654,15 +670,17 @@ extern "C" int jamie_bn_act_bwd_cs(const jamie_bnact_bwd_problem* pr, int count,
 }
 
 extern "C" int jamie_bn_act_bwd_pf(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
-                                   const jamie_colsum_problem* colsums, int n_colsums, const void* prefetch, long long prefetch_bytes,
-                                   void* stream) {
+                                   const jamie_colsum_problem* colsums, int n_colsums, const void* const* prefetch,
+                                   const long long* prefetch_bytes, int n_prefetch, void* stream) {
     JAMIE_ARG(n_colsums >= 0 && n_colsums <= JAMIE_MAX_GROUP && (n_colsums == 0 || colsums), "0 <= column-sum problems <= JAMIE_MAX_GROUP");
-    JAMIE_ARG(prefetch_bytes >= 0 && (prefetch_bytes == 0 || (prefetch && (uintptr_t)prefetch % 16 == 0)), "prefetch range: 16-byte aligned");
-    return bn_act_bwd_impl(pr, count, p_drop, slope, rng, colsums, n_colsums, stream, prefetch, prefetch_bytes);
+    return bn_act_bwd_impl(pr, count, p_drop, slope, rng, colsums, n_colsums, stream, prefetch, prefetch_bytes, n_prefetch);
 }
 
 static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p_drop, float slope, const uint64_t* rng,
-                           const jamie_colsum_problem* csp, int cs_count, void* stream, const void* pf, long long pf_bytes) {
+                           const jamie_colsum_problem* csp, int cs_count, void* stream, const void* const* pf,
+                           const long long* pf_bytes, int n_pf) {
+    PfRanges pfr;
+    { const int rc = pf_fill(pf, pf_bytes, n_pf, pfr); if (rc) return rc; }
     JAMIE_ARG(pr && count >= 1 && count <= JAMIE_MAX_GROUP, "1 <= count <= JAMIE_MAX_GROUP");
     JAMIE_ARG(p_drop >= 0.f && p_drop < 1.f, "0 <= p < 1");
     BnBwdGroup g;
@@ -712,13 +730,13 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     cs.count = cs_count;
     const bool wide4 = wide && maxB <= 8 * BN4_RP;
     const int extra = wide4 ? cs_blocks : 0;            // the float4 kernels take the column sums as extra workgroups
-    const int pfb = (pf && pf_bytes > 0) ? bn_pf_blocks() : 0;
+    const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;
     if (wide && maxB <= BN4_MAXR * BN4_RP)
         hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
-                           (const char*)pf, pf_bytes, blocks + extra);
+                           pfr, blocks + extra);
     else if (wide4)
         hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
-                           (const char*)pf, pf_bytes, blocks + extra);
+                           pfr, blocks + extra);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);
     else

@@ -537,21 +537,34 @@ class TrainEngine:
             noise[kind][i][j] = m
         return m
 
-    def _prefetch(self, lin):
-        """The weights of layer `lin` (both modalities: one contiguous range of the flat layout) as the next launch's product
-        streams them -- the bf16 copy, or the fp32 master -- for the BatchNorm launches' prefetch rider; None: switched off
-        (JAMIE_PREFETCH=0) or nothing to prefetch."""
-        # Measured (one box, interleaved, profiles/r03_ab_prefetch.log): bf16 622.2 -> 615.9 us per step (the forward launches
-        # 27.6 -> 24.6 us each; 64 rider workgroups: 16 / 32 stretch the BatchNorm launch, 695 / 641 us; 128 / 256 and more loads
-        # in flight: no better); fp32 1512 -> 1551 us (those products are bound by the matrix pipe, not by their first
-        # touch of the weights, and the riders delay the BatchNorm launch): bf16 mode only.
-        if lin is None or not self.bf16 or os.environ.get('JAMIE_PREFETCH', '1') == '0' or self.pipeline:
+    def _prefetch(self, *items):
+        """Ranges for the BatchNorm launches' prefetch rider (jamie_bn_act_fwd_pf / _bwd_pf): what the NEXT launches stream from
+        HBM-cold memory, read into the Infinity Cache by 64 extra workgroups of a launch that has bandwidth to spare.
+        Items: 'W:<layer>' = that layer's weights, both modalities (one contiguous range of the bf16 copy); '<key>' = a workspace
+        tensor of every modality (saved activations the dW products read, the pre-activations the next BatchNorm backward reads).
+        Measured (one box, interleaved, profiles/r03_ab_prefetch.log): bf16 622.2 -> 615.9 us per step with the weights alone (the
+        forward launches 27.6 -> 24.6 us each; 64 rider workgroups: 16 / 32 stretch the BatchNorm launch, 695 / 641 us; 128 / 256
+        and more loads in flight: no better); fp32 1512 -> 1551 us (those products are bound by the matrix pipe, not by their first
+        touch of the weights, and the riders delay the BatchNorm launch): bf16 mode only.  The saved activations on top of the
+        weights (JAMIE_PREFETCH=2): 631.9 against 628.3 us with the weights alone (632.6 without): the extra ranges stretch the
+        BatchNorm launches by what the next launches gain -- the default (1) prefetches the weights only.  JAMIE_PREFETCH=0: off."""
+        mode = os.environ.get('JAMIE_PREFETCH', '1')
+        if not self.bf16 or mode == '0' or self.pipeline:
             return None
-        lo, hi = self.m.layout.regions[lin]
-        lo = (lo + 7) // 8 * 8                       # (16-byte aligned in the bf16 copy)
-        return self.wbf_flat[lo:hi]
+        out = []
+        for it in items:
+            if it.startswith('W:'):
+                lo, hi = self.m.layout.regions[it[2:]]
+                lo = (lo + 7) // 8 * 8                   # (16-byte aligned in the bf16 copy)
+                out.append(self.wbf_flat[lo:hi])
+            elif mode != '1':
+                for w in self.ws:
+                    t = w.get(it)
+                    if t is not None and t.numel() * t.element_size() >= (1 << 20):
+                        out.append(t[0] if t.dim() == 3 else t)
+        return out[:8] or None
 
-    def _bn_fwd(self, layer, h_key, out_key, stream_base, noise, kind, j, next_lin=None):
+    def _bn_fwd(self, layer, h_key, out_key, stream_base, noise, kind, j, prefetch=()):
         probs = []
         for i, d in enumerate(self.dims):
             w, P, bn = self.ws[i], self.m.p, self.m.bn
@@ -567,9 +580,9 @@ class TrainEngine:
                 pr.out, pr.out_bf16 = None, nv.ptr(w[out_key + '_bf'])
                 pr.outT_bf16 = nv.ptr(w[out_key + '_T']) if out_key in self.need_T else None
             probs.append(pr)
-        nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE, self._prefetch(next_lin))
+        nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE, self._prefetch(*prefetch))
 
-    def _bn_bwd(self, layer, da_key, h_key, lin, stream_base, noise, kind, j, colsums=None, next_lin=None):
+    def _bn_bwd(self, layer, da_key, h_key, lin, stream_base, noise, kind, j, colsums=None, prefetch=()):
         probs = []
         for i, d in enumerate(self.dims):
             w, P = self.ws[i], self.m.p
@@ -586,7 +599,7 @@ class TrainEngine:
                 pr.dh_bf16, pr.skip_f32 = nv.ptr(w[da_key + '_bf']), 1
                 pr.dhT_bf16 = nv.ptr(w[da_key + '_T']) if da_key in self.need_T else None
             probs.append(pr)
-        nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE, colsums, self._prefetch(next_lin))
+        nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE, colsums, self._prefetch(*prefetch))
 
     # ---- Linear forward + BatchNorm + LeakyReLU + dropout as ONE launch (jamie_gemm_bf16_bn): the split-K slices of a column
     # strip hand their fp32 slabs to each other inside the launch and run the BatchNorm strip code themselves -- no BatchNorm
@@ -608,7 +621,8 @@ class TrainEngine:
         bf16 plan applies, else the product and the BatchNorm launch."""
         if not self._fused_bn_ok(sk_key, out_key):
             self._fwd_gemm(a_key, lin, h_key, sk_key)
-            self._bn_fwd(layer, h_key, out_key, stream_base, noise, kind, j, next_lin={'enc0': 'enc1', 'dec1': 'dec2'}.get(lin))
+            self._bn_fwd(layer, h_key, out_key, stream_base, noise, kind, j,
+                         prefetch={'enc0': ('W:enc1',), 'dec1': ('W:dec2', 'x')}.get(lin, ()))      # (x: the MSE launch reads it)
             self._cast(out_key)
             return
         probs, bns = [], []
@@ -987,7 +1001,7 @@ class TrainEngine:
         if not fused:            # (the fused kernel has written g1 = comb W^T + b and the bf16 copies of comb itself)
             self._cast('comb')
             self._fwd_gemm('comb', 'dec0', 'g1', 'dec0')
-        self._bn_fwd('bn2', 'g1', 'e1', 12, noise, 'dec_masks', 0, next_lin='dec1')
+        self._bn_fwd('bn2', 'g1', 'e1', 12, noise, 'dec_masks', 0, prefetch=('W:dec1',))
         self._cast('e1')
         self._fwd_block('e1', 'dec1', 'g2', 'dec1', 'bn3', 'e2', 13, noise, 'dec_masks', 1)
         if not fused_losses:                                              # plain x_hat (autograd seam)
@@ -1108,11 +1122,12 @@ class TrainEngine:
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2', ranges=dr.get('dec2'))
         self._region(allreduce, 'dec2')
         self._bn_bwd('bn3', 'de2', 'g2', 'dec1', 13, noise, 'dec_masks', 1,
-                     colsums=nv.colsum_problems(cs_items, acc) if ride else None, next_lin='dec1')   # de2[0] <- dg2p
+                     colsums=nv.colsum_problems(cs_items, acc) if ride else None,
+                     prefetch=('W:dec1', 'e1_bf', 'g1'))   # de2[0] <- dg2p   (next: dX / dW of dec1, then BatchNorm backward on g1)
         self._cast('de2')
         self._bwd_gemms('de2', 'dec1', 'e1', 'de1', 'd_e1', ranges=dr.get('dec1'))
         self._region(allreduce, 'dec1')
-        self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0)   # de1[0] <- dg1p
+        self._bn_bwd('bn2', 'de1', 'g1', 'dec0', 12, noise, 'dec_masks', 0, prefetch=('h2', 'a2_bf'))   # de1[0] <- dg1p
         self._cast('de1')
         # the heads' input gradient comes out of the latent backward launch (fused kernels); the dW products of the two skinny
         # layers (decoder layer 0, heads: K = batch, the longest tiles of their launches) then ride in the next big layer's
@@ -1144,7 +1159,7 @@ class TrainEngine:
         else:
             self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
             self._region(allreduce, 'head')
-        self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1, next_lin='enc1')   # da2[0] <- dh2p
+        self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1, prefetch=('W:enc1', 'a1_bf', 'h1', 'x_bf'))   # da2[0] <- dh2p
         self._cast('da2')
         self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=late_dw, ranges=dr.get('enc1'))
         for ex in late_dw:

@@ -1129,7 +1129,7 @@ def test_bn_prefetch_rider_changes_nothing(nv):
     state = torch.tensor([5, 1, 0, 0], dtype=torch.int64, device='cuda')
     weights = torch.randn(3_000_001, device='cuda').to(torch.bfloat16)
     outs = []
-    for pf in (None, weights[8:]):
+    for pf in (None, [weights[8:], gamma]):
         h = hs.clone()
         out = torch.zeros(B, N, dtype=torch.bfloat16, device='cuda')
         rm, rv, sm, si = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda'), torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
@@ -1150,4 +1150,4 @@ def test_bn_prefetch_rider_changes_nothing(nv):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     with pytest.raises(nv.JamieHipError):
-        nv.bn_act_fwd([pr], p, state, prefetch=weights[1:])        # 2-byte aligned only
+        nv.bn_act_fwd([pr], p, state, prefetch=[weights[1:]])        # 2-byte aligned only
