@@ -1314,6 +1314,19 @@ extern "C" int jamie_cast_transpose(const jamie_cast_problem* pr, int count, voi
 // of the 64x64 GEMM), and d * scale written as fp32 [R, C] plus the bf16 / bf16-transposed copies the backward
 // products read.  Same 64x64 LDS-transposing layout as cast_transpose_kernel.
 // ------------------------------------------------------------------------------------------------
+// once-read loads of the MSE launch (the x_hat slabs, the batch) non-temporal: -2.5 us per step (profiles/r03_ab_more_nt.log;
+// -DJB_MSE_NT=0: default policy)
+#ifndef JB_MSE_NT
+#define JB_MSE_NT 1
+#endif
+__device__ __forceinline__ float4 JB_MSE_LD4(const float* p) {
+#if JB_MSE_NT
+    return make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
+                       __builtin_nontemporal_load(p + 3));
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
 struct MseDev { const float* y; const float* x; float* d; unsigned short* dst; unsigned short* dstT; float* partial;
                 long long slab_stride; int R, C, nslab, blk_begin, tiles_c; float scale, pscale; };
 struct MseGroup { MseDev p[JAMIE_MAX_GROUP]; int count; };
@@ -1337,7 +1350,7 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
     for (int pass = 0; pass < 4; ++pass) {
         yv[pass] = xv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int r = r0 + rr0 + 16 * pass, c = c0 + 4 * q;
-        if (vec && r < P.R && c < P.C) xv[pass] = *reinterpret_cast<const float4*>(P.x + (long long)r * P.C + c);
+        if (vec && r < P.R && c < P.C) xv[pass] = JB_MSE_LD4(P.x + (long long)r * P.C + c);
     }
     if (vec) {
         for (int s0 = 0; s0 < P.nslab; s0 += 4) {
@@ -1348,7 +1361,7 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     t[pass][u] = (r < P.R && c < P.C && s0 + u < P.nslab)
-                                     ? *reinterpret_cast<const float4*>(P.y + (s0 + u) * P.slab_stride + (long long)r * P.C + c)
+                                     ? JB_MSE_LD4(P.y + (s0 + u) * P.slab_stride + (long long)r * P.C + c)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll

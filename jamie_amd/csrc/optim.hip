@@ -72,8 +72,11 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 // whose write-back ran into the next step's first launches -- the forward GEMMs took 31.5 instead of 28.8 us each and the kernel
 // itself 196 instead of 191 us: 638 -> 622 us per step on one box, interleaved (profiles/r03_ab_adam_cache_policy.log; the
 // stand-alone microbenchmark, tools/bench_adam.py, had said "2 % slower" in round 1: what the stores cost shows in the kernels
-// AFTER them).  Loading p and g non-temporally as well: the step another -4 us, the kernel +7 us: not adopted (LD_NT).  The
-// bf16 weight copy non-temporal or not: no difference once the fp32 stores are (W16_NT stays 1).
+// AFTER them).  Loads (LD_NT bit 0: master weights, bit 1: the bf16 gradient): the GRADIENT non-temporal takes 9 us off the
+// kernel and 12 off the step (178 -> 169, 610 -> 598 us: r03_ab_adam_ldnt.log; it is dead once read); the master weights
+// non-temporal cost the kernel 9 us (with or without the gradient): LD_NT = 2.  The bf16 weight copy non-temporal or not: no
+// difference once the fp32 stores are (W16_NT stays 1).  Starting the streams at the second layer so that the first layer's bf16
+// weights are written last (state[2]): +5 us, rejected (r03_ab_adam_rotate_rejected.log).
 #ifndef JAMIE_ADAM_W16_NT
 #define JAMIE_ADAM_W16_NT 1
 #endif
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 #define JAMIE_ADAM_ST_NT 1
 #endif
 #ifndef JAMIE_ADAM_LD_NT
-#define JAMIE_ADAM_LD_NT 0
+#define JAMIE_ADAM_LD_NT 2
 #endif
 template <int U, int T, bool RIDE>
 __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -110,15 +113,21 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
     float4* v4 = reinterpret_cast<float4*>(v);
     const long long nwg = RIDE ? n_stream : gridDim.x;          // streaming workgroups
     // plain loads/stores: non-temporal variants measured 2 % slower here (tools/bench_adam.py: 4.83 vs 4.75 TB/s)
+    // state[2] (optional, float4 units, < n / 4): the stream STARTS there and wraps around, so that the range in front of it -- the
+    // first layer's parameters when the caller passes the offset of the second layer -- is updated LAST and its bf16 weight copy is
+    // the freshest thing in the caches when the next step's first product reads it
+    const long long rot4 = state[2] > 0 && state[2] < n4 ? state[2] : 0;
     float4 pp[U], mm[U], vv[U], gg[U];
     auto load_batch = [&](long long i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = i0 + u * T;
+            long long i = i0 + u * T;
             if (i < n4) {
+                i += rot4;
+                if (i >= n4) i -= n4;
                 // the moments are read once per step: non-temporal loads (in the step -2..-4 us; the master weights and the
                 // stores of all three measured no better streamed)
-#if JAMIE_ADAM_LD_NT      // (A/B build: master weights and gradient loaded non-temporally as well)
+#if JAMIE_ADAM_LD_NT & 1      // (A/B builds: master weights (1) and / or gradient (2) loaded non-temporally as well)
                 pp[u] = make_float4(__builtin_nontemporal_load(&p[4 * i]), __builtin_nontemporal_load(&p[4 * i + 1]),
                                     __builtin_nontemporal_load(&p[4 * i + 2]), __builtin_nontemporal_load(&p[4 * i + 3]));
 #else
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
                 vv[u] = make_float4(__builtin_nontemporal_load(&v[4 * i]), __builtin_nontemporal_load(&v[4 * i + 1]),
                                     __builtin_nontemporal_load(&v[4 * i + 2]), __builtin_nontemporal_load(&v[4 * i + 3]));
                 if (g_bf16) {      // reduced gradient read straight from the bf16 message buffer (no fp32 copy-back pass)
-#if JAMIE_ADAM_LD_NT
+#if JAMIE_ADAM_LD_NT & 2
                     const unsigned long long q64 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(g_bf16) + i);
                     const uint2 q = make_uint2((unsigned)q64, (unsigned)(q64 >> 32));
 #else
@@ -181,8 +190,10 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
     for (; i0 < n4;) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = i0 + u * T;
+            long long i = i0 + u * T;
             if (i >= n4) continue;
+            i += rot4;
+            if (i >= n4) i -= n4;
             upd(pp[u].x, gg[u].x, mm[u].x, vv[u].x);
             upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
             upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z);

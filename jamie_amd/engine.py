@@ -159,6 +159,8 @@ class TrainEngine:
         self.norm_partials = torch.zeros(self.n_norm, **f32)
         # rng/state: [seed, step, 0, 0]
         self.state = torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=self.dev)
+        if self.bf16 and os.environ.get('JAMIE_ADAM_ROTATE', '0') == '1':        # (A/B switch: measured +5 us per step, off)
+            self.set_adam_start(True)
         hyper = torch.zeros(16)
         hyper[H_REC], hyper[H_ALIGN], hyper[H_F] = (self.loss_weights[1], self.loss_weights[2] * ALIGN_WEIGHT,
                                                      self.loss_weights[3])
@@ -403,6 +405,14 @@ class TrainEngine:
             if self._wT_pending:
                 nv.current_stream().wait_event(self._ev_wT)
         self._both(fn)
+
+    def set_adam_start(self, on=True):
+        """clip + Adam walks the flat buffers from the start of the SECOND layer and wraps around (state[2], float4 units): the
+        first layer's parameters are then updated last and its bf16 weights are the freshest lines in the caches when the next
+        step's first product starts (the one forward launch no BatchNorm launch can prefetch for).  Every element sees the
+        same update; only the order of the streams changes."""
+        lo = self.m.layout.regions['enc1'][0] if on else 0
+        self.state[2] = (lo // 4) if lo % 4 == 0 else 0
 
     def enable_pipeline(self, priority=0):
         """Run clip + Adam (and the bf16 weight transposes) on a side stream; `flush()` before anything other than
