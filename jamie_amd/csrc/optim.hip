@@ -67,16 +67,18 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 //   * one workgroup (if smp.idx): the next batch's sampler (state[1] already holds the next step's number), and / or
 //   * the next batch's row gather + bf16 cast (jamie_cast_transpose's 64 x 64 tiles; the batch buffers are free once the last dW
 //     product of this step has run).  Sampler and gather never ride together here: the gather needs the sampler's output.
-// Cache policy of the optimiser's streams (A/B switches: tools/ab.sh + JAMIE_LIB builds).  Round 3: the fp32 stores of p, m, v
-// (484 MB per step, next read a whole step later) go out NON-TEMPORALLY: through the caches they stayed behind as dirty lines
-// whose write-back ran into the next step's first launches -- the forward GEMMs took 31.5 instead of 28.8 us each and the kernel
-// itself 196 instead of 191 us: 638 -> 622 us per step on one box, interleaved (profiles/r03_ab_adam_cache_policy.log; the
-// stand-alone microbenchmark, tools/bench_adam.py, had said "2 % slower" in round 1: what the stores cost shows in the kernels
-// AFTER them).  Loads (LD_NT bit 0: master weights, bit 1: the bf16 gradient): the GRADIENT non-temporal takes 9 us off the
-// kernel and 12 off the step (178 -> 169, 610 -> 598 us: r03_ab_adam_ldnt.log; it is dead once read); the master weights
-// non-temporal cost the kernel 9 us (with or without the gradient): LD_NT = 2.  The bf16 weight copy non-temporal or not: no
-// difference once the fp32 stores are (W16_NT stays 1).  Starting the streams at the second layer so that the first layer's bf16
-// weights are written last (state[2]): +5 us, rejected (r03_ab_adam_rotate_rejected.log).
+// Cache policy of the optimiser's streams (A/B switches: tools/ab.sh + JAMIE_LIB builds).  Round 3: the stores of the moments m, v
+// (322 MB per step, next read a whole step later) go out NON-TEMPORALLY (ST_NT bit 0): through the caches they stayed behind as
+// dirty lines whose write-back ran into the next step's first launches -- the forward GEMMs took 31.5 instead of 28.8 us each and
+// the kernel itself 196 instead of 191 us: 638 -> 622 us per step on one box, interleaved (profiles/r03_ab_adam_cache_policy.log;
+// the stand-alone microbenchmark, tools/bench_adam.py, had said "2 % slower" in round 1: what the stores cost shows in the
+// kernels AFTER them).  The master weights' store too (ST_NT bit 1; in the first build hipcc had silently dropped the hint from
+// the four scalar nt stores it merged): no difference (r03_ab_adam_p_nt.log), left at the default policy.  Loads (LD_NT bit 0:
+// master weights, bit 1: the bf16 gradient): the GRADIENT non-temporal takes 9 us off the kernel and 12 off the step (178 -> 169,
+// 610 -> 598 us: r03_ab_adam_ldnt.log; it is dead once read); the master weights non-temporal cost the kernel 9 us: LD_NT = 2.
+// The bf16 weight copy non-temporal or not: no difference once the moments' stores are (W16_NT stays 1).  Starting the streams
+// at the second layer so that the first layer's bf16 weights are written last (state[2]): +5 us, rejected
+// (r03_ab_adam_rotate_rejected.log).
 #ifndef JAMIE_ADAM_W16_NT
 #define JAMIE_ADAM_W16_NT 1
 #endif
@@ -198,13 +200,16 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
             upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
             upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z);
             upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
-#if JAMIE_ADAM_ST_NT      // (A/B build: the fp32 streams stored non-temporally, so that only the bf16 weights allocate in the caches)
-            __builtin_nontemporal_store(pp[u].x, &p[4 * i]); __builtin_nontemporal_store(pp[u].y, &p[4 * i + 1]);
-            __builtin_nontemporal_store(pp[u].z, &p[4 * i + 2]); __builtin_nontemporal_store(pp[u].w, &p[4 * i + 3]);
-            __builtin_nontemporal_store(mm[u].x, &m[4 * i]); __builtin_nontemporal_store(mm[u].y, &m[4 * i + 1]);
-            __builtin_nontemporal_store(mm[u].z, &m[4 * i + 2]); __builtin_nontemporal_store(mm[u].w, &m[4 * i + 3]);
-            __builtin_nontemporal_store(vv[u].x, &v[4 * i]); __builtin_nontemporal_store(vv[u].y, &v[4 * i + 1]);
-            __builtin_nontemporal_store(vv[u].z, &v[4 * i + 2]); __builtin_nontemporal_store(vv[u].w, &v[4 * i + 3]);
+#if JAMIE_ADAM_ST_NT      // the fp32 streams stored non-temporally (whole 16-byte vectors: four scalar nt stores to p lost the hint
+                          // when hipcc merged them next to the plain vector load of the same address)
+            typedef float adam_f4 __attribute__((ext_vector_type(4)));
+#if JAMIE_ADAM_ST_NT & 2
+            __builtin_nontemporal_store((adam_f4){pp[u].x, pp[u].y, pp[u].z, pp[u].w}, reinterpret_cast<adam_f4*>(p) + i);
+#else
+            p4[i] = pp[u];
+#endif
+            __builtin_nontemporal_store((adam_f4){mm[u].x, mm[u].y, mm[u].z, mm[u].w}, reinterpret_cast<adam_f4*>(m) + i);
+            __builtin_nontemporal_store((adam_f4){vv[u].x, vv[u].y, vv[u].z, vv[u].w}, reinterpret_cast<adam_f4*>(v) + i);
 #else
             p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
 #endif
