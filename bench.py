@@ -506,6 +506,34 @@ def main():
         if world > 1:
             out['rccl'] = rccl_record(world, log_dir) if log_dir else {'backend': torch.distributed.get_backend(),
                                                                         'world': torch.distributed.get_world_size(), 'algo': None}
+    if world > 1 and args.dtype == 'bf16' and comm is not None and args.grad_comm == 'auto' and not args.no_f32_record:
+        # N > 1, bf16 compute: the headline exchanges bf16 messages (summed in bf16 by the collective); the SAME job with fp32
+        # messages (exact sums, twice the bytes) is timed right behind it, on every rank (a step is a collective), so that one
+        # invocation reports both
+        del plan
+        torch.manual_seed(666)
+        m2 = edModelVar(dims, L, device=dev, pad_features=pad)
+        jd.broadcast_flat(m2.flat)
+        e2 = TrainEngine(m2, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype)
+        e2.set_kl_anneal(0.5)
+        ar2 = jd.OverlappedGradAllReduce(comm_dtype=None)
+        idx2 = torch.zeros(B, dtype=torch.int32, device=dev)
+        p2 = e2.make_plan(data, idx2, hi - lo, rep, ar2)
+        n2 = max(10, args.steps // 4)
+        for _ in range(min(args.warmup, 10)):
+            e2.run_plan(p2)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            e2.run_plan(p2)
+        barrier()
+        d2 = time.perf_counter() - t2
+        tt = torch.tensor([d2], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            out['grad_comm_f32'] = {'value': world * B * n2 / float(tt.item()), 'unit': 'cells/s', 'ms_per_step': 1e3 * float(tt.item()) / n2,
+                                    'steps': n2, 'grad_allreduce': 'f32', 'note': 'the same job with fp32 gradient messages (exact sums)'}
+        del p2, e2, m2
     if world == 1:
         # free the timed engine's buffers before the side legs
         del plan

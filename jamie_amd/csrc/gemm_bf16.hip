@@ -68,6 +68,11 @@ struct BnFuse {
 #ifndef JB_W_NT
 #define JB_W_NT 0
 #endif
+// A/B build -DJB_SLAB_SC1=1: the large-tile kernel's plain fp32 stores (split-K slabs, read by the next launch) go out
+// write-through, so that the launch leaves no dirty lines for the kernel boundary to write back
+#ifndef JB_SLAB_SC1
+#define JB_SLAB_SC1 0
+#endif
 
 // Diagnostic build only (-DJAMIE_GEMMB_STAMP, tools/stamp_gemm_bf16.sh): thread 0 of every workgroup of the large-tile
 // kernel writes s_memrealtime (100 MHz) at entry / tile 0 published / k-loop done / stores issued into a buffer of its
@@ -833,7 +838,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                                       // L2 / Infinity Cache, whose write-back ran into the optimiser kernel (229 -> 208 us)
                     __builtin_nontemporal_store(v[0], cp); __builtin_nontemporal_store(v[1], cp + 1);
                     __builtin_nontemporal_store(v[2], cp + 2); __builtin_nontemporal_store(v[3], cp + 3);
-                } else if constexpr (FUSE) {
+                } else if constexpr (FUSE || JB_SLAB_SC1 != 0) {
                     // write-through (sc1): the slab is read by another workgroup of THIS launch (publish-large: no release
                     // fence, no dirty lines to write back before the ticket)
                     const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(

@@ -559,14 +559,15 @@ class TrainEngine:
         weights (JAMIE_PREFETCH=2): 631.9 against 628.3 us with the weights alone (632.6 without): the extra ranges stretch the
         BatchNorm launches by what the next launches gain -- the default (1) prefetches the weights only.  JAMIE_PREFETCH=0: off."""
         mode = os.environ.get('JAMIE_PREFETCH', '1')
-        if not self.bf16 or mode == '0' or self.pipeline:
+        f32_mode = os.environ.get('JAMIE_PREFETCH_F32', '0')          # (A/B knob: '1' = in fp32 mode too, 'bwd' = its backward only)
+        if mode == '0' or self.pipeline or (not self.bf16 and f32_mode == '0'):
             return None
         out = []
         for it in items:
             if it.startswith('W:'):
                 lo, hi = self.m.layout.regions[it[2:]]
                 lo = (lo + 7) // 8 * 8                   # (16-byte aligned in the bf16 copy)
-                out.append(self.wbf_flat[lo:hi])
+                out.append((self.wbf_flat if self.bf16 else self.m.flat)[lo:hi])
             elif mode != '1':
                 for w in self.ws:
                     t = w.get(it)
@@ -590,6 +591,8 @@ class TrainEngine:
                 pr.out, pr.out_bf16 = None, nv.ptr(w[out_key + '_bf'])
                 pr.outT_bf16 = nv.ptr(w[out_key + '_T']) if out_key in self.need_T else None
             probs.append(pr)
+        if not self.bf16 and os.environ.get('JAMIE_PREFETCH_F32', '0') == 'bwd':
+            prefetch = ()
         nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE, self._prefetch(*prefetch))
 
     def _bn_bwd(self, layer, da_key, h_key, lin, stream_base, noise, kind, j, colsums=None, prefetch=()):

@@ -325,6 +325,15 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and 'cpu_baseline' not in out
     assert np.isfinite(out['final_loss'])
+    # bf16 compute at N > 1: the line also carries the same job timed with fp32 gradient messages
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29578', os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--steps', '8', '--warmup', '2', '--config', 'c1'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert out['dtype'] == 'bf16' and out['config']['grad_allreduce'] == 'bf16'
+    assert out['grad_comm_f32']['grad_allreduce'] == 'f32' and out['grad_comm_f32']['value'] > 0
 
 
 def test_bench_config5_path_two_ranks_at_reduced_cells(tmp_path):
