@@ -29,8 +29,8 @@
 // q = ceil(strips / 8): blocks are dealt round-robin over the 8 XCDs (lb & 7), so every XCD owns a CONTIGUOUS range of
 // strips.  Neighbouring strips share 128-byte lines (a strip is 64 bytes of an fp32 row, 32 bytes of a bf16 row): the
 // two halves of a line are then read through ONE L2 and the partial-line stores of neighbours merge there.
-__device__ __forceinline__ int bn_strip(int lb, int n_cols) {
-    const int nst = (n_cols + 15) / 16, q = (nst + 7) >> 3;
+__device__ __forceinline__ int bn_strip(int lb, int n_cols, int width = 16) {
+    const int nst = (n_cols + width - 1) / width, q = (nst + 7) >> 3;
     return (lb & 7) * q + (lb >> 3);
 }
 #define BN_RP 16
@@ -362,15 +362,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
 // two slabs in flight at a time, column sums by xor-shuffles over the 16 row phases of a wave + a 4-wave LDS step.
 // ------------------------------------------------------------------------------------------------
 // two column sums at once (one pair of barriers): sh2 is [4][2 * BN_CW]
+template <int CQ = 4>
 __device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)[2 * BN_CW], int tid) {
 #pragma unroll
-    for (int m = 4; m < 64; m <<= 1) {
+    for (int m = CQ; m < 64; m <<= 1) {
         a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
         b.x += __shfl_xor(b.x, m); b.y += __shfl_xor(b.y, m); b.z += __shfl_xor(b.z, m); b.w += __shfl_xor(b.w, m);
     }
-    const int lane = tid & 63, wid = tid >> 6, cq = tid & 3;
+    const int lane = tid & 63, wid = tid >> 6, cq = tid & (CQ - 1);
     __syncthreads();
-    if (lane < 4) {
+    if (lane < CQ) {
         float* d = sh2[wid] + 8 * lane;
         d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
     }
@@ -380,7 +381,7 @@ __device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)
     for (int e = 0; e < 8; ++e) {
         t[e] = 0.f;
 #pragma unroll
-        for (int w = 0; w < BN4_NW; ++w) t[e] += sh2[w][8 * cq + e];
+        for (int w = 0; w < 2 * CQ; ++w) t[e] += sh2[w][8 * cq + e];
     }
     a = make_float4(t[0], t[1], t[2], t[3]);
     b = make_float4(t[4], t[5], t[6], t[7]);
@@ -400,8 +401,8 @@ static int bn_pf_blocks() {         // (tuning knob: JAMIE_PF_BLOCKS)
 #define BN_PF_MAX 8
 struct PfRanges { const char* p[BN_PF_MAX]; long long bytes[BN_PF_MAX]; int n; };
 __device__ __forceinline__ void prefetch_range(const char* p, long long bytes, int blk, int nblk) {
-    const long long stride = (long long)nblk * 512 * 16;
-    for (long long off = ((long long)blk * 512 + threadIdx.x) * 16; off < bytes; off += BN_PF_UNROLL * stride) {
+    const long long stride = (long long)nblk * blockDim.x * 16;
+    for (long long off = ((long long)blk * blockDim.x + threadIdx.x) * 16; off < bytes; off += BN_PF_UNROLL * stride) {
         bn_u32x4 v[BN_PF_UNROLL];
 #pragma unroll
         for (int u = 0; u < BN_PF_UNROLL; ++u) {
@@ -419,9 +420,9 @@ __device__ __forceinline__ void prefetch_block(const PfRanges& r, int blk, int n
         if (i < r.n) prefetch_range(r.p[i], r.bytes[i], blk, nblk);
 }
 
-template <int R>
-__global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
-                                                          float slope, const uint64_t* rng, PfRanges pf, int n_main) {
+template <int R, int CQ>
+__global__ __launch_bounds__(128 * CQ) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
+                                                               float slope, const uint64_t* rng, PfRanges pf, int n_main) {
     if ((int)blockIdx.x >= n_main) {
         prefetch_block(pf, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);
         return;
@@ -433,16 +434,16 @@ __global__ __launch_bounds__(512) void bn_act_fwd4_kernel(BnFwdGroup g, float p_
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnFwdDev& P = g.p[pi];
-    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW;
-    bn_fwd4_strip<R, JAMIE_BN_LD_AUX>(P, col0, (int)threadIdx.x, true, sh, tl, p_drop, momentum, eps, slope, rng);      // (bn_fwd_strip.h)
+    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N, 4 * CQ) * (4 * CQ);
+    bn_fwd4_strip<R, JAMIE_BN_LD_AUX, CQ>(P, col0, (int)threadIdx.x, true, sh, tl, p_drop, momentum, eps, slope, rng);      // (bn_fwd_strip.h)
 }
 
 // `cs` / `cs_begin`: workgroups cs_begin .. are EXTRA ones that compute column sums (jamie_bn_act_bwd_cs: the decoder's
 // output-bias gradient = column sums of d x_hat rides in the first BatchNorm-backward launch of the step instead of being a
 // launch of its own at the head of the backward pass; 47 short workgroups beside 375 long ones)
-template <int R>
-__global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng,
-                                                          ColsumGroup cs, int cs_begin, PfRanges pf, int pf_begin) {
+template <int R, int CQ>
+__global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng,
+                                                               ColsumGroup cs, int cs_begin, PfRanges pf, int pf_begin) {
     if ((int)blockIdx.x >= pf_begin) {
         prefetch_block(pf, (int)blockIdx.x - pf_begin, (int)gridDim.x - pf_begin);
         return;
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
     const BnBwdDev& P = g.p[pi];
-    const int tid = threadIdx.x, cq = tid & 3, rp = tid >> 2;
-    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N) * BN_CW, col = col0 + 4 * cq;
+    const int tid = threadIdx.x, cq = tid & (CQ - 1), rp = tid / CQ;
+    const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N, 4 * CQ) * (4 * CQ), col = col0 + 4 * cq;
     const bool cok = col < P.N;
     const int B = P.B, N = P.N, nslab = P.nslab;
     float mean[4] = {0.f, 0.f, 0.f, 0.f}, invstd[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
         s1.x += d[0]; s1.y += d[1]; s1.z += d[2]; s1.w += d[3];
         s2.x += d[0] * x[0]; s2.y += d[1] * x[1]; s2.z += d[2] * x[2]; s2.w += d[3] * x[3];
     }
-    col_reduce4x2(s1, s2, sh2, tid);
+    col_reduce4x2<CQ>(s1, s2, sh2, tid);
     const float4 dbeta = s1, dgamma = s2;
     const float invB = 1.f / (float)B;
     const float k1[4] = {dbeta.x * invB, dbeta.y * invB, dbeta.z * invB, dbeta.w * invB};
@@ -560,8 +561,8 @@ __global__ __launch_bounds__(512) void bn_act_bwd4_kernel(BnBwdGroup g, float p_
     }
     // the bias-gradient column sums come BEFORE the bf16 stores: col_reduce4's barriers are `__syncthreads()`, which drain
     // vmcnt(0) -- behind the stores they made every wave wait for its stores to be acknowledged
-    const float4 dbias = col_reduce4(s3, sh, tid);
-    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4<R>(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, tid, cok);
+    const float4 dbias = col_reduce4<CQ>(s3, sh, tid);
+    if (P.dh_bf || P.dhT_bf) strip_out_bf16x4<R, CQ>(dyv, P.dh_bf, P.dhT_bf, tl, B, N, col0, tid, cok);
     if (cok && rp == 0) {
         const float dg[4] = {dgamma.x, dgamma.y, dgamma.z, dgamma.w}, db[4] = {dbeta.x, dbeta.y, dbeta.z, dbeta.w};
         const float dl[4] = {dbias.x, dbias.y, dbias.z, dbias.w};
@@ -601,6 +602,18 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
                                    float slope, const uint64_t* rng, const void* const* prefetch, const long long* prefetch_bytes,
                                    int n_prefetch, void* stream) {
     return bn_act_fwd_impl(pr, count, p_drop, momentum, eps, slope, rng, prefetch, prefetch_bytes, n_prefetch, stream);
+}
+
+// Strip width of the float4 kernels: 16 columns on 512 threads (CQ = 4 column quads).  8 columns on 256 threads (CQ = 2) was
+// built in round 3 to balance the chip -- at config 2 the 2d-wide layers have 375 strips for 256 CUs: half of the CUs carry two
+// workgroups, the others one -- and measured: the step 595 -> 639 us (profiles/r03_ab_bn_strip_width_rejected.log): a
+// wave-instruction then covers 32 rows x 32 bytes instead of 16 rows x 64, every 128-byte line is fetched by four workgroups
+// instead of two, and the address path, not the balance, sets these kernels' time.  JAMIE_BN_CQ=2 selects it (tuning knob; the
+// transposed bf16 copies are laid out for 16-column strips and always take CQ = 4).
+static int bn_pick_cq(long long strips16, bool needs16) {
+    (void)strips16;
+    const char* e = getenv("JAMIE_BN_CQ");
+    return (!needs16 && e && atoi(e) == 2) ? 2 : 4;
 }
 
 static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
@@ -643,10 +656,21 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     hipStream_t st = (hipStream_t)stream;
     JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
-    if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel<4>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
+    bool needs16 = false;
+    for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].outT_bf16 != nullptr;
+    const int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16) : 4;
+    if (cq == 2) {                 // 8-column strips: the workgroup ranges of the problems again
+        blocks = 0;
+        for (int i = 0; i < count; ++i) { g.p[i].blk_begin = blocks; blocks += 8 * (((pr[i].N + 7) / 8 + 7) / 8); }
+    }
+    if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 2)
+        hipLaunchKernelGGL((bn_act_fwd4_kernel<4, 2>), dim3(blocks + pfb), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
+    else if (wide && maxB <= 8 * BN4_RP && cq == 2)
+        hipLaunchKernelGGL((bn_act_fwd4_kernel<8, 2>), dim3(blocks + pfb), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
+    else if (wide && maxB <= BN4_MAXR * BN4_RP)
+        hipLaunchKernelGGL((bn_act_fwd4_kernel<4, 4>), dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
     else if (wide && maxB <= 8 * BN4_RP)
-        hipLaunchKernelGGL(bn_act_fwd4_kernel<8>, dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
+        hipLaunchKernelGGL((bn_act_fwd4_kernel<8, 4>), dim3(blocks + pfb), dim3(512), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng);
     else
@@ -731,11 +755,24 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     const bool wide4 = wide && maxB <= 8 * BN4_RP;
     const int extra = wide4 ? cs_blocks : 0;            // the float4 kernels take the column sums as extra workgroups
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;
-    if (wide && maxB <= BN4_MAXR * BN4_RP)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel<4>, dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
+    bool needs16 = false;
+    for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].dhT_bf16 != nullptr;
+    const int cq = wide4 ? bn_pick_cq(blocks, needs16) : 4;
+    if (cq == 2) {
+        blocks = 0;
+        for (int i = 0; i < count; ++i) { g.p[i].blk_begin = blocks; blocks += 8 * (((pr[i].N + 7) / 8 + 7) / 8); }
+    }
+    if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 2)
+        hipLaunchKernelGGL((bn_act_bwd4_kernel<4, 2>), dim3(blocks + extra + pfb), dim3(256), 0, st, g, p_drop, slope, rng, cs, blocks,
+                           pfr, blocks + extra);
+    else if (wide4 && cq == 2)
+        hipLaunchKernelGGL((bn_act_bwd4_kernel<8, 2>), dim3(blocks + extra + pfb), dim3(256), 0, st, g, p_drop, slope, rng, cs, blocks,
+                           pfr, blocks + extra);
+    else if (wide && maxB <= BN4_MAXR * BN4_RP)
+        hipLaunchKernelGGL((bn_act_bwd4_kernel<4, 4>), dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
                            pfr, blocks + extra);
     else if (wide4)
-        hipLaunchKernelGGL(bn_act_bwd4_kernel<8>, dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
+        hipLaunchKernelGGL((bn_act_bwd4_kernel<8, 4>), dim3(blocks + extra + pfb), dim3(512), 0, st, g, p_drop, slope, rng, cs, blocks,
                            pfr, blocks + extra);
     else if (maxB <= BN_MAXR * BN_RP)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, g, p_drop, slope, rng);

@@ -54,19 +54,21 @@ __device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned o
 __device__ __forceinline__ unsigned buf_u32(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
 }
-// `t`: thread index inside the team (0 .. 511); the barriers are workgroup barriers (every team of the workgroup calls in step)
+// `t`: thread index inside the team (0 .. 128 CQ - 1); CQ = column quads per strip (4: 16 columns on 512 threads, 2: 8 columns on
+// 256); the barriers are workgroup barriers (every team of the workgroup calls in step)
+template <int CQ = 4>
 __device__ __forceinline__ float4 col_reduce4(float4 v, float (*sh)[BN_CW], int t) {
 #pragma unroll
-    for (int m = 4; m < 64; m <<= 1) {
+    for (int m = CQ; m < 64; m <<= 1) {
         v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
     }
-    const int lane = t & 63, wid = t >> 6, cq = t & 3;
+    const int lane = t & 63, wid = t >> 6, cq = t & (CQ - 1);
     __syncthreads();
-    if (lane < 4) { sh[wid][4 * lane] = v.x; sh[wid][4 * lane + 1] = v.y; sh[wid][4 * lane + 2] = v.z; sh[wid][4 * lane + 3] = v.w; }
+    if (lane < CQ) { sh[wid][4 * lane] = v.x; sh[wid][4 * lane + 1] = v.y; sh[wid][4 * lane + 2] = v.z; sh[wid][4 * lane + 3] = v.w; }
     __syncthreads();
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < BN4_NW; ++w)
+    for (int w = 0; w < 2 * CQ; ++w)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] += sh[w][4 * cq + e];
     return make_float4(s[0], s[1], s[2], s[3]);
@@ -76,10 +78,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 }
 // bf16 outputs of a strip held as val[j] = 4 columns of row rp + 128 j: row-major [B, N] (8-byte stores) and, optionally,
 // transposed [N, B] through the LDS tile `tl` (16 x (128 R + 2) shorts)
-template <int R>
+template <int R, int CQ = 4>
 __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigned short* out_bf, unsigned short* outT_bf,
                                                  unsigned short* tl, int B, int N, int col0, int t, bool cok) {
-    const int cq = t & 3, rp = t >> 2;
+    const int cq = t & (CQ - 1), rp = t / CQ;
     const int col = col0 + 4 * cq;
     if (out_bf && cok) {
 #pragma unroll
@@ -90,7 +92,7 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigne
                     make_uint2(pack_bf16x2(val[j].x, val[j].y), pack_bf16x2(val[j].z, val[j].w));
         }
     }
-    if (!outT_bf) return;
+    if (CQ != 4 || !outT_bf) return;                 // (the transposed copy is laid out for 16-column strips)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -114,11 +116,11 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigne
 // One strip: columns col0 .. col0 + 15 (those < N; `active` false: the team only takes part in the barriers).
 // The summed pre-activation goes back to slab 0 (read again by the backward pass), the batch statistics to save_mean /
 // save_invstd, the running statistics are updated in place, the activation goes out as fp32 and / or bf16.
-template <int R, int AUX>
+template <int R, int AUX, int CQ = 4>
 __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t, bool active, float (*sh)[BN_CW],
                                               unsigned short* tl, float p_drop, float momentum, float eps, float slope,
                                               const uint64_t* rng) {
-    const int cq = t & 3, rp = t >> 2;
+    const int cq = t & (CQ - 1), rp = t / CQ;
     const int col = col0 + 4 * cq;
     const bool cok = active && col < P.N;             // N % 4 == 0: a quad is wholly in or out
     const int B = P.B, N = P.N, nslab = P.nslab;
@@ -197,7 +199,7 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < R; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
-    float4 mean = col_reduce4(sum, sh, t);
+    float4 mean = col_reduce4<CQ>(sum, sh, t);
     const float fB = (float)B;
     mean.x /= fB; mean.y /= fB; mean.z /= fB; mean.w /= fB;
     float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -208,7 +210,7 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
             sq.x += dx * dx; sq.y += dy * dy; sq.z += dz * dz; sq.w += dw * dw;
         }
     }
-    float4 var = col_reduce4(sq, sh, t);
+    float4 var = col_reduce4<CQ>(sq, sh, t);
     var.x /= fB; var.y /= fB; var.z /= fB; var.w /= fB;
     const float4 invstd = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
     if (cok && rp == 0) {
@@ -250,5 +252,5 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
         }
         v[j] = make_float4(y[0], y[1], y[2], y[3]);
     }
-    if (P.out_bf || P.outT_bf) strip_out_bf16x4<R>(v, P.out_bf, P.outT_bf, tl, B, N, col0, t, cok);
+    if (P.out_bf || P.outT_bf) strip_out_bf16x4<R, CQ>(v, P.out_bf, P.outT_bf, tl, B, N, col0, t, cok);
 }

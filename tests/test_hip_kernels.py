@@ -1085,7 +1085,8 @@ def _fused_bn_case(nv, B, shapes, cfg, sks, p, mode, explicit_mask, rounds=3, se
     (200, [(264, 136)], 32, (2,), 0.6, False),                         # rows beyond the batch in the last M tile
     (512, [(10000, 5000)], 31, (2,), 0.6, False),                      # config 5's width: 79 strips, 316 workgroups (> 256 CUs: two rounds)
 ])
-def test_gemm_bf16_fused_batchnorm_equals_two_launches(nv, B, shapes, cfg, sks, p, explicit, mode):
+def test_gemm_bf16_fused_batchnorm_equals_two_launches(nv, monkeypatch, B, shapes, cfg, sks, p, explicit, mode):
+    monkeypatch.setenv('JAMIE_BN_CQ', '4')       # (the fused launch runs 16-column strips: the same summation order as these)
     _fused_bn_case(nv, B, shapes, cfg, sks, p, mode, explicit, seed=B + cfg)
 
 

@@ -1124,6 +1124,7 @@ def test_fused_linear_batchnorm_launch_is_bit_identical_to_two_launches(jam, mon
     g = torch.Generator().manual_seed(1)
     data = [torch.randn(N, d, generator=g).cuda() for d in dims]
     out = []
+    monkeypatch.setenv('JAMIE_BN_CQ', '4')           # (the fused launch runs 16-column strips: the same summation order)
     for fused, mode in (('0', '2'), ('1', '1'), ('1', '2')):
         monkeypatch.setenv('JAMIE_FUSED_BN', fused)
         monkeypatch.setenv('JAMIE_FUSED_BN_MODE', mode)
