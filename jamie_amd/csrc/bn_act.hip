@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnBwdGroup g, float p_d
 // ------------------------------------------------------------------------------------------------
 // two column sums at once (one pair of barriers): sh2 is [4][2 * BN_CW]
 template <int CQ = 4>
-__device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)[2 * BN_CW], int tid) {
+__device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)[8 * CQ], int tid) {
 #pragma unroll
     for (int m = CQ; m < 64; m <<= 1) {
         a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
@@ -427,8 +427,9 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_fwd4_kernel(BnFwdGroup g, flo
         prefetch_block(pf, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);
         return;
     }
-    __shared__ float sh[BN4_NW][BN_CW];
-    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * (128 * R + 2)];
+    __shared__ float shraw[2 * CQ * 4 * CQ];                     // [waves = 2 CQ][columns = 4 CQ]
+    float (*sh)[4 * CQ] = reinterpret_cast<float (*)[4 * CQ]>(shraw);
+    __shared__ __attribute__((aligned(16))) unsigned short tl[CQ == 4 ? BN_CW * (128 * R + 2) : 8];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
@@ -454,9 +455,11 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, flo
         colsum_block(cs, (int)blockIdx.x - cs_begin, csh, &o);
         return;
     }
-    __shared__ float sh[BN4_NW][BN_CW];
-    __shared__ float sh2[BN4_NW][2 * BN_CW];
-    __shared__ __attribute__((aligned(16))) unsigned short tl[BN_CW * (128 * R + 2)];
+    __shared__ float shraw[2 * CQ * 4 * CQ];
+    __shared__ float sh2raw[2 * CQ * 8 * CQ];
+    float (*sh)[4 * CQ] = reinterpret_cast<float (*)[4 * CQ]>(shraw);
+    float (*sh2)[8 * CQ] = reinterpret_cast<float (*)[8 * CQ]>(sh2raw);
+    __shared__ __attribute__((aligned(16))) unsigned short tl[CQ == 4 ? BN_CW * (128 * R + 2) : 8];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
@@ -608,12 +611,14 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
 // built in round 3 to balance the chip -- at config 2 the 2d-wide layers have 375 strips for 256 CUs: half of the CUs carry two
 // workgroups, the others one -- and measured: the step 595 -> 639 us (profiles/r03_ab_bn_strip_width_rejected.log): a
 // wave-instruction then covers 32 rows x 32 bytes instead of 16 rows x 64, every 128-byte line is fetched by four workgroups
-// instead of two, and the address path, not the balance, sets these kernels' time.  JAMIE_BN_CQ=2 selects it (tuning knob; the
-// transposed bf16 copies are laid out for 16-column strips and always take CQ = 4).
+// instead of two, and the address path, not the balance, sets these kernels' time.  32 columns on 1024 threads (CQ = 8: whole
+// lines per row, 188 workgroups): 592 -> 601 us.  JAMIE_BN_CQ=2 / 8 select them (tuning knob; the transposed bf16 copies are laid
+// out for 16-column strips and always take CQ = 4).
 static int bn_pick_cq(long long strips16, bool needs16) {
     (void)strips16;
     const char* e = getenv("JAMIE_BN_CQ");
-    return (!needs16 && e && atoi(e) == 2) ? 2 : 4;
+    const int v = e ? atoi(e) : 4;
+    return (!needs16 && (v == 2 || v == 8)) ? v : 4;
 }
 
 static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
@@ -658,12 +663,19 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].outT_bf16 != nullptr;
-    const int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16) : 4;
+    int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16) : 4;
+    if (cq == 8 && maxB > BN4_MAXR * BN4_RP) cq = 4;
     if (cq == 2) {                 // 8-column strips: the workgroup ranges of the problems again
         blocks = 0;
         for (int i = 0; i < count; ++i) { g.p[i].blk_begin = blocks; blocks += 8 * (((pr[i].N + 7) / 8 + 7) / 8); }
     }
-    if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 2)
+    if (cq == 8) {                 // 32-column strips on 1024 threads (B <= 512 only)
+        blocks = 0;
+        for (int i = 0; i < count; ++i) { g.p[i].blk_begin = blocks; blocks += 8 * (((pr[i].N + 31) / 32 + 7) / 8); }
+    }
+    if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 8)
+        hipLaunchKernelGGL((bn_act_fwd4_kernel<4, 8>), dim3(blocks + pfb), dim3(1024), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
+    else if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 2)
         hipLaunchKernelGGL((bn_act_fwd4_kernel<4, 2>), dim3(blocks + pfb), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
     else if (wide && maxB <= 8 * BN4_RP && cq == 2)
         hipLaunchKernelGGL((bn_act_fwd4_kernel<8, 2>), dim3(blocks + pfb), dim3(256), 0, st, g, p_drop, momentum, eps, slope, rng, pfr, blocks);
@@ -757,12 +769,20 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].dhT_bf16 != nullptr;
-    const int cq = wide4 ? bn_pick_cq(blocks, needs16) : 4;
+    int cq = wide4 ? bn_pick_cq(blocks, needs16) : 4;
+    if (cq == 8 && maxB > BN4_MAXR * BN4_RP) cq = 4;
     if (cq == 2) {
         blocks = 0;
         for (int i = 0; i < count; ++i) { g.p[i].blk_begin = blocks; blocks += 8 * (((pr[i].N + 7) / 8 + 7) / 8); }
     }
-    if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 2)
+    if (cq == 8) {
+        blocks = 0;
+        for (int i = 0; i < count; ++i) { g.p[i].blk_begin = blocks; blocks += 8 * (((pr[i].N + 31) / 32 + 7) / 8); }
+    }
+    if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 8)
+        hipLaunchKernelGGL((bn_act_bwd4_kernel<4, 8>), dim3(blocks + extra + pfb), dim3(1024), 0, st, g, p_drop, slope, rng, cs, blocks,
+                           pfr, blocks + extra);
+    else if (wide && maxB <= BN4_MAXR * BN4_RP && cq == 2)
         hipLaunchKernelGGL((bn_act_bwd4_kernel<4, 2>), dim3(blocks + extra + pfb), dim3(256), 0, st, g, p_drop, slope, rng, cs, blocks,
                            pfr, blocks + extra);
     else if (wide4 && cq == 2)

@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned buf_u32(__amdgpu_buffer_rsrc_t r, unsigned o
 // `t`: thread index inside the team (0 .. 128 CQ - 1); CQ = column quads per strip (4: 16 columns on 512 threads, 2: 8 columns on
 // 256); the barriers are workgroup barriers (every team of the workgroup calls in step)
 template <int CQ = 4>
-__device__ __forceinline__ float4 col_reduce4(float4 v, float (*sh)[BN_CW], int t) {
+__device__ __forceinline__ float4 col_reduce4(float4 v, float (*sh)[4 * CQ], int t) {
 #pragma unroll
     for (int m = CQ; m < 64; m <<= 1) {
         v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
@@ -117,7 +117,7 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigne
 // The summed pre-activation goes back to slab 0 (read again by the backward pass), the batch statistics to save_mean /
 // save_invstd, the running statistics are updated in place, the activation goes out as fp32 and / or bf16.
 template <int R, int AUX, int CQ = 4>
-__device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t, bool active, float (*sh)[BN_CW],
+__device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t, bool active, float (*sh)[4 * CQ],
                                               unsigned short* tl, float p_drop, float momentum, float eps, float slope,
                                               const uint64_t* rng) {
     const int cq = t & (CQ - 1), rp = t / CQ;
