@@ -382,11 +382,13 @@ class TrainEngine:
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
     # Adam is HBM-bound (28 B/parameter) and the forward GEMMs are bound by the L2 -> LDS fabric and the matrix pipe, so
-    # the two share the chip well.  The flat buffers are layer-major, so the update is issued as four contiguous
-    # launches in FORWARD order (enc0 | enc1+head+dec0 | dec1 | dec2, about a quarter of the parameters each); the
+    # the two share the chip well.  The flat buffers hold the small tensors first and then the large weight matrices in
+    # forward order, so the update is issued as four contiguous launches (rep + enc0 | enc1 | dec1 | dec2, about a quarter
+    # of the parameters each); the
     # forward pass of the next step waits, layer by layer, for the event of the group it is about to read.  Every
     # element sees exactly the update of the one-launch form (bit-identical, tests/test_hip_step.py).
-    PIPE_GROUPS = (('enc0',), ('enc1', 'head', 'dec0'), ('dec1',), ('dec2',))
+    PIPE_GROUPS = (('rep', 'enc0'), ('enc1',), ('dec1',), ('dec2',))
+    PIPE_LINS = (('enc0', 'head', 'dec0'), ('enc1',), ('dec1',), ('dec2',))       # (the layers whose weights a group holds)
     PIPE_WAIT = {'enc0': 0, 'enc1': 1, 'dec1': 2, 'dec2': 3}
 
     def enable_side_transposes(self):
@@ -916,6 +918,8 @@ class TrainEngine:
     def _region(self, ar, name):
         """Tell an overlapping all-reduce that the gradients of parameter region `name` have been launched."""
         if ar is not None and hasattr(ar, 'region_done'):
+            if name not in self.m.layout.regions:      # (heads / decoder layer 0: their gradients travel with `rep`)
+                return
             lo, hi = self.m.layout.regions[name]
             if self._direct_now:
                 fn = lambda: ar.region_done(self.grad, lo, hi, precast=True)   # noqa: E731
@@ -1054,7 +1058,7 @@ class TrainEngine:
     def _direct_setup(self, allreduce):
         """Data parallel with bf16 messages: every producer writes its gradients into the exchange's bf16 buffer itself -- the
         dW epilogues store bf16 there (c_bf16; no fp32 copy of the weight gradients), the few KB of bias / BatchNorm / sigma
-        gradients of a region are copied by riders of that region's GEMM launch (range_norm.h with the message buffer as the
+        gradients are copied by a rider of the last GEMM launch (range_norm.h with the message buffer as the
         bf16 copy; no step-counter increment) -- so the fp32 -> bf16 cast pass over the 161 MB gradient (a second stream beside
         the backward GEMMs, two events per region) does not exist.  Returns None where the path does not apply."""
         ok = (allreduce is not None and hasattr(allreduce, 'message_buffer') and getattr(allreduce, 'comm_dtype', None) == torch.bfloat16
@@ -1067,40 +1071,34 @@ class TrainEngine:
         comm = allreduce.message_buffer(self.grad)
         if self._direct is None or self._direct['comm'] is not comm:
             lay = self.m.layout
-            small = {}
-            for name, (lo, hi) in lay.regions.items():
-                big = sorted((o, o + int(np.prod(shp))) for k, (o, shp) in lay.entries.items()
-                             if k.endswith('.W') and lo <= o < hi)
-                rest, pos = [], lo
-                for a, b in big:
-                    if a > pos:
-                        rest.append((pos, a - pos))
-                    pos = b
-                if hi > pos:
-                    rest.append((pos, hi - pos))
-                small[name] = rest
-            # the latent block's finalisation (d sigma, the head-bias gradients: fp32 and bf16 copies) is deferred to the rider that
-            # carries the head region's small pieces: those slots are cut out of its ranges
+            # the small tensors all live in region `rep`, which is announced last (with enc0): ONE rider, on the enc0 dW launch,
+            # copies what no GEMM epilogue writes there (everything but the two skinny weight matrices per modality)
+            lo, hi = lay.regions['rep']
+            big = sorted((o, o + int(np.prod(shp))) for k, (o, shp) in lay.entries.items() if k.endswith('.W') and lo <= o < hi)
+            rest, pos = [], lo
+            for a, b in big:
+                if a > pos:
+                    rest.append((pos, a - pos))
+                pos = b
+            if hi > pos:
+                rest.append((pos, hi - pos))
+            # the latent block's finalisation (d sigma, the head-bias gradients: fp32 and bf16 copies) is deferred to that same
+            # rider: those slots are cut out of its ranges
             cut = sorted((o, o + (int(np.prod(shp)) + 3) // 4 * 4) for o, shp in
                          [lay.entries['sigma']] + [lay.entries[f'm{i}.head.b'] for i in range(self.M)])
-            head_rest = []
-            for lo_, ln_ in small['head']:
+            small = []
+            for lo_, ln_ in rest:
                 hi_ = lo_ + ln_
                 for c0, c1 in cut:
                     if c0 >= hi_ or c1 <= lo_:
                         continue
                     if c0 > lo_:
-                        head_rest.append((lo_, c0 - lo_))
+                        small.append((lo_, c0 - lo_))
                     lo_ = max(lo_, c1)
                 if hi_ > lo_:
-                    head_rest.append((lo_, hi_ - lo_))
-            small['head'] = head_rest
-            groups = {'dec2': ['dec2'], 'dec1': ['dec1'], 'enc1': ['dec0', 'head', 'enc1'], 'enc0': ['enc0']}
-            rides = {}
-            for key, names in groups.items():
-                rg = nv.SqRanges([r for nm in names for r in small[nm]])
-                extra = 1 if key == 'enc1' else 0               # (+ the finaliser's slot)
-                rides[key] = (self.grad, comm, rg, torch.zeros(rg.blocks + extra, device=self.dev, dtype=torch.float32), None, None)
+                    small.append((lo_, hi_ - lo_))
+            rg = nv.SqRanges(small)
+            rides = {'enc0': (self.grad, comm, rg, torch.zeros(rg.blocks + 1, device=self.dev, dtype=torch.float32), None, None)}
             self._direct = {'comm': comm, 'views': lay.views(comm), 'rides': rides}
         return self._direct
 
@@ -1110,9 +1108,9 @@ class TrainEngine:
         direct = self._direct_setup(allreduce) if isinstance(lat, nv.LatentM) and lat.da2[0] else None
         self._direct_now = direct is not None
         dr = dict(direct['rides']) if direct else {}
-        if direct:                     # the finaliser rides with the head region's small pieces (enc1 launch)
+        if direct:                     # the finaliser rides with the small pieces (enc0 launch, the last of the pass)
             lat.defer_final = 1
-            dr['enc1'] = dr['enc1'][:5] + (lat,)
+            dr['enc0'] = dr['enc0'][:5] + (lat,)
         self._wait_wT()
         if self.bf16 and self._wT_stale:          # an optimiser step without a new batch since (tests): refresh here
             self.refresh_weights_bf16(transposes_only=True)
@@ -1127,8 +1125,8 @@ class TrainEngine:
             self.grad16, self.g16, self._g16_last = direct['comm'], direct['views'], True
         # the decoder's output-bias gradient (column sums of d x_hat) rides in the first BatchNorm-backward launch as extra
         # workgroups (47 short ones beside 375 long ones) instead of being a launch of its own at the head of the backward
-        # pass; with an overlapped gradient exchange the region must be complete before it is announced: own launch
-        ride = allreduce is None and os.environ.get('JAMIE_NO_CS_RIDE') != '1'
+        # pass (with a gradient exchange too: the biases live in region `rep`, which is announced last)
+        ride = os.environ.get('JAMIE_NO_CS_RIDE') != '1'
         cs_items = [(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))]
         if not ride:
             nv.colsum_group(cs_items, acc)
@@ -1187,6 +1185,7 @@ class TrainEngine:
         ride = (self._fuse_now and self.bf16 and self._dw_cfg('enc0') == BF16_CFG_DW and os.environ.get('JAMIE_NO_RANGE_RIDE') != '1')
         self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else dr.get('enc0'))
         self._ranges_done = ride
+        self._region(allreduce, 'rep')        # (adjacent to enc0: an all-reduce exchange merges the two into one message)
         self._region(allreduce, 'enc0')
         self._norm_ready = self._fuse_now
         self.m.num_batches_tracked += 1
@@ -1267,7 +1266,7 @@ class TrainEngine:
                                                            self.exp_avg_sq[lo:hi], norm, self.hyper,
                                                            self.state, self.wbf_flat[lo:hi] if self.bf16 else None))
                 if self.bf16:
-                    self.refresh_weights_bf16(transposes_only=True, lins=names)
+                    self.refresh_weights_bf16(transposes_only=True, lins=self.PIPE_LINS[g])
                 ev = self._ev_params[g]
                 self._both(lambda ev=ev: ev.record(opt))
         finally:

@@ -32,12 +32,16 @@ def _align4(n):
 class ParamLayout:
     """Offsets of every parameter tensor inside the flat buffer.
 
-    Layer-major; inside a layer, modality by modality (d = input_dim[i], L = output_dim):
+    Tensors (d = input_dim[i], L = output_dim), modality by modality inside a layer:
       enc0: W [2d,d] b [2d] bn0.g bn0.b [2d] | enc1: W [d,2d] b [d] bn1.g bn1.b [d] |
-      head: sigma [M], then W [2L,d] (rows 0..L-1 = fc_mus, L..2L-1 = fc_vars) b [2L] |
+      head: W [2L,d] (rows 0..L-1 = fc_mus, L..2L-1 = fc_vars) b [2L] | sigma [M] |
       dec0: W [d,L] b [d] bn2.g bn2.b [d] | dec1: W [2d,d] b [2d] bn3.g bn3.b [2d] | dec2: W [d,2d] b [d]
     The two heads of a modality are adjacent so that mu and logvar come out of one GEMM.
+    Memory: region `rep` (all the small tensors + head + dec0), then the W matrices of enc0 | enc1 | dec1 | dec2.
     """
+
+    BIG_LAYERS = ('enc0', 'enc1', 'dec1', 'dec2')
+    SHARD_ALIGN = 512            # elements: 8-element (16 B as bf16) pieces for every world size that divides 64
 
     def __init__(self, input_dim, output_dim, real_dim=None):
         """`input_dim`: the feature counts the kernels see; `real_dim` (default: the same) the model's own feature counts
@@ -59,23 +63,46 @@ class ParamLayout:
             self.real[name] = tuple(shape if real_shape is None else real_shape)
             off += _align4(n)
 
-        # layer-major order: the backward pass finishes layers from the END of the buffer towards the start,
-        # so the data-parallel all-reduce can start on contiguous tail regions while earlier layers are still
-        # in their backward GEMMs (`regions`, in backward completion order).
+        # Memory order: one region `rep` with everything small (sigma, every bias and BatchNorm affine pair, and the two skinny
+        # layers whole: heads and decoder layer 0 -- 1 % of the parameters, read in fp32 by the latent kernels), then the four
+        # large weight-matrix regions layer by layer in FORWARD order.  The backward pass completes the large regions from
+        # the END of the buffer towards the start, so a data-parallel exchange can start on contiguous tail regions while the
+        # earlier layers are still in their backward GEMMs (`regions`); `rep` is complete last (with enc0) and adjacent to it.
+        # A large region holds nothing but its weight matrices and is a multiple of SHARD_ALIGN elements long: under a
+        # sharded optimiser (distributed.ShardedGradExchange) it is cut into world-size equal, 16-byte aligned pieces, while
+        # `rep` stays replicated on every rank.
         layers = [('enc0', lambda d: [('enc0.W', (2 * d, d)), ('enc0.b', (2 * d,)), ('bn0.g', (2 * d,)), ('bn0.b', (2 * d,))]),
                   ('enc1', lambda d: [('enc1.W', (d, 2 * d)), ('enc1.b', (d,)), ('bn1.g', (d,)), ('bn1.b', (d,))]),
                   ('head', lambda d: [('head.W', (2 * L, d)), ('head.b', (2 * L,))]),
                   ('dec0', lambda d: [('dec0.W', (d, L)), ('dec0.b', (d,)), ('bn2.g', (d,)), ('bn2.b', (d,))]),
                   ('dec1', lambda d: [('dec1.W', (2 * d, d)), ('dec1.b', (2 * d,)), ('bn3.g', (2 * d,)), ('bn3.b', (2 * d,))]),
                   ('dec2', lambda d: [('dec2.W', (d, 2 * d)), ('dec2.b', (d,))])]
+
+        def align_region():
+            nonlocal off
+            off = (off + self.SHARD_ALIGN - 1) // self.SHARD_ALIGN * self.SHARD_ALIGN
+
+        def is_big(lname, nm):
+            return lname in self.BIG_LAYERS and nm.endswith('.W')
         self.regions = {}
+        start = off
+        add('sigma', (self.M,))               # sigma's gradient is produced with the heads' (latent backward)
         for lname, spec in layers:
-            start = off
-            if lname == 'head':
-                add('sigma', (self.M,))       # sigma's gradient is produced with the heads' (latent backward)
             for i, d in enumerate(input_dim):
                 for (nm, shape), (_, rshape) in zip(spec(d), spec(self.real_dim[i])):
-                    add(f'm{i}.{nm}', shape, rshape)
+                    if not is_big(lname, nm):
+                        add(f'm{i}.{nm}', shape, rshape)
+        align_region()
+        self.regions['rep'] = (start, off)
+        for lname, spec in layers:
+            if lname not in self.BIG_LAYERS:
+                continue
+            start = off
+            for i, d in enumerate(input_dim):
+                for (nm, shape), (_, rshape) in zip(spec(d), spec(self.real_dim[i])):
+                    if is_big(lname, nm):
+                        add(f'm{i}.{nm}', shape, rshape)
+            align_region()
             self.regions[lname] = (start, off)
         self.total = off
         # BN running statistics (not optimised): separate flat buffer
