@@ -80,29 +80,70 @@ def synth_shard(n_cells, lo, hi, dims, rank, world, device):
     return out
 
 
-def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_f32):
-    """Exposure model of the gradient exchange for `world` GPUs from ONE GPU's timeline (bench.py --dry-run-world): the
-    messages (bytes, time after the step's first launch at which the backward pass announces them: HIP events of the dry
-    run) go over one wire, in order, at the all-reduce algorithm bandwidth algbw = busbw * n / (2 (n - 1)) for an ASSUMED bus
-    bandwidth (ASSUMED_BUS_GBS; a ring over xGMI is per-link bound: tools/rccl_probe.py measures the real figure); whatever
-    is still on the wire when the backward pass ends is exposed in front of the norm kernel.  Collectives and backward kernels
-    are assumed not to slow each other down (they will, somewhat: both use HBM).  Returns the block printed as `dp_model`."""
-    algbw = ASSUMED_BUS_GBS * world / (2.0 * (world - 1))
-    msgs = [(b, t) for k, b, t in trace_ms if k == 'message']
-    fin = [t for k, b, t in trace_ms if k == 'finish']
-    bwd_end = fin[0] if fin else max(t for _, t in msgs)
-    out = {'world': world, 'assumed_bus_bandwidth_GBps': ASSUMED_BUS_GBS, 'algorithm_bandwidth_GBps': algbw,
-           'messages': [{'bytes': int(b), 'announced_us': 1e3 * t} for b, t in msgs],
-           'backward_end_us': 1e3 * bwd_end, 'step_us_dry_run': 1e3 * step_ms_dry, 'step_us_one_gpu': 1e3 * step_ms_one}
-    for name, scale in (('as_run', 1.0), ('fp32_messages' if msg_scale_f32 == 2.0 else 'bf16_messages', msg_scale_f32)):
-        wire = 0.0
-        for b, t in msgs:
-            wire = max(wire, t) + 1e3 * (b * scale / 1e9) / algbw        # ms
-        exposed = max(0.0, wire - bwd_end)
-        pred = step_ms_dry + exposed
-        out[name] = {'message_bytes_total': int(sum(b for b, _ in msgs) * scale), 'exposed_us': 1e3 * exposed,
+ASSUMED_COLLECTIVE_LATENCY_US = 20.0   # per collective, on top of bytes / bandwidth (stated, not measured)
+
+
+def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_other, other_name):
+    """Exposure model of the data-parallel exchange for `world` GPUs from ONE GPU's timeline (bench.py --dry-run-world).
+    The dry run's HIP events give, relative to the step's first launch, when the backward pass announces each gradient message,
+    where the step starts waiting for them (`finish`), when the updated weights' all-gathers are issued (sharded optimiser) and
+    where the NEXT forward pass needs each gathered region (`wait:<layer>`).  All collectives go over ONE wire, in issue order,
+    each taking ASSUMED_COLLECTIVE_LATENCY_US + bytes / algbw with, for an ASSUMED bus bandwidth ASSUMED_BUS_GBS (a ring over
+    xGMI is per-link bound: tools/rccl_probe.py measures the real figure): all-reduce algbw = busbw n / (2 (n - 1)),
+    reduce-scatter and all-gather algbw = busbw n / (n - 1).  A few steady-state steps are simulated: the main stream stalls where
+    it waits for a collective that has not finished, and the stall pushes everything behind it.  Collectives and kernels are
+    assumed not to slow each other down (they will, somewhat: both use HBM).  Returns the block printed as `dp_model`."""
+    n = world
+    bw_ar = ASSUMED_BUS_GBS * n / (2.0 * (n - 1))
+    bw_half = ASSUMED_BUS_GBS * n / (n - 1.0)
+    lat = ASSUMED_COLLECTIVE_LATENCY_US * 1e-3            # ms
+    ev = sorted(trace_ms, key=lambda e: e[2])
+    sharded = any(k == 'reduce_scatter' for k, _, _ in ev)
+    out = {'world': n, 'optimizer': 'sharded' if sharded else 'replicated', 'assumed_bus_bandwidth_GBps': ASSUMED_BUS_GBS,
+           'assumed_collective_latency_us': ASSUMED_COLLECTIVE_LATENCY_US,
+           'all_reduce_algorithm_bandwidth_GBps': bw_ar, 'reduce_scatter_all_gather_algorithm_bandwidth_GBps': bw_half,
+           'events': [{'kind': k, 'bytes': int(b), 'at_us': 1e3 * t} for k, b, t in ev],
+           'step_us_dry_run': 1e3 * step_ms_dry, 'step_us_one_gpu': 1e3 * step_ms_one}
+
+    def simulate(scale):
+        wire, t0, gathered, dur, stalls = 0.0, 0.0, {}, step_ms_dry, {}
+        for it in range(8):
+            shift, order = 0.0, []
+            stalls = {'forward_waits_us': 0.0, 'gradient_wait_us': 0.0, 'norm_all_reduce_us': 0.0}
+            for k, b, t in ev:
+                now = t0 + t + shift
+                if k.startswith('wait:'):
+                    end = gathered.get(k[5:])
+                    if end is not None and end > now:
+                        shift += end - now
+                        stalls['forward_waits_us'] += 1e3 * (end - now)
+                elif k in ('reduce_scatter', 'message'):
+                    wire = max(wire, now) + lat + (b * scale / 1e6) / (bw_half if k == 'reduce_scatter' else bw_ar)
+                elif k == 'finish':
+                    if wire > now:
+                        shift += wire - now
+                        stalls['gradient_wait_us'] += 1e3 * (wire - now)
+                    if sharded:                 # the partial sums of squares: one small all-reduce the main stream waits for
+                        shift += lat
+                        stalls['norm_all_reduce_us'] += 1e3 * lat
+                        wire = max(wire, t0 + t + shift)
+                elif k == 'all_gather':
+                    wire = max(wire, now) + lat + (b / 1e6) / bw_half
+                    order.append(wire)
+            names = [k[5:] for k, _, _ in ev if k.startswith('wait:')]
+            gathered = dict(zip(names, order))
+            dur = step_ms_dry + shift
+            t0 += dur
+        return dur, stalls
+
+    grad_bytes = sum(b for k, b, _ in ev if k in ('reduce_scatter', 'message'))
+    for name, scale in (('as_run', 1.0), (other_name, msg_scale_other)):
+        pred, stalls = simulate(scale)
+        out[name] = {'gradient_message_bytes': int(grad_bytes * scale),
+                     'weight_all_gather_bytes': int(sum(b for k, b, _ in ev if k == 'all_gather')),
+                     'exposed_us': 1e3 * (pred - step_ms_dry), 'stalls': stalls,
                      'predicted_step_us': 1e3 * pred, 'predicted_scaling_efficiency': step_ms_one / pred,
-                     'predicted_speedup': world * step_ms_one / pred}
+                     'predicted_speedup': n * step_ms_one / pred}
     return out
 
 
@@ -293,6 +334,10 @@ def main():
     ap.add_argument('--dry-run-world', type=int, default=0,
                     help='one GPU: run the per-rank step of an N-rank job with the collectives skipped (message casts, side stream, '
                          'one-pass norm of the "reduced" gradient): the compute-side cost of data parallelism; NOT a benchmark line')
+    ap.add_argument('--dp-optimizer', default='auto', choices=['auto', 'sharded', 'replicated'],
+                    help='N > 1: sharded = reduce-scatter the large gradient regions, clip + Adam over 1/N of the parameters per rank, '
+                         'all-gather the updated weights under the next forward pass (distributed.ShardedGradExchange); replicated = '
+                         'all-reduce + the full update on every rank; auto = sharded where the world size divides the regions')
     ap.add_argument('--no-f32-record', action='store_true', help='skip the short fp32 (parity configuration) leg')
     ap.add_argument('--pipeline', action='store_true',
                     help='clip + Adam on a second stream under the next forward pass (+2-3 %; default: main stream, so '
@@ -345,7 +390,22 @@ def main():
                       dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr, grad_bf16=False if args.grad_fp32 else None)
     data = eng.pad_cells(data_real)
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
-    allreduce = jd.OverlappedGradAllReduce(comm_dtype=comm, dry_run_world=args.dry_run_world) if (world > 1 or args.dry_run_world > 1) else None
+    n_dp = max(world, args.dry_run_world)
+
+    def make_exchange(eng_, comm_dtype, mode):
+        """(exchange, 'sharded' | 'replicated' | None) for engine `eng_`."""
+        if n_dp <= 1:
+            return None, None
+        if mode != 'replicated':
+            try:
+                ex = jd.ShardedGradExchange(comm_dtype=comm_dtype, dry_run_world=args.dry_run_world)
+                eng_.enable_sharded_optimizer(ex)
+                return ex, 'sharded'
+            except ValueError as err:
+                if mode == 'sharded':
+                    raise SystemExit(f'--dp-optimizer sharded: {err}')
+        return jd.OverlappedGradAllReduce(comm_dtype=comm_dtype, dry_run_world=args.dry_run_world), 'replicated'
+    allreduce, dp_opt = make_exchange(eng, comm, 'replicated' if (args.pipeline or args.side_transposes or args.transposed_weight_copies) else args.dp_optimizer)
     idx = torch.zeros(B, dtype=torch.int32, device=dev)      # 'diag' sampling: same rows in both modalities
     # the reference's quirk `replace = min(features) < batch_size` (jamie.py:553) belongs to its two-modality loop; the
     # 3-modality generalisation always samples without replacement (duplicates would need a non-identity corr)
@@ -402,6 +462,9 @@ def main():
         for _ in range(20):
             step()
         barrier()
+    if dp_opt == 'sharded':           # (outside the timed region: the replicated buffers current again, no all-gather left in flight)
+        eng.flush()
+        barrier()
     ls, total, _ = eng.read_losses()
     if not np.isfinite(total):
         raise SystemExit('non-finite loss in benchmark')
@@ -434,7 +497,8 @@ def main():
             e1.run_plan(p1)
         torch.cuda.synchronize()
         one_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-        dp = dp_model(med, 1e3 * dt / args.steps, one_ms, args.dry_run_world, 2.0 if comm is not None else 0.5)
+        dp = dp_model(med, 1e3 * dt / args.steps, one_ms, args.dry_run_world, 2.0 if comm is not None else 0.5,
+                      'fp32_messages' if comm is not None else 'bf16_messages')
         del p1, e1, m1
 
     if rank == 0:
@@ -471,11 +535,14 @@ def main():
         else:
             n_par = model.layout.total
             adam_launches = len(eng.PIPE_GROUPS) if eng.pipeline else 1
+            if dp_opt == 'sharded':          # (the timed launch is the one over this rank's packed shard; `rep` has its own small launch)
+                n_par = eng._zs['S']
             adam_bytes = eng.adam_bytes_per_param() * n_par / adam_launches
             achieved = adam_bytes / (adam_ms * 1e-3) / 1e9
-            step_bytes = 44.0 * n_par
+            step_bytes = 44.0 * model.layout.total
             roof = {'bound': 'hbm', 'kernel': f'clip_adam_kernel (global-norm clip + Adam on the flat fp32 buffers; {adam_launches} launch(es)/step'
-                                       + (', on the optimiser stream under the next forward pass)' if eng.pipeline else ')'),
+                                       + (', on the optimiser stream under the next forward pass)' if eng.pipeline else
+                                          (f'; sharded optimiser: this launch covers 1/{n_dp} of the large weight regions)' if dp_opt == 'sharded' else ')')),
                     'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS,
                     'avg_launch_ms': adam_ms, 'bytes_per_launch': adam_bytes,
                     'bytes_per_parameter': eng.adam_bytes_per_param(), 'traffic': traffic, 'traffic_source': traffic_source,
@@ -493,6 +560,7 @@ def main():
                                     + ('; the noise term drawn on the device (torch generator per rank)' if (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1' else ''),
                        'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
                        'parallelism': f'dp{world}', 'grad_allreduce': ('none' if world == 1 else ('bf16' if comm is not None else 'f32')),
+                       'dp_optimizer': dp_opt,
                        'parameters': model.num_parameters(),
                        'flop_per_cell': flops_per_cell(dims, L)},
             'roofline': roof,
@@ -506,34 +574,42 @@ def main():
         if world > 1:
             out['rccl'] = rccl_record(world, log_dir) if log_dir else {'backend': torch.distributed.get_backend(),
                                                                         'world': torch.distributed.get_world_size(), 'algo': None}
-    if world > 1 and args.dtype == 'bf16' and comm is not None and args.grad_comm == 'auto' and not args.no_f32_record:
-        # N > 1, bf16 compute: the headline exchanges bf16 messages (summed in bf16 by the collective); the SAME job with fp32
-        # messages (exact sums, twice the bytes) is timed right behind it, on every rank (a step is a collective), so that one
-        # invocation reports both
+    if world > 1 and not args.no_f32_record:
+        # N > 1: the same job in its other data-parallel arrangements, timed right behind the headline on every rank (a step is
+        # a collective), so that one invocation reports them all:
+        #   grad_comm_f32       (bf16 compute, bf16 messages in the headline) fp32 gradient messages: exact sums, twice the bytes
+        #   replicated_optimizer (sharded optimiser in the headline) all-reduce + the full clip + Adam on every rank
+        legs = []
+        if args.dtype == 'bf16' and comm is not None and args.grad_comm == 'auto':
+            legs.append(('grad_comm_f32', None, args.dp_optimizer, 'the same job with fp32 gradient messages (exact sums)'))
+        if dp_opt == 'sharded':
+            legs.append(('replicated_optimizer', comm, 'replicated', 'the same job with an all-reduce and the full update on every rank'))
         del plan
-        torch.manual_seed(666)
-        m2 = edModelVar(dims, L, device=dev, pad_features=pad)
-        jd.broadcast_flat(m2.flat)
-        e2 = TrainEngine(m2, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype)
-        e2.set_kl_anneal(0.5)
-        ar2 = jd.OverlappedGradAllReduce(comm_dtype=None)
-        idx2 = torch.zeros(B, dtype=torch.int32, device=dev)
-        p2 = e2.make_plan(data, idx2, hi - lo, rep, ar2)
-        n2 = max(10, args.steps // 4)
-        for _ in range(min(args.warmup, 10)):
-            e2.run_plan(p2)
-        barrier()
-        t2 = time.perf_counter()
-        for _ in range(n2):
-            e2.run_plan(p2)
-        barrier()
-        d2 = time.perf_counter() - t2
-        tt = torch.tensor([d2], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        if rank == 0:
-            out['grad_comm_f32'] = {'value': world * B * n2 / float(tt.item()), 'unit': 'cells/s', 'ms_per_step': 1e3 * float(tt.item()) / n2,
-                                    'steps': n2, 'grad_allreduce': 'f32', 'note': 'the same job with fp32 gradient messages (exact sums)'}
-        del p2, e2, m2
+        for key, comm2, mode2, note in legs:
+            torch.manual_seed(666)
+            m2 = edModelVar(dims, L, device=dev, pad_features=pad)
+            jd.broadcast_flat(m2.flat)
+            e2 = TrainEngine(m2, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype)
+            e2.set_kl_anneal(0.5)
+            ar2, opt2 = make_exchange(e2, comm2, mode2)
+            idx2 = torch.zeros(B, dtype=torch.int32, device=dev)
+            p2 = e2.make_plan(data, idx2, hi - lo, rep, ar2)
+            n2 = max(10, args.steps // 4)
+            for _ in range(min(args.warmup, 10)):
+                e2.run_plan(p2)
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(n2):
+                e2.run_plan(p2)
+            barrier()
+            d2 = time.perf_counter() - t2
+            tt = torch.tensor([d2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            if rank == 0:
+                out[key] = {'value': world * B * n2 / float(tt.item()), 'unit': 'cells/s', 'ms_per_step': 1e3 * float(tt.item()) / n2,
+                            'steps': n2, 'grad_allreduce': 'f32' if comm2 is None else 'bf16', 'dp_optimizer': opt2, 'note': note}
+            e2.flush()
+            del p2, e2, m2, ar2
     if world == 1:
         # free the timed engine's buffers before the side legs
         del plan

@@ -130,20 +130,19 @@ class OverlappedGradAllReduce:
             self._issue(*self.pending)
             self.pending = None
 
+    def _collective(self, buf, lo, hi):
+        """The collective of one message (`buf` = the message bytes of gradient range [lo, hi)); None in a dry run."""
+        return None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _issue(self, flat, lo, hi, precast=False):
         if self.trace is not None and flat.is_cuda:
             from . import _native as nv
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(nv.current_stream())
-            self.trace.append(('message', (hi - lo) * (flat.element_size() if self.comm_dtype is None else 2), ev))
-        if self.comm_dtype is not None and precast:
-            buf = self.message_buffer(flat)[lo:hi]
-            self.works.append((None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
-                               None, None, None))
-            return
-        if self.comm_dtype is None:
-            self.works.append((None if self.dry else dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                                     async_op=True), None, None, None))
+            self.trace.append((self._kind(lo, hi), (hi - lo) * (flat.element_size() if self.comm_dtype is None else 2), ev))
+        if self.comm_dtype is None or precast:
+            buf = (flat if self.comm_dtype is None else self.message_buffer(flat))[lo:hi]
+            self.works.append((self._collective(buf, lo, hi), None, None, None))
             return
         buf = self.message_buffer(flat)[lo:hi]
         if flat.is_cuda:
@@ -162,11 +161,17 @@ class OverlappedGradAllReduce:
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 cast.run(self.stream)                     # fp32 region -> bf16 message buffer (HIP launch, no ATen op)
-                work = None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = self._collective(buf, lo, hi)
         else:
             buf.copy_(flat[lo:hi])
-            work = None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = self._collective(buf, lo, hi)
         self.works.append((work, flat, lo, hi))
+
+    def _kind(self, lo, hi):
+        return 'message'
+
+    def _copies_back(self, lo, hi):
+        return True
 
     def finish(self, copy_back=True):
         """Wait for every message.  With low-precision messages the reduced gradient is cast back into the fp32 buffer,
@@ -185,13 +190,108 @@ class OverlappedGradAllReduce:
                 w.wait()
             elif self.stream is not None:       # (dry run: what work.wait() does for a device collective)
                 torch.cuda.current_stream().wait_stream(self.stream)
-            if flat is not None and copy_back:
+            if flat is not None and copy_back and self._copies_back(lo, hi):
                 flat[lo:hi].copy_(self.comm[lo:hi])
         self.works = []
 
     def __call__(self, flat):          # non-overlapped use
         self.region_done(flat, 0, flat.numel())
         self.finish()
+
+
+class ShardedGradExchange(OverlappedGradAllReduce):
+    """Data parallel with a SHARDED optimiser (the ZeRO stage-1 arrangement): clip + Adam is the one kernel of the step that is
+    bound by HBM bytes per PARAMETER (28 B each, 29 % of the one-GPU step at config 2), and with replicated parameters every
+    rank repeats it in full.  Here each of the four large weight regions (model.ParamLayout: 99 % of the parameters) is cut into
+    `world` equal pieces and rank r owns piece r of every region -- its fp32 master weights and Adam moments live in packed
+    shard buffers (TrainEngine.enable_sharded_optimizer) -- so that
+
+      * the gradient of a large region is REDUCE-SCATTERED as the backward pass completes it (half the wire time of the
+        all-reduce it replaces; rank r receives the sum of piece r into its packed gradient shard),
+      * the small region `rep` (biases, BatchNorm affine pairs, sigma, the skinny head / latent layers) is all-reduced and
+        updated by every rank, as before,
+      * the squared norm of the reduced gradient = sum over ranks of (own pieces) + (rep): one all-reduce of the partial sums,
+      * clip + Adam runs over the packed shard: 1 / world of the bytes,
+      * the updated weights (bf16 copy in bf16 compute mode, fp32 otherwise) are ALL-GATHERED region by region in FORWARD
+        order while the next step's sampler, gather and first layers already run; a layer's product waits for its own region.
+
+    The wire carries the same bytes per step as the all-reduce (reduce-scatter + all-gather = all-reduce), but the second half
+    moves from the end of the backward pass, where nothing can overlap it, to the next forward pass.  Every rank applies the
+    same update to `rep` and receives the same gathered bytes, so the replicas stay bit-identical.  The fp32 master copy of
+    the large regions is only current on its owner in bf16 mode: TrainEngine.gather_sharded_state() before anything other
+    than the next training step reads `model.flat` (evaluation, checkpoints)."""
+
+    def __init__(self, group=None, comm_dtype=None, dry_run_world=0, dry_run_rank=0):
+        super().__init__(group, min_bytes=1 << 62, comm_dtype=comm_dtype, dry_run_world=dry_run_world)
+        self.rank = int(dry_run_rank) if self.dry or not dist.is_initialized() else dist.get_rank(group)
+        self.spans = {}              # (lo, hi) of a sharded region -> this rank's packed gradient piece (length (hi - lo) / world)
+        self.gathers = {}            # layer name -> pending all-gather of its updated weights
+
+    def set_shards(self, spans):
+        """`spans` = [(lo, hi, dst)]: gradient range [lo, hi) is reduce-scattered, this rank's piece lands in `dst`."""
+        for lo, hi, dst in spans:
+            if (hi - lo) % self.world or dst.numel() != (hi - lo) // self.world:
+                raise ValueError(f'sharded region [{lo}, {hi}) does not split into {self.world} pieces of {dst.numel()}')
+        self.spans = {(int(lo), int(hi)): dst for lo, hi, dst in spans}
+
+    def region_done(self, flat, lo, hi, precast=False):
+        if self.world == 1:
+            return
+        if (lo, hi) in self.spans:               # a sharded region is one message, never merged with its neighbours
+            if self.pending is not None:
+                self._issue(*self.pending)
+                self.pending = None
+            self._issue(flat, lo, hi, bool(precast))
+            return
+        super().region_done(flat, lo, hi, precast)
+
+    def _kind(self, lo, hi):
+        return 'reduce_scatter' if (lo, hi) in self.spans else 'message'
+
+    def _copies_back(self, lo, hi):
+        return (lo, hi) not in self.spans
+
+    def _collective(self, buf, lo, hi):
+        dst = self.spans.get((lo, hi))
+        if dst is None:
+            return super()._collective(buf, lo, hi)
+        if self.dry:      # (what the device does besides the wire: this rank's piece arrives in the packed shard)
+            s = dst.numel()
+            dst.copy_(buf[self.rank * s:(self.rank + 1) * s])
+            return None
+        return dist.reduce_scatter_tensor(dst, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def sum_partials(self, t):
+        """In-place sum over the ranks of the partial sums of squares of the pieces each rank owns."""
+        if not self.dry and self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def gather(self, name, out, piece):
+        """Start the all-gather of region `name`: `piece` (this rank's updated piece) -> `out` (the whole region)."""
+        if self.trace is not None and out.is_cuda:
+            from . import _native as nv
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(nv.current_stream())
+            self.trace.append(('all_gather', out.numel() * out.element_size(), ev))
+        if self.dry:
+            s = piece.numel()
+            out[self.rank * s:(self.rank + 1) * s].copy_(piece)
+            return
+        self.gathers[name] = dist.all_gather_into_tensor(out, piece, group=self.group, async_op=True)
+
+    def wait_gather(self, name):
+        if self.trace is not None and torch.cuda.is_available():
+            from . import _native as nv
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(nv.current_stream())
+            self.trace.append(('wait:' + name, 0, ev))
+        w = self.gathers.pop(name, None)
+        if w is not None:
+            w.wait()
+
+    def wait_all_gathers(self):
+        for name in list(self.gathers):
+            self.wait_gather(name)
 
 
 def broadcast_flat(flat, src=0, group=None):

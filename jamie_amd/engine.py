@@ -378,6 +378,7 @@ class TrainEngine:
         self._timing = None
         self._timing_every, self._timing_step = 1, 0
         self.pipeline = False            # enable_pipeline(): optimiser on its own stream, overlapped with the next forward
+        self._zs = None                  # enable_sharded_optimizer(): packed shard state of a data-parallel run
         self.side_transposes, self._wT_pending, self._wT_stale = False, False, False
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
@@ -431,6 +432,10 @@ class TrainEngine:
         fn()
 
     def _wait_params(self, lin):
+        if self._zs is not None and lin in self._zs['names']:       # sharded optimiser: this layer's all-gathered weights
+            ex = self._zs['ex']
+            self._both(lambda: ex.wait_gather(lin))
+            return
         g = self.PIPE_WAIT.get(lin) if self.pipeline else None
         if g is None:
             return
@@ -443,6 +448,8 @@ class TrainEngine:
 
     def flush(self):
         """Make torch's current stream wait for the optimiser stream (parameters, Adam moments, bf16 copies)."""
+        if self._zs is not None:
+            self.gather_sharded_state()
         if self.pipeline and self._opt_pending:
             for ev in self._ev_params:
                 torch.cuda.current_stream().wait_event(ev)
@@ -451,6 +458,88 @@ class TrainEngine:
         if self.bf16 and self._wT_stale:                 # the skinny weights' transposed copies ride on the next batch launch
             self.refresh_weights_bf16(transposes_only=True)
             self._wT_stale = False
+
+    # ---- data parallel with a sharded optimiser (distributed.ShardedGradExchange) ----
+    def enable_sharded_optimizer(self, ex):
+        """Cut each large weight region into `ex.world` pieces; this rank keeps fp32 master weights, Adam moments, the reduced
+        gradient and (bf16 mode) the bf16 weight copy of piece `ex.rank` of every region in PACKED buffers, so that clip + Adam
+        is one launch over 1 / world of the parameters.  The small region `rep` stays replicated."""
+        lay, n, r = self.m.layout, int(ex.world), int(ex.rank)
+        if n < 2:
+            raise ValueError('a sharded optimiser needs more than one rank')
+        if self.pipeline or self.accumulate or self.side_transposes or any(k.split('.')[1] in lay.BIG_LAYERS for k in self.wT):
+            raise ValueError('sharded optimiser: not with the pipelined optimiser, accumulating gradients or transposed copies '
+                             'of the large weight matrices (bf16 mode with layers under 256 features)')
+        spans, off = [], 0
+        for name in lay.BIG_LAYERS:
+            lo, hi = lay.regions[name]
+            if (hi - lo) % (8 * n):
+                raise ValueError(f'region {name} ({hi - lo} elements) does not split into {n} 16-byte aligned pieces')
+            s = (hi - lo) // n
+            spans.append((name, lo, hi, s, off))
+            off += s
+        bf_msgs = ex.comm_dtype is not None
+        zs = {'ex': ex, 'n': n, 'r': r, 'spans': spans, 'names': tuple(lay.BIG_LAYERS), 'S': off, 'bf_msgs': bf_msgs,
+              'p': self._flat_alloc(off, torch.float32, 0), 'm': self._flat_alloc(off, torch.float32, 1),
+              'v': self._flat_alloc(off, torch.float32, 2),
+              'g': self._flat_alloc(off, torch.bfloat16 if bf_msgs else torch.float32, 3),
+              'w16': self._flat_alloc(off, torch.bfloat16, 4) if self.bf16 else None}
+        for name, lo, hi, s, o in spans:
+            a = lo + r * s
+            zs['p'][o:o + s].copy_(self.m.flat[a:a + s])
+            zs['m'][o:o + s].copy_(self.exp_avg[a:a + s])
+            zs['v'][o:o + s].copy_(self.exp_avg_sq[a:a + s])
+            if self.bf16:
+                zs['w16'][o:o + s].copy_(self.wbf_flat[a:a + s])
+        rlo, rhi = lay.regions['rep']
+        zs['n_a'] = nv.optim_blocks(off)
+        zs['partials'] = torch.zeros(zs['n_a'] + nv.optim_blocks(rhi - rlo), device=self.dev, dtype=torch.float32)
+        if zs['partials'].numel() > nv.load().jamie_max_norm_partials():
+            raise ValueError('sharded optimiser: too many norm partials')
+        ex.set_shards([(lo, hi, zs['g'][o:o + s]) for _, lo, hi, s, o in spans])
+        self._zs = zs
+
+    def _sharded_step(self, sample=None, casts=None):
+        """Norm of the reduced gradient from the pieces + `rep`, clip + Adam over the packed shard and over `rep`, then the
+        all-gathers of the updated weights (waited for layer by layer in the next forward pass: _wait_params)."""
+        zs = self._zs
+        ex, na, part = zs['ex'], zs['n_a'], zs['partials']
+        rlo, rhi = self.m.layout.regions['rep']
+        g_rep = (ex.comm if zs['bf_msgs'] else self.grad)[rlo:rhi]
+        nv.grad_sqnorm(zs['g'], part[:na], self.state)                 # (+ the step counter)
+        nv.grad_sqnorm(g_rep, part[na:], None)
+        self._both(lambda: ex.sum_partials(part[:na]))
+        self._norm_ready = self._g16_pending = self._ranges_done = False
+        self._lat_deferred = None
+        self._launch('adam', lambda: nv.clip_adam(zs['p'], zs['g'], zs['m'], zs['v'], part, self.hyper, self.state,
+                                                   zs['w16'], sample, casts))
+        nv.clip_adam(self.m.flat[rlo:rhi], g_rep, self.exp_avg[rlo:rhi], self.exp_avg_sq[rlo:rhi], part, self.hyper, self.state,
+                     self.wbf_flat[rlo:rhi] if self.bf16 else None)
+        full = self.wbf_flat if self.bf16 else self.m.flat
+        piece = zs['w16'] if self.bf16 else zs['p']
+
+        def gathers():
+            for name, lo, hi, s, o in zs['spans']:                    # forward order
+                ex.gather(name, full[lo:hi], piece[o:o + s])
+        self._both(gathers)
+        zs['stale'] = True
+        if self.bf16:
+            self._wT_stale = True
+
+    def gather_sharded_state(self):
+        """Make the replicated flat buffers current again: wait for the weight all-gathers and all-gather what only the owners
+        hold (the fp32 master weights of the large regions in bf16 mode, the Adam moments)."""
+        zs = self._zs
+        if zs is None or not zs.get('stale'):
+            return
+        ex = zs['ex']
+        ex.wait_all_gathers()
+        for name, lo, hi, s, o in zs['spans']:
+            pairs = [(self.exp_avg, zs['m']), (self.exp_avg_sq, zs['v'])] + ([(self.m.flat, zs['p'])] if self.bf16 else [])
+            for full, piece in pairs:
+                ex.gather(name, full[lo:hi], piece[o:o + s])
+                ex.wait_gather(name)
+        zs['stale'] = False
 
     # ---- host-side knobs (all written into device scalars so the launch sequence is capturable) ----
     def set_kl_anneal(self, anneal):
@@ -1290,6 +1379,16 @@ class TrainEngine:
             self._lat_deferred = lat
         self._backward(lat, noise, allreduce, sample if next_casts else None)
         g16 = None
+        if self._zs is not None:
+            if allreduce is not self._zs['ex']:
+                raise nv.JamieHipError('sharded optimiser: step() must be given the exchange it was enabled with')
+            fn = lambda: allreduce.finish(copy_back=False)     # noqa: E731
+            nv.record_callable(fn)
+            fn()
+            if after_norm is not None:
+                raise nv.JamieHipError('sharded optimiser: no side-stream batch prefetch')
+            self._sharded_step(None if next_casts else sample, next_casts)
+            return
         if allreduce is not None:
             # bf16 messages: the reduced gradient stays in the exchange's bf16 buffer; norm and Adam read it there
             in_place = (getattr(allreduce, 'comm_dtype', None) == torch.bfloat16 and getattr(allreduce, 'world', 1) > 1

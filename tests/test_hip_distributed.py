@@ -77,6 +77,88 @@ torch.distributed.destroy_process_group()
     assert out.count('SAME OK') == 2, out[-2000:]
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16_f32msgs', 'bf16_msgs_direct'])
+def test_sharded_optimizer_matches_replicated_optimizer(tmp_path, mode):
+    """distributed.ShardedGradExchange (reduce-scatter of the large regions, clip + Adam over this rank's packed pieces, all-gather
+    of the updated weights under the next forward pass) against the all-reduce exchange with the full update on every rank:
+    two ranks with DIFFERENT cells, 4 eager steps + 3 replayed plan steps.  The two arrangements sum the same gradients; only the
+    order in which the squared norm is summed differs (pieces + rep against one pass), i.e. the clip coefficient's last bits:
+    after one step (and gather_sharded_state()) parameters and both Adam moments agree to that; after seven, everywhere but on
+    the parameters whose gradient is rounding noise.  The two ranks hold identical parameters throughout."""
+    script = tmp_path / 'sharded.py'
+    script.write_text(f'''
+import sys, torch, numpy as np
+sys.path.insert(0, {ROOT!r})
+from jamie_amd import distributed as jd, _native as nv
+from jamie_amd.engine import TrainEngine
+from jamie_amd.model import edModelVar
+rank, world, local = jd.init_from_env()
+dev = torch.device('cuda', local)
+mode = {mode!r}
+dims, L, B, N = ((264, 136) if mode == 'f32' else (328, 264)), 8, 128, 1024      # (bf16: the large-tile launches, no transposed W)
+g = torch.Generator(device=dev).manual_seed(50 + rank)          # different cells on every rank
+data = [torch.randn(N, d, generator=g, device=dev) for d in dims]
+compute = 'f32' if mode == 'f32' else 'bf16'
+comm = torch.bfloat16 if mode == 'bf16_msgs_direct' else None
+res, first = {{}}, {{}}
+for label in ('replicated', 'sharded'):
+    torch.manual_seed(3)
+    model = edModelVar(dims, L, device=dev)
+    eng = TrainEngine(model, B, seed=11, world_size=world, compute_dtype=compute)
+    if label == 'sharded':
+        ar = jd.ShardedGradExchange(comm_dtype=comm)
+        eng.enable_sharded_optimizer(ar)
+        assert eng._zs['S'] * world == sum(hi - lo for k, (lo, hi) in model.layout.regions.items() if k != 'rep')
+    else:
+        ar = jd.OverlappedGradAllReduce(min_bytes=1 << 16, comm_dtype=comm)
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    for s in range(4):
+        nv.sample_indices(idx, N, 0, False, eng.state, 200)
+        eng.load_batch(data, [idx, idx])
+        eng.step(None, None, None, ar)
+        if s == 0:                      # (a flush in the middle of training: the run goes on from the gathered state)
+            eng.flush()
+            first[label] = (model.flat.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone())
+    assert eng._direct_now == (mode == 'bf16_msgs_direct'), (label, eng._direct_now)
+    plan = eng.make_plan(data, idx, N, False, ar)
+    for s in range(2):
+        eng.run_plan(plan)
+    eng.flush()
+    torch.cuda.synchronize()
+    assert int(eng.state[1].item()) == 7
+    res[label] = (model.flat.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.read_losses()[1])
+    both = [torch.zeros_like(model.flat) for _ in range(world)]
+    torch.distributed.all_gather(both, model.flat)
+    assert torch.equal(both[0], both[1]), (label, float((both[0] - both[1]).abs().max()))
+    if label == 'sharded' and compute == 'bf16':            # the bf16 weight copy every rank multiplies with = the master, rounded
+        lo = model.layout.regions['enc0'][0]
+        assert torch.equal(eng.wbf_flat[lo:], model.flat[lo:].to(torch.bfloat16))
+# after ONE step the two arrangements differ by the clip coefficient's last bits alone
+for k, (a, b) in enumerate(zip(first['replicated'], first['sharded'])):
+    d = (a - b).abs()
+    tol = 2e-9 if k == 0 else 2e-6 * float(a.abs().max())
+    assert float(d.max()) <= tol, ('first step', k, float(d.max()), tol)
+# ... and after seven they still agree except where a gradient is rounding noise anyway (the biases in front of a BatchNorm:
+# Adam's normalised update of pure noise flips sign with the last bit of an activation; bounded by 2 lr per step)
+a, b = res['replicated'][0], res['sharded'][0]
+d = (a - b).abs()
+if mode == 'f32':
+    frac = float((d > 1e-6).float().mean())
+    assert float(d.max()) <= 7 * 2e-3 and frac < 2e-3, (float(d.max()), frac)
+    assert abs(res['replicated'][3] - res['sharded'][3]) <= 1e-4 * abs(res['replicated'][3])
+else:
+    # bf16 products: a last-bit difference in a weight flips bf16 roundings downstream, i.e. the two runs are two samples of the
+    # same bf16 rounding noise (gradients differ by ~2^-9 relative, Adam's normalised update by that times lr per step)
+    frac = float((d > 7 * 1e-3 * 2.0 ** -8 * 4).float().mean())
+    assert float(d.max()) <= 7 * 2e-3 and frac < 5e-2, (float(d.max()), frac)
+    assert abs(res['replicated'][3] - res['sharded'][3]) <= 2e-2 * abs(res['replicated'][3])
+print('SHARDED OK', rank)
+torch.distributed.destroy_process_group()
+''')
+    out = _torchrun(script, 29583)
+    assert out.count('SHARDED OK') == 2, out[-2000:]
+
+
 @pytest.mark.parametrize('variant', ['diag_numpy', 'diag_device_bf16', 'hybrid_sparse'])
 def test_facade_distributed_is_rank_invariant(tmp_path, variant):
     """JAMIE(distributed=True) with two ranks: 255 cells -> shards of 128 and 127 rows, i.e. 2 vs 1 batches of 64 per epoch

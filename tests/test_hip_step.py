@@ -325,6 +325,9 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and 'cpu_baseline' not in out
     assert np.isfinite(out['final_loss'])
+    # the default at N > 1 is the sharded optimiser; the same job with the replicated one is timed behind it
+    assert out['config']['dp_optimizer'] == 'sharded' and out['replicated_optimizer']['dp_optimizer'] == 'replicated'
+    assert out['replicated_optimizer']['value'] > 0
     # bf16 compute at N > 1: the line also carries the same job timed with fp32 gradient messages
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                         '--master-addr', '127.0.0.1', '--master-port', '29578', os.path.join(root, 'bench.py'),
@@ -334,6 +337,8 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
     assert out['dtype'] == 'bf16' and out['config']['grad_allreduce'] == 'bf16'
     assert out['grad_comm_f32']['grad_allreduce'] == 'f32' and out['grad_comm_f32']['value'] > 0
+    # (config 1 in bf16 multiplies with transposed copies of its small weight matrices: the optimiser stays replicated there)
+    assert out['grad_comm_f32']['dp_optimizer'] == out['config']['dp_optimizer'] == 'replicated'
 
 
 def test_bench_config5_path_two_ranks_at_reduced_cells(tmp_path):

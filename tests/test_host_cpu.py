@@ -217,6 +217,42 @@ dist.all_gather(out, p[0])
 assert torch.equal(out[0], out[1])            # identical updates on every rank
 lo, hi = jd.shard_bounds(11, rank, world)
 assert (lo, hi) == ((0, 6) if rank == 0 else (6, 11))
+# ---- sharded optimiser exchange: the large regions are reduce-scattered into this rank's packed pieces, the small region in
+# front of them is all-reduced, updated pieces are all-gathered back (fp32 messages and bf16 messages written by the producer)
+for comm in (None, torch.bfloat16):
+    ex = jd.ShardedGradExchange(comm_dtype=comm)
+    assert ex.world == 2 and ex.rank == rank
+    n = 40 + 64 + 32
+    g = (torch.arange(n, dtype=torch.float32) * 0.25 + rank + 1)
+    mine = g.clone()
+    spans = [(40, 104), (104, 136)]
+    shard = torch.zeros(48, dtype=torch.float32 if comm is None else torch.bfloat16)
+    ex.set_shards([(40, 104, shard[:32]), (104, 136, shard[32:])])
+    if comm is not None:
+        ex.message_buffer(g).copy_(g.to(torch.bfloat16))
+    for lo_, hi_ in ((104, 136), (0, 40), (40, 104)):          # backward order; the small region is announced before the first one
+        ex.region_done(g, lo_, hi_, precast=comm is not None)
+    ex.finish(copy_back=False)
+    both = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(both, mine)
+    total = both[0] + both[1] if comm is None else (both[0].to(torch.bfloat16).float() + both[1].to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    want = torch.cat([total[40 + 32 * rank:40 + 32 * (rank + 1)], total[104 + 16 * rank:104 + 16 * (rank + 1)]])
+    assert torch.equal(shard.float(), want), (comm, shard, want)
+    src = g if comm is None else ex.comm
+    assert torch.equal(src[:40].float(), total[:40])                           # the small region: all-reduced in place
+    part = torch.tensor([float(rank + 1), 10.0 * (rank + 1)])
+    ex.sum_partials(part)
+    assert part.tolist() == [3.0, 30.0]
+    full = torch.full((64,), -1.0)
+    piece = torch.arange(32, dtype=torch.float32) + 100 * rank
+    ex.gather('enc0', full, piece)
+    ex.wait_gather('enc0')
+    assert torch.equal(full, torch.cat([torch.arange(32.0), torch.arange(32.0) + 100])) and not ex.gathers
+    try:
+        ex.set_shards([(0, 41, torch.zeros(20))])
+        raise SystemExit('an odd region must be refused')
+    except ValueError:
+        pass
 dist.destroy_process_group()
 print('OK', rank)
 '''
@@ -237,6 +273,25 @@ def test_dry_run_exchange_issues_no_collective():
     ov.region_done(g, 0, 100, precast=True)
     ov.finish(copy_back=False)
     assert float(ov.comm.abs().sum()) == 0.0 and torch.equal(g, torch.arange(100, dtype=torch.float32))
+
+
+def test_dry_run_sharded_exchange_moves_this_ranks_pieces():
+    """ShardedGradExchange(dry_run_world=N, dry_run_rank=r) in one process: no collective, but the data movement a rank sees
+    besides the wire -- its piece of a reduce-scattered region lands in the packed shard, its updated piece in the full buffer."""
+    from jamie_amd import distributed as jd
+    ex = jd.ShardedGradExchange(dry_run_world=4, dry_run_rank=2)
+    assert ex.world == 4 and ex.rank == 2 and ex.dry
+    g = torch.arange(96, dtype=torch.float32)
+    shard = torch.zeros(16)
+    ex.set_shards([(32, 96, shard)])
+    ex.region_done(g, 32, 96)
+    ex.region_done(g, 0, 32)
+    ex.finish(copy_back=False)
+    assert torch.equal(shard, g[32 + 32:32 + 48]) and not ex.works and ex.pending is None
+    full = torch.zeros(64)
+    ex.gather('enc0', full, shard + 1)
+    ex.wait_gather('enc0')
+    assert torch.equal(full[32:48], shard + 1) and float(full[:32].abs().sum() + full[48:].abs().sum()) == 0.0
 
 
 def test_gradient_exchange_world2_gloo(tmp_path):
