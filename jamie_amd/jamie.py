@@ -53,6 +53,11 @@ class JAMIE:
       compute_dtype 'f32' (default: exact-fp32 MFMA, the parity configuration) or 'bf16' (bf16 MFMA GEMMs with
                    fp32 accumulation, master weights, optimiser, BatchNorm and losses; feature counts, latent
                    size and batch size must be multiples of 8)
+      dp_optimizer 'auto' (default), 'sharded' or 'replicated' (distributed runs): sharded = the large gradient regions are
+                   reduce-scattered, every rank runs clip + Adam over 1/world of the large weight matrices and the updated
+                   weights are all-gathered under the next forward pass (distributed.ShardedGradExchange); replicated =
+                   all-reduce and the full update on every rank; auto = sharded where it applies (batch_step=True, a world
+                   size that divides the regions, no transposed weight copies), else replicated
       grad_comm_dtype 'auto' (default: the compute dtype), 'f32' or 'bf16': precision of the gradient all-reduce
                    messages when distributed (bf16 halves the 4 P bytes exchanged per step)
     """
@@ -62,7 +67,7 @@ class JAMIE:
                  dropout=None, pca_dim=2 * [512], batch_step=True, use_f_tilde=True, use_early_stop=True,
                  min_epochs=2500, min_increment=1e-8, max_steps_without_increment=500, debug=False,
                  log_debug=100, record_loss=True, enable_memory_logging=False, device='cuda',
-                 sampler='auto', distributed=False, compute_dtype='f32', grad_comm_dtype='auto',
+                 sampler='auto', distributed=False, compute_dtype='f32', grad_comm_dtype='auto', dp_optimizer='auto',
                  preprocess='host', checkpoint_path=None, checkpoint_every=0, **kwargs):
         self.match_result = match_result
         self.PF_Ratio = PF_Ratio
@@ -103,6 +108,9 @@ class JAMIE:
         self._resume_from = None
         if grad_comm_dtype not in ('auto', 'f32', 'bf16'):
             raise ValueError("grad_comm_dtype must be 'auto', 'f32' or 'bf16'")
+        if dp_optimizer not in ('auto', 'sharded', 'replicated'):
+            raise ValueError("dp_optimizer must be 'auto', 'sharded' or 'replicated'")
+        self.dp_optimizer = dp_optimizer
         self.grad_comm_dtype = compute_dtype if grad_comm_dtype == 'auto' else grad_comm_dtype
         # UnionCom attributes (reference jamie.py:99-111 defaults, then unioncom 0.4.0's)
         defaults = {'project_mode': 'jamie', 'log_pd': 500, 'lr': 1e-3, 'epoch_DNN': 10000, 'log_DNN': 500,
@@ -409,6 +417,15 @@ class JAMIE:
         if self._resume_from is not None:
             start_epoch, best_running_loss, streak = self._load_checkpoint(self._resume_from, eng)
             self._resume_from = None
+        if allreduce is not None and world > 1 and self.dp_optimizer != 'replicated' and self.batch_step:
+            # (after a resume: the packed pieces are cut from the restored parameters and moments)
+            try:
+                ex = jd.ShardedGradExchange(comm_dtype=allreduce.comm_dtype)
+                eng.enable_sharded_optimizer(ex)
+                allreduce = ex
+            except ValueError:
+                if self.dp_optimizer == 'sharded':
+                    raise
         timer.log('Setup')
         n_steps = start_epoch * len_dataloader
         if self._noise_source is not None and (use_plan or plan_hybrid):
@@ -526,10 +543,12 @@ class JAMIE:
                 if streak >= self.max_steps_without_increment and self.use_early_stop:
                     break
             if self.checkpoint_every and self.checkpoint_path and (epoch + 1) % self.checkpoint_every == 0:
+                eng.flush()                      # (every rank: a sharded optimiser gathers its pieces with collectives)
                 if world > 1:
                     jd.average_(self.model.bn_flat)
                 if rank == 0:
                     self.save_checkpoint(self.checkpoint_path, epoch + 1, best_running_loss, streak)
+        eng.flush()
         if world > 1:
             # BatchNorm running statistics are per-rank during training (no SyncBN: one collective per step); the model
             # that is evaluated / saved carries their average, so every rank returns the same embeddings
@@ -587,7 +606,7 @@ class JAMIE:
         device step / RNG counters, the host sampler's RNG, the early-stop bookkeeping and the loss history."""
         eng, m = self.engine, self.model
         eng.flush()
-        torch.save({'format': 'jamie_amd.ckpt.v1', 'epoch': int(next_epoch), 'input_dim': list(m.input_dim),
+        torch.save({'format': 'jamie_amd.ckpt.v2', 'epoch': int(next_epoch), 'input_dim': list(m.input_dim),
                     'output_dim': m.output_dim, 'dropout': m.dropout, 'batch_size': eng.B,
                     'compute_dtype': eng.compute_dtype,
                     'state_dict': {k: v.cpu() for k, v in m.state_dict().items()},
@@ -600,7 +619,7 @@ class JAMIE:
     def _load_checkpoint(self, f, eng):
         ck = torch.load(f, weights_only=False)
         m = self.model
-        if ck.get('format') != 'jamie_amd.ckpt.v1':
+        if ck.get('format') != 'jamie_amd.ckpt.v2':
             raise ValueError(f'{f}: not a jamie_amd training checkpoint')
         if list(ck['input_dim']) != list(m.input_dim) or ck['output_dim'] != m.output_dim or ck['batch_size'] != eng.B \
                 or ck['compute_dtype'] != eng.compute_dtype:

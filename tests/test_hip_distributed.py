@@ -198,7 +198,10 @@ sig = torch.cat([jm.model.flat, jm.model.bn_flat, torch.from_numpy(np.concatenat
 others = [torch.zeros_like(sig) for _ in range(world)]
 torch.distributed.all_gather(others, sig)
 assert torch.equal(others[0], others[1]), float((others[0] - others[1]).abs().max())
-print('FACADE OK', rank, epochs, jm.sampling_method)
+opt = 'sharded' if jm.engine._zs is not None else 'replicated'
+# (dp_optimizer='auto': sharded, except in bf16 mode at these small sizes, where the products read transposed weight copies)
+assert opt == ('replicated' if variant == 'diag_device_bf16' else 'sharded'), opt
+print('FACADE OK', rank, epochs, jm.sampling_method, opt)
 torch.distributed.destroy_process_group()
 ''')
     out = _torchrun(script, 29582)
