@@ -382,15 +382,15 @@ def main():
     pad = 8 if (args.dtype == 'bf16' and any(d % 8 for d in dims)) else 1
     lo, hi = jd.shard_bounds(n_cells, rank, world)
     data_real = synth_shard(n_cells, lo, hi, dims, rank, world, dev)
-    torch.manual_seed(666)
-    model = edModelVar(dims, L, device=dev, pad_features=pad)
-    if world > 1:
-        jd.broadcast_flat(model.flat)
-    eng = TrainEngine(model, B, lr=1e-3, seed=666 + 7919 * rank, world_size=max(world, args.dry_run_world), compute_dtype=args.dtype,
-                      dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr, grad_bf16=False if args.grad_fp32 else None)
-    data = eng.pad_cells(data_real)
     comm = torch.bfloat16 if (args.dtype == 'bf16' and args.grad_comm == 'auto') or args.grad_comm == 'bf16' else None
     n_dp = max(world, args.dry_run_world)
+    # the reference's quirk `replace = min(features) < batch_size` (jamie.py:553) belongs to its two-modality loop; the
+    # 3-modality generalisation always samples without replacement (duplicates would need a non-identity corr)
+    rep = min(dims) < B and len(dims) == 2
+    # KL anneal per epoch as in the reference's loop (jamie.py:630-632, min_epochs 2500, epoch_DNN 10000): a device scalar,
+    # rewritten (asynchronously) when the step count crosses an epoch boundary
+    steps_per_epoch = max(1, int((hi - lo) / B))
+    state = {'step': 0, 'epoch': -1}
 
     def make_exchange(eng_, comm_dtype, mode):
         """(exchange, 'sharded' | 'replicated' | None) for engine `eng_`."""
@@ -405,30 +405,48 @@ def main():
                 if mode == 'sharded':
                     raise SystemExit(f'--dp-optimizer sharded: {err}')
         return jd.OverlappedGradAllReduce(comm_dtype=comm_dtype, dry_run_world=args.dry_run_world), 'replicated'
-    allreduce, dp_opt = make_exchange(eng, comm, 'replicated' if (args.pipeline or args.side_transposes or args.transposed_weight_copies) else args.dp_optimizer)
-    idx = torch.zeros(B, dtype=torch.int32, device=dev)      # 'diag' sampling: same rows in both modalities
-    # the reference's quirk `replace = min(features) < batch_size` (jamie.py:553) belongs to its two-modality loop; the
-    # 3-modality generalisation always samples without replacement (duplicates would need a non-identity corr)
-    rep = min(dims) < B and len(dims) == 2
-    # KL anneal per epoch as in the reference's loop (jamie.py:630-632, min_epochs 2500, epoch_DNN 10000): a device scalar,
-    # rewritten (asynchronously) when the step count crosses an epoch boundary
-    steps_per_epoch = max(1, int((hi - lo) / B))
-    state = {'step': 0, 'epoch': -1}
+
+    def build_job(mode):
+        """Model, engine, exchange and the recorded plan of the timed job (the recording step is a real step)."""
+        torch.manual_seed(666)
+        model_ = edModelVar(dims, L, device=dev, pad_features=pad)
+        if world > 1:
+            jd.broadcast_flat(model_.flat)
+        eng_ = TrainEngine(model_, B, lr=1e-3, seed=666 + 7919 * rank, world_size=n_dp, compute_dtype=args.dtype,
+                           dx_from_weights=not args.transposed_weight_copies, skinny_tr=not args.no_skinny_tr,
+                           grad_bf16=False if args.grad_fp32 else None)
+        data_ = eng_.pad_cells(data_real)
+        ar_, opt_ = make_exchange(eng_, comm, mode)
+        idx_ = torch.zeros(B, dtype=torch.int32, device=dev)      # 'diag' sampling: same rows in both modalities
+        eng_.set_kl_anneal(kl_anneal(0, 2500, 10000))
+        if args.pipeline:
+            eng_.enable_pipeline(args.opt_priority)
+        if args.side_transposes:
+            eng_.enable_side_transposes()
+        eng_.enable_kernel_timing('enc_gemm', 'adam')
+        # the step is a fixed launch sequence on static buffers: record it once, replay it (one foreign call per launch)
+        plan_ = eng_.make_plan(data_, idx_, hi - lo, rep, ar_, prefetch=args.prefetch)
+        eng_.run_plan(plan_)
+        torch.cuda.synchronize()
+        return model_, eng_, data_, ar_, opt_, idx_, plan_
+
+    mode0 = 'replicated' if (args.pipeline or args.side_transposes or args.transposed_weight_copies) else args.dp_optimizer
+    dp_fallback = None
+    try:
+        model, eng, data, allreduce, dp_opt, idx, plan = build_job(mode0)
+    except Exception as err:         # noqa: BLE001  (the same failure on every rank: an API the backend lacks, not a hang)
+        if not (mode0 == 'auto' and n_dp > 1):
+            raise
+        dp_fallback = f'{type(err).__name__}: {err}'[:300]
+        model, eng, data, allreduce, dp_opt, idx, plan = build_job('replicated')
 
     def set_anneal():
         ep = state['step'] // steps_per_epoch
         if ep != state['epoch']:
             state['epoch'] = ep
             eng.set_kl_anneal(kl_anneal(ep, 2500, 10000))
-    set_anneal()
-    if args.pipeline:
-        eng.enable_pipeline(args.opt_priority)
-    if args.side_transposes:
-        eng.enable_side_transposes()
-    eng.enable_kernel_timing('enc_gemm', 'adam')
-    # the step is a fixed launch sequence on static buffers: record it once, replay it (one foreign call per launch)
-    plan = eng.make_plan(data, idx, hi - lo, rep, allreduce, prefetch=args.prefetch)
-    state['step'] = 1
+    state['epoch'] = 0
+    state['step'] = 2
 
     def step():
         set_anneal()
@@ -560,7 +578,7 @@ def main():
                                     + ('; the noise term drawn on the device (torch generator per rank)' if (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1' else ''),
                        'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B,
                        'parallelism': f'dp{world}', 'grad_allreduce': ('none' if world == 1 else ('bf16' if comm is not None else 'f32')),
-                       'dp_optimizer': dp_opt,
+                       'dp_optimizer': dp_opt, **({'dp_optimizer_fallback': dp_fallback} if dp_fallback else {}),
                        'parameters': model.num_parameters(),
                        'flop_per_cell': flops_per_cell(dims, L)},
             'roofline': roof,
