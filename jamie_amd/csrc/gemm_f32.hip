@@ -754,6 +754,8 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
             } else {
                 return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC>(pr, count, st);
             }
+        case 15: return launch_cfg<256, 128, 32, 4, 4, A_KC, B_KC>(pr, count, st);    // 16 waves of 64x32, one workgroup per CU
+        case 16: return launch_cfg<128, 256, 32, 4, 4, A_KC, B_KC>(pr, count, st);    // 16 waves of 32x64
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
 }
@@ -805,10 +807,10 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[15][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
-                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}};
+    static const int T[17][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
+                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 256}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 14 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 16 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

@@ -57,6 +57,26 @@ def test_gemm_layouts(nv, layout, M, N, K):
     close(out, ref, rtol=1e-5, atol=2e-6 * scale)
 
 
+@pytest.mark.parametrize('cfg', [4, 10, 11, 12, 15, 16])
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
+    """The register-staged fp32 kernel on its larger tiles (128x128 on 8 / 16 waves, 64x128, 128x64, 256x128, 128x256) in every
+    operand layout, ragged edges and split-K slabs included, against fp64."""
+    for (M, N, K, sk) in ((512, 520, 264, 1), (300, 200, 100, 1), (512, 384, 1000, 3)):
+        g = torch.Generator().manual_seed(M + N + K + cfg)
+        a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+        out = torch.full((sk, M, N), float('nan'), device='cuda')
+        kw = dict(splitk=sk, slab_stride=M * N) if sk > 1 else {}
+        if layout == 'NT':
+            nv.gemm([nv.gemm_problem(dev(a), dev(b.t()), out, M, N, K, K, K, N, **kw)], nv.NT, cfg)
+        elif layout == 'NN':
+            nv.gemm([nv.gemm_problem(dev(a), dev(b), out, M, N, K, K, N, N, **kw)], nv.NN, cfg)
+        else:
+            nv.gemm([nv.gemm_problem(dev(a.t()), dev(b), out, M, N, K, M, N, N, **kw)], nv.TN, cfg)
+        torch.cuda.synchronize()
+        close(out.sum(0), a.double() @ b.double(), rtol=1e-5, atol=2e-6 * float(np.sqrt(K)), msg=f'{layout} cfg {cfg} {(M, N, K, sk)}')
+
+
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES + [(512, 2000, 1000), (130, 72, 1002), (64, 64, 20)])
 @pytest.mark.parametrize('cfg', [7, 8, 9])
 def test_gemm_f32_lds_dma_nt(nv, M, N, K, cfg):

@@ -27,12 +27,20 @@ def run(layout, shapes, sks, cfg, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms * 1e3, fl / ms / 1e9
-tests = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 12: [(3, 2)], 13: [(3, 2)], 14: [(3, 2), (2, 1)]}),
-         ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 3)], 12: [(6, 3), (6, 4)], 13: [(6, 3)], 14: [(6, 3), (3, 2)]}),
-         ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 3)], 12: [(6, 3), (6, 4)]}),
-         ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 12: [(3, 2)]}),
-         ('TN dW 2dxd', nv.TN, [(2 * x, x, B) for x in d], {1: [(1, 1)], 12: [(1, 1)], 4: [(1, 1)]}),
-         ('TN dW dx2d', nv.TN, [(x, 2 * x, B) for x in d], {1: [(1, 1)], 12: [(1, 1)]})]
+if os.environ.get('BIG_TILES') == '1':       # 256x128 / 128x256 on 16 waves (one workgroup per CU) against the 128x128 plan
+    tests = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], {12: [(3, 2)], 15: [(3, 2), (2, 2), (4, 2)], 16: [(3, 2)]}),
+             ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], {12: [(6, 3)], 15: [(6, 4), (6, 3), (4, 2)], 16: [(6, 4)]}),
+             ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], {12: [(6, 3)], 15: [(6, 4), (4, 2)], 16: [(6, 4)]}),
+             ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], {12: [(3, 2)], 15: [(3, 2)], 16: [(3, 2)]}),
+             ('TN dW 2dxd', nv.TN, [(2 * x, x, B) for x in d], {12: [(1, 1)], 15: [(1, 1)], 16: [(1, 1)]}),
+             ('TN dW dx2d', nv.TN, [(x, 2 * x, B) for x in d], {12: [(1, 1)], 15: [(1, 1)], 16: [(1, 1)]})]
+else:
+    tests = [('NT d->2d', nv.NT, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 12: [(3, 2)], 13: [(3, 2)], 14: [(3, 2), (2, 1)]}),
+             ('NT 2d->d', nv.NT, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 3)], 12: [(6, 3), (6, 4)], 13: [(6, 3)], 14: [(6, 3), (3, 2)]}),
+             ('NN dy[2d]W', nv.NN, [(B, x, 2 * x) for x in d], {1: [(4, 2)], 4: [(6, 3)], 12: [(6, 3), (6, 4)]}),
+             ('NN dy[d]W', nv.NN, [(B, 2 * x, x) for x in d], {1: [(1, 1)], 4: [(3, 2)], 12: [(3, 2)]}),
+             ('TN dW 2dxd', nv.TN, [(2 * x, x, B) for x in d], {1: [(1, 1)], 12: [(1, 1)], 4: [(1, 1)]}),
+             ('TN dW dx2d', nv.TN, [(x, 2 * x, B) for x in d], {1: [(1, 1)], 12: [(1, 1)]})]
 for name, layout, shapes, plan in tests:
     for cfg, skl in plan.items():
         for sks in skl:
