@@ -521,8 +521,8 @@ class TrainEngine:
         def gathers():
             for name, lo, hi, s, o in zs['spans']:                    # forward order
                 ex.gather(name, full[lo:hi], piece[o:o + s])
+            zs['stale'] = True               # (set here: a replayed plan runs this callable, not the Python around it)
         self._both(gathers)
-        zs['stale'] = True
         if self.bf16:
             self._wT_stale = True
 

@@ -209,3 +209,46 @@ torch.distributed.destroy_process_group()
     assert out.count('FACADE OK') == 2, out[-2000:]
     eps = {ln.split()[3] for ln in out.splitlines() if ln.startswith('FACADE OK')}
     assert len(eps) == 1
+
+
+def test_facade_distributed_sharded_checkpoint_resume_is_bit_identical(tmp_path):
+    """Two ranks, sharded optimiser (the facade's default under distributed=True): 6 epochs with a checkpoint after the 4th ==
+    4 epochs + checkpoint + resume for 2 more.  The checkpoint is written by rank 0 from the replicated buffers after every rank has gathered its pieces
+    (parameters, both Adam moments); on resume the packed pieces are cut from the restored buffers."""
+    script = tmp_path / 'resume.py'
+    script.write_text(f'''
+import sys, io, contextlib, torch, numpy as np
+sys.path.insert(0, {ROOT!r})
+import jamie_amd
+from jamie_amd import distributed as jd
+rank, world, local = jd.init_from_env()
+rng = np.random.default_rng(4)
+N, dims = 640, (72, 40)
+Z = rng.standard_normal((N, 5))
+data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
+kw = dict(output_dim=8, batch_size=64, min_epochs=3, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9, sampler='device',
+          distributed=True, use_early_stop=False)
+ck = {str(tmp_path / 'dp.ckpt')!r}
+with contextlib.redirect_stdout(io.StringIO()):
+    # (the straight run checkpoints at the same epoch: a checkpoint averages the per-rank BatchNorm statistics in place)
+    full = jamie_amd.JAMIE(epoch_DNN=6, checkpoint_path=ck + '.full', checkpoint_every=4, **kw)
+    e_full = full.fit_transform(dataset=data)
+    part = jamie_amd.JAMIE(epoch_DNN=4, checkpoint_path=ck, checkpoint_every=4, **kw)
+    part.fit_transform(dataset=data)
+    torch.distributed.barrier()
+    res = jamie_amd.JAMIE(epoch_DNN=6, **kw)
+    e_res = res.fit_transform(dataset=data, resume_from=ck)
+assert full.engine._zs is not None and res.engine._zs is not None
+assert torch.equal(full.model.flat, res.model.flat), float((full.model.flat - res.model.flat).abs().max())
+assert torch.equal(full.engine.exp_avg, res.engine.exp_avg) and torch.equal(full.engine.exp_avg_sq, res.engine.exp_avg_sq)
+assert len(res.loss_history['Rec']) == 6
+if rank == 0:                       # (the checkpoint carries rank 0's loss history; the losses are per-shard)
+    assert full.loss_history == res.loss_history
+assert torch.equal(full.model.bn_flat, res.model.bn_flat)
+for a, b in zip(e_full, e_res):
+    assert np.array_equal(a, b)
+print('RESUME OK', rank)
+torch.distributed.destroy_process_group()
+''')
+    out = _torchrun(script, 29584)
+    assert out.count('RESUME OK') == 2, out[-2000:]
