@@ -5,6 +5,7 @@ GEMM/BN/act x2 -> output GEMM with fused MSE -> backward of all of it -> clip + 
 
 All buffers are allocated once per batch size; no step allocates, synchronises or reads back.
 """
+import functools
 import math
 import os
 
@@ -91,19 +92,96 @@ F32_CFG_DW = 1              # fp32 dW (TN, K = batch): 64x64x32 tile (sweep: too
 F32_CFG_DW_FUSED = 12       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
 
 
-def plan_f32_rows(B, shapes, target=2 * N_CU):
-    """fp32 forward / dX launch with shapes = [(N_i, K_i)]: the 128x128x32 tile with K slices of one common length such
-    that the launch has at most two workgroups per CU (tools/bench_gemm_f32_tiles.py: d -> 2d (3, 2) slices 110 us
-    against 119-122 us for the unsplit 64x64 tiles; 2d -> d (6, 3) 102 against 107 us).  (-1, None): keep the default."""
+def launch_makespan(works, n_cu=N_CU, per_cu=2, solo=0.87):
+    """Time (in units of work) a grid of workgroups takes on `n_cu` CUs that hold up to `per_cu` workgroups each.  The
+    dispatcher hands out workgroups in grid order to the least occupied CU with a free slot (completions of one instant are
+    retired first); the workgroups resident on a CU share its matrix pipe equally, and a workgroup alone on its CU gets `solo`
+    of it (nothing fills its barrier bubbles).  `works` = the work of every workgroup in grid order.  The model behind
+    plan_f32_rows: it ranks the split-K plans measured at config 5's dimensions in their measured order (14 plans,
+    profiles/r03_c5_f32_plan_sweep*.log) and reproduces config 2's (3, 2) / (6, 3)."""
+    import heapq
+    works = list(works)
+    clock, rem, ver = [0.0] * n_cu, [[] for _ in range(n_cu)], [0] * n_cu
+    free = [set(range(n_cu))] + [set() for _ in range(per_cu)]     # free[k]: CUs with k resident workgroups
+    heap, pos, end = [], 0, 0.0
+
+    def rate(c):
+        return solo if len(rem[c]) == 1 else 1.0 / len(rem[c])
+
+    def advance(c, t):
+        if rem[c]:
+            done = (t - clock[c]) * rate(c)
+            rem[c] = [r - done for r in rem[c]]
+        clock[c] = t
+
+    def schedule(c):
+        ver[c] += 1
+        if rem[c]:
+            heapq.heappush(heap, (clock[c] + min(rem[c]) / rate(c), c, ver[c]))
+
+    def dispatch(t):
+        nonlocal pos
+        while pos < len(works):
+            k = next((k for k in range(per_cu) if free[k]), None)
+            if k is None:
+                return
+            c = free[k].pop()
+            advance(c, t)
+            rem[c].append(works[pos])
+            pos += 1
+            free[k + 1].add(c)
+            schedule(c)
+    dispatch(0.0)
+    while heap:
+        t, c, v = heapq.heappop(heap)
+        if v != ver[c]:
+            continue
+        advance(c, t)
+        free[len(rem[c])].discard(c)
+        rem[c] = [r for r in rem[c] if r > 1e-9]
+        free[len(rem[c])].add(c)
+        end = t
+        schedule(c)
+        if not (heap and heap[0][0] <= t + 1e-9):
+            dispatch(t)
+    return end
+
+
+def plan_f32_rows(B, shapes):
+    """(tile configuration, K slices per problem) of an fp32 forward / dX launch; see _plan_f32_rows."""
+    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), os.environ.get('JAMIE_F32_ROWS'))
+
+
+@functools.lru_cache(maxsize=256)
+def _plan_f32_rows(B, shapes, _knob):
+    """fp32 forward / dX launch with shapes = [(N_i, K_i)]: the 128x128x32 tile (two workgroups per CU) with K slices of one
+    common length, chosen by a model of the launch: workgroup work = k-steps + 3 (prologue, store tail), launch time =
+    launch_makespan of the grid (every problem's slices in problem order) + what the extra slabs cost their consumer
+    (written and read once more at ~3 TB/s; a k-step of a CU is ~2 us).  Config 2: d -> 2d (3, 2) slices, exactly two
+    workgroups per CU (tools/bench_gemm_f32_tiles.py: 110 us against 119-122 us for the unsplit 64x64 tiles), 2d -> d (6, 3)
+    (102 against 107 us); config 5's dimensions: (2, 1) and (4, 2), one and a half rounds of 79-k-step workgroups -- the rule of
+    rounds 1-2 (the largest grid of at most two workgroups per CU) left a quarter of the CUs with one long workgroup there:
+    8.61 -> 7.60 ms per step, forward launches 94 -> 120 TFLOP/s.  (-1, None): keep the default."""
     if B < 256 or any(N < 512 or K < 512 for (N, K) in shapes):
         return -1, None
+    if os.environ.get('JAMIE_F32_ROWS'):          # tuning knob (tools/ab.sh): "s0,s1[;s0,s1 for the N < K launches]"
+        parts = os.environ['JAMIE_F32_ROWS'].split(';')
+        part = parts[0] if (all(N >= K for (N, K) in shapes) or len(parts) == 1) else parts[1]
+        sks = [int(v) for v in part.split(',')]
+        return F32_CFG_ROWS, [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
     tiles = [math.ceil(B / 128) * math.ceil(N / 128) for (N, K) in shapes]
-    best = None
+    kstep_us, overhead, slab_tbps = 2.05, 3.0, 3.0
+    best, seen = None, set()
     for kc in range(256, max(K for (_, K) in shapes) + 1, 8):
-        sk = [min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes]
-        total = sum(t * s for t, s in zip(tiles, sk))
-        if total <= target and (best is None or total > best[0]):
-            best = (total, sk)
+        sk = tuple(min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes)
+        if sk in seen:
+            continue
+        seen.add(sk)
+        works = [K / s / 32.0 + overhead for t, s, (_, K) in zip(tiles, sk, shapes) for _ in range(t * s)]
+        slabs = sum((s - 1) * B * N * 8.0 for s, (N, _) in zip(sk, shapes)) / (slab_tbps * 1e6)        # us
+        cost = launch_makespan(works) * kstep_us + slabs
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, list(sk))
     return (F32_CFG_ROWS, best[1]) if best else (-1, None)
 
 

@@ -532,11 +532,15 @@ def test_config5_dims_step_vs_oracle(jam):
     # see the config-4 test for the 2e-3 (LeakyReLU kink crossings; profiles/r02_c5_grad_error_vs_fp64.log)
     assert abs(float(eng.grad_flat().double().norm()) - st['grad_norm']) < 2e-3 * st['grad_norm']
     _check_first_adam_step(eng, model, init_flat)
+    # (which layers carry the kink-crossing noise depends on the summation order, i.e. on the split-K plan: 7e-4 on the gradients
+    #  upstream of decoders.0.5 with the plan of rounds 1-2, 5e-4 upstream of encoders.0.5 with round 3's -- everywhere else 1e-6,
+    #  tools/diag_c5_f32_plans.py, profiles/r03_diag_c5_f32_plans.log; Adam's first step is sign(g), so a first-layer matrix full of
+    #  near-zero gradients turns that into 1.2e-3 on its weights)
     sd = model.state_dict()
     for k, v in P.items():
         if not orc.is_dead_bias(k):
             assert_mostly_close(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-3, atol=2e-5, max_bad_frac=2e-2,
-                                rel_l2=1e-2 if v.dim() == 1 else 5e-4, msg=k)
+                                rel_l2=1e-2 if v.dim() == 1 else 2e-3, msg=k)
 
 
 def test_config5_dims_bf16_step_vs_emulating_oracle(jam):

@@ -380,3 +380,21 @@ def test_bf16_message_sum_keeps_the_clip_norm():
     rel_l2 = float((acc.double() - exact).norm() / exact.norm())
     assert rel_norm < 1e-3, rel_norm            # measured 2e-5: round-to-nearest-even is unbiased, the norm averages it out
     assert rel_l2 < 1e-2, rel_l2                # per-element noise ~4e-3, an order below the bf16 GEMMs' own (6e-2)
+
+
+def test_f32_split_k_plans_come_from_the_launch_model():
+    """engine.plan_f32_rows picks the K slices of an fp32 forward / dX launch by simulating the grid on 256 CUs with two
+    workgroups each (engine.launch_makespan): the plans measured best on the GPU (profiles/r03_c5_f32_plan_sweep*.log,
+    r03_c2_f32_plan_check.log) must come out of it."""
+    from jamie_amd.engine import F32_CFG_ROWS, launch_makespan, plan_f32_rows
+    assert launch_makespan([10.0] * 4, n_cu=2) == pytest.approx(20.0)             # two CUs, two workgroups each
+    assert launch_makespan([10.0] * 3, n_cu=2) == pytest.approx(20.0)             # the lone one finishes earlier (10 / 0.87)
+    assert launch_makespan([10.0] * 5, n_cu=2) == pytest.approx(20.0 + 10.0 / 0.87)
+    assert launch_makespan([8.0, 2.0], n_cu=1) == pytest.approx(4.0 + 6.0 / 0.87)  # shared until the short one leaves
+    B = 512
+    assert plan_f32_rows(B, [(4000, 2000), (2000, 1000)]) == (F32_CFG_ROWS, [3, 2])          # config 2, d -> 2d
+    cfg, sk = plan_f32_rows(B, [(2000, 4000), (1000, 2000)])                                 # config 2, 2d -> d: (3, 2) = (6, 3) measured
+    assert cfg == F32_CFG_ROWS and sk in ([3, 2], [6, 3], [6, 4])
+    assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)]) == (F32_CFG_ROWS, [2, 1])         # config 5, d -> 2d
+    assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)]) == (F32_CFG_ROWS, [4, 2])         # config 5, 2d -> d
+    assert plan_f32_rows(B, [(400, 200), (200, 100)]) == (-1, None)                          # small layers: the library default
