@@ -167,8 +167,9 @@ def _plan_f32_rows(B, shapes, _knob):
     if os.environ.get('JAMIE_F32_ROWS'):          # tuning knob (tools/ab.sh): "s0,s1[;s0,s1 for the N < K launches]"
         parts = os.environ['JAMIE_F32_ROWS'].split(';')
         part = parts[0] if (all(N >= K for (N, K) in shapes) or len(parts) == 1) else parts[1]
+        cfg, _, part = part.rpartition(':')                 # ("cfg:s0,s1": another tile configuration)
         sks = [int(v) for v in part.split(',')]
-        return F32_CFG_ROWS, [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
+        return (int(cfg) if cfg else F32_CFG_ROWS), [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
     tiles = [math.ceil(B / 128) * math.ceil(N / 128) for (N, K) in shapes]
     kstep_us, overhead, slab_tbps = 2.05, 3.0, 3.0
     best, seen = None, set()
