@@ -65,6 +65,12 @@ struct BnFuse {
 // optimiser): JB_W_NT = 0 default policy; 1 non-temporal (aux = 2) in the forward launches; 2 in the forward and dX launches
 // (MI355X_MICROARCH.md row nt-weights; A/B builds with -DJB_W_NT=.., tools/ab.sh + JAMIE_LIB).  Never for dW (B = activations,
 // re-read by every tile row): on ALL launches the step took 681 instead of 635 us (profiles/r03_ab_nt_weights_rejected.log).
+#ifndef JB_LONG_PRIO
+#define JB_LONG_PRIO 0
+#endif
+#ifndef JB_LONG_NK
+#define JB_LONG_NK 12
+#endif
 #ifndef JB_W_NT
 #define JB_W_NT 0
 #endif
@@ -560,6 +566,11 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     const int kend = min(P.K, kbeg + P.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
+#if JB_LONG_PRIO
+    // the long tiles of a grouped launch (dX: K = features) are its critical path: their waves win the issue arbitration against
+    // the short dW tiles (K = batch) they share a CU with (A/B: -DJB_LONG_PRIO=n, threshold JB_LONG_NK k-steps)
+    if (nk >= JB_LONG_NK) __builtin_amdgcn_s_setprio(JB_LONG_PRIO);
+#endif
     JB_STAMPV(4, pi * 1000 + nk);
     JB_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));   // XCC_ID, HW_ID cu/se bits
 

@@ -66,6 +66,54 @@ cases = {
  'bwd_dec1_r': ([(B, x, 2 * x) for x in d] + [(2 * x, x, B) for x in d], 25, (4, 2, 1, 1)),      # dX problems first
  'bwd_enc1_r': ([(B, 2 * x, x) for x in d] + [(x, 2 * x, B) for x in d], 25, (2, 1, 1, 1)),
 }
+def run_bwd_now(name, wshape, sks, cfg=29, iters=13):
+    """The grouped backward launch as the engine issues it now (engine._bwd_gemms): dX problems first (dy [B, out] x W [out, in]
+    as stored, b_tr), then the dW problems (dy^T a on the row-major operands, a_tr + b_tr, bf16 result, nt stores)."""
+    sets = []
+    for b in range(NBUF):
+        probs = []
+        for (nout, nin), s1 in zip(wshape, sks):
+            dy, W = T(B, nout), T(nout, nin)
+            probs.append(nv.gemm_problem(dy, W, torch.empty(s1, B, nin, device='cuda'), B, nin, nout, nout, nin, nin, splitk=s1, slab_stride=B * nin, b_tr=True))
+        for (nout, nin) in wshape:
+            dy, a = T(B, nout), T(B, nin)
+            probs.append(nv.gemm_problem(dy, a, torch.empty(nout, nin, device='cuda', dtype=torch.bfloat16), nout, nin, B, nout, nin, nin,
+                                         a_tr=True, b_tr=True, store_nt=True, c_bf16=True))
+        sets.append(probs)
+    for i in range(iters): nv.gemm_bf16(sets[i % NBUF], cfg)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); nv.gemm_bf16(sets[iters % NBUF], cfg); e1.record(); torch.cuda.synchronize()
+    nb = 8192
+    buf = (C.c_ulonglong * (8 * nb))()
+    fn = lib.jamie_debug_stamps
+    fn.argtypes = [C.c_void_p, C.c_int]
+    assert fn(buf, nb) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
+    a = a[a[:, 3] > 0]
+    a = a[a[:, 0] > a[:, 0].max() - 30000]
+    t0 = a[:, 0].min()
+    us = lambda x: x / 100.0
+    st, pro, loop, epi, end = us(a[:, 0] - t0), us(a[:, 1] - a[:, 0]), us(a[:, 2] - a[:, 1]), us(a[:, 3] - a[:, 2]), us(a[:, 3] - t0)
+    print(f'== {name} cfg {cfg} sk {sks}: {len(a)} workgroups, event {e0.elapsed_time(e1)*1e3:.1f} us, last end {end.max():.1f} us')
+    for pi in sorted(set(a[:, 4] // 1000)):
+        m = a[:, 4] // 1000 == pi
+        nk = a[m, 4] % 1000
+        print(f'  problem {pi}: {m.sum()} wgs, nk {nk.min()}..{nk.max()}: start med {np.median(st[m]):.2f} (max {st[m].max():.2f}), prologue med {np.median(pro[m]):.2f}, '
+              f'loop med {np.median(loop[m]):.2f} us = {np.median(loop[m]) / np.median(nk) * 1e3:.0f} ns/k-step, epilogue med {np.median(epi[m]):.2f}, whole med {np.median(end[m] - st[m]):.2f}, end max {end[m].max():.2f}')
+    cu = a[:, 5]
+    for c in np.unique(cu)[:4]:
+        m = cu == c
+        o = np.argsort(st[m])
+        print('   CU', c, '(problem*1000+nk, start, published, loop end, end):',
+              [(int(x), round(float(y), 1), round(float(y + p), 1), round(float(y + p + l), 1), round(float(z), 1))
+               for x, y, p, l, z in zip(a[m, 4][o], st[m][o], pro[m][o], loop[m][o], end[m][o])])
+
+
+if os.environ.get('CASES') == 'bwd_now':
+    run_bwd_now('bwd dec2 (dX K = d, dW d x 2d)', [(x, 2 * x) for x in d], (1, 1))
+    run_bwd_now('bwd dec1 (dX K = 2d, dW 2d x d)', [(2 * x, x) for x in d], (2, 1))
+    sys.exit(0)
 for k in os.environ.get('CASES', 'fwd_d2d,fwd_2dd,bwd_dec1,bwd_dec1_r,bwd_enc1,bwd_enc1_r').split(','):
     shapes, cfg, sks = cases[k]
     run(k, shapes, int(os.environ.get('CFG', cfg)), sks)
