@@ -6,7 +6,9 @@ bandwidth?  (SURVEY.md §5 last row: check before hand-rolling P2P kernels.)  Fo
       tools/rccl_probe.py [--mb 40 --count 4 --dtype bf16|f32 --iters 20]
 
 Defaults are config 2's exchange: 4 messages of ~40 MB (bf16: 80 MB per step in all; f32: use --mb 40 --count 4 for the
-161 MB).  Rank 0 prints one JSON line: per-message time, algorithmic and bus bandwidth (2 (n-1)/n x bytes / time), and the
+161 MB).  Rank 0 prints one JSON line: per-message time, algorithmic and bus bandwidth (2 (n-1)/n x bytes / time) of the
+all-reduce, the same for the sharded optimiser's reduce-scatter and all-gather ((n-1)/n x bytes / time), the latency of a
+256-byte all-reduce (bench.py's dp_model assumes 300 GB/s and 20 us: put the measured figures next to its prediction), and the
 lines of RCCL's own INFO log (subsystems INIT, GRAPH, TUNING, COLL; one file per rank under --log-dir) that name the
 algorithm (Ring / Tree / ...), the protocol (LL / LL128 / Simple), the channels and the transport (P2P over xGMI)."""
 import argparse
@@ -55,6 +57,28 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
     dist.barrier()
+    # the sharded optimiser's exchange (distributed.ShardedGradExchange): every message is reduce-scattered into a 1/world piece,
+    # and a 1/world piece of the updated weights is all-gathered into a message-sized buffer
+    m = n // world * world
+    pieces = [torch.empty(m // world, device='cuda', dtype=dt) for _ in bufs]
+    fulls = [torch.empty(m, device='cuda', dtype=dt) for _ in bufs]
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.iters):
+            for w in fn():
+                w.wait()
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t1) / args.iters], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    el_rs = timed(lambda: [dist.reduce_scatter_tensor(pc, b[:m], async_op=True) for pc, b in zip(pieces, bufs)])
+    el_ag = timed(lambda: [dist.all_gather_into_tensor(f, pc, async_op=True) for f, pc in zip(fulls, pieces)])
+    small = torch.zeros(64, device='cuda')
+    el_small = timed(lambda: [dist.all_reduce(small, async_op=True)])
     if rank == 0:
         nbytes = n * bufs[0].element_size() * args.count
         text = ''
@@ -71,6 +95,9 @@ def main():
         print(json.dumps({'world': world, 'dtype': args.dtype, 'messages': args.count, 'bytes_per_step': nbytes,
                           'ms_per_step': 1e3 * el, 'alg_GBps': nbytes / el / 1e9,
                           'bus_GBps': 2 * (world - 1) / world * nbytes / el / 1e9,
+                          'reduce_scatter': {'ms_per_step': 1e3 * el_rs, 'bus_GBps': (world - 1) / world * nbytes / el_rs / 1e9},
+                          'all_gather': {'ms_per_step': 1e3 * el_ag, 'bus_GBps': (world - 1) / world * nbytes / el_ag / 1e9},
+                          'all_reduce_256_bytes_us': 1e6 * el_small,
                           'rccl_version': '.'.join(map(str, torch.cuda.nccl.version())), 'log_dir': log_dir,
                           'rccl_log_lines': uniq[:40]}))
     dist.destroy_process_group()
