@@ -80,7 +80,7 @@ def synth_shard(n_cells, lo, hi, dims, rank, world, device):
     return out
 
 
-ASSUMED_COLLECTIVE_LATENCY_US = 20.0   # per collective, on top of bytes / bandwidth (stated, not measured)
+ASSUMED_COLLECTIVE_LATENCY_US = 35.0   # per collective, on top of bytes / bandwidth: a 256-byte all-reduce takes 35 us in a ONE-rank RCCL 2.26.6 group on the box (tools/rccl_probe.py); more ranks will not be faster
 
 
 def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_other, other_name):

@@ -221,8 +221,12 @@ class ShardedGradExchange(OverlappedGradAllReduce):
     the large regions is only current on its owner in bf16 mode: TrainEngine.gather_sharded_state() before anything other
     than the next training step reads `model.flat` (evaluation, checkpoints)."""
 
-    def __init__(self, group=None, comm_dtype=None, dry_run_world=0, dry_run_rank=0):
+    def __init__(self, group=None, comm_dtype=None, dry_run_world=0, dry_run_rank=0, single_rank_ok=False):
+        """`single_rank_ok`: run the whole exchange in a one-rank process group as well (every collective is then a copy on the
+        backend's own stream): the one way to put this code path through RCCL itself on a one-GPU box
+        (tests/test_hip_distributed.py::test_sharded_exchange_on_rccl_with_one_rank)."""
         super().__init__(group, min_bytes=1 << 62, comm_dtype=comm_dtype, dry_run_world=dry_run_world)
+        self.single = bool(single_rank_ok) and self.world == 1 and dist.is_initialized()
         self.rank = int(dry_run_rank) if self.dry or not dist.is_initialized() else dist.get_rank(group)
         self.spans = {}              # (lo, hi) of a sharded region -> this rank's packed gradient piece (length (hi - lo) / world)
         self.gathers = {}            # layer name -> pending all-gather of its updated weights
@@ -235,13 +239,18 @@ class ShardedGradExchange(OverlappedGradAllReduce):
         self.spans = {(int(lo), int(hi)): dst for lo, hi, dst in spans}
 
     def region_done(self, flat, lo, hi, precast=False):
-        if self.world == 1:
+        if self.world == 1 and not self.single:
             return
         if (lo, hi) in self.spans:               # a sharded region is one message, never merged with its neighbours
             if self.pending is not None:
                 self._issue(*self.pending)
                 self.pending = None
             self._issue(flat, lo, hi, bool(precast))
+            return
+        if self.single:                          # (the base class drops everything in a one-rank world)
+            if self.pending is not None:
+                self._issue(*self.pending)
+            self.pending = (flat, lo, hi, bool(precast))
             return
         super().region_done(flat, lo, hi, precast)
 
@@ -263,7 +272,7 @@ class ShardedGradExchange(OverlappedGradAllReduce):
 
     def sum_partials(self, t):
         """In-place sum over the ranks of the partial sums of squares of the pieces each rank owns."""
-        if not self.dry and self.world > 1:
+        if not self.dry and (self.world > 1 or self.single):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def gather(self, name, out, piece):

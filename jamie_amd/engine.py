@@ -544,7 +544,7 @@ class TrainEngine:
         gradient and (bf16 mode) the bf16 weight copy of piece `ex.rank` of every region in PACKED buffers, so that clip + Adam
         is one launch over 1 / world of the parameters.  The small region `rep` stays replicated."""
         lay, n, r = self.m.layout, int(ex.world), int(ex.rank)
-        if n < 2:
+        if n < 2 and not getattr(ex, 'single', False):
             raise ValueError('a sharded optimiser needs more than one rank')
         if self.pipeline or self.accumulate or self.side_transposes or any(k.split('.')[1] in lay.BIG_LAYERS for k in self.wT):
             raise ValueError('sharded optimiser: not with the pipelined optimiser, accumulating gradients or transposed copies '
@@ -1230,7 +1230,7 @@ class TrainEngine:
         bf16 copy; no step-counter increment) -- so the fp32 -> bf16 cast pass over the 161 MB gradient (a second stream beside
         the backward GEMMs, two events per region) does not exist.  Returns None where the path does not apply."""
         ok = (allreduce is not None and hasattr(allreduce, 'message_buffer') and getattr(allreduce, 'comm_dtype', None) == torch.bfloat16
-              and getattr(allreduce, 'world', 1) > 1 and self.bf16 and self.grad.is_cuda and not self.accumulate
+              and (getattr(allreduce, 'world', 1) > 1 or getattr(allreduce, 'single', False)) and self.bf16 and self.grad.is_cuda and not self.accumulate
               and self.gcfg.get('dw', -1) == BF16_CFG_DW and self.skinny_tr and 3 * self.M <= nv.MAX_GEMM_GROUP
               and all(self.gcfg.get(k, -1) == BF16_CFG_DW for k in ('d_e2', 'd_e1', 'd_a1'))
               and self._fused_latent(None, None) and self._fuse_da2() and os.environ.get('JAMIE_NO_DIRECT_COMM') != '1')

@@ -252,3 +252,71 @@ torch.distributed.destroy_process_group()
 ''')
     out = _torchrun(script, 29584)
     assert out.count('RESUME OK') == 2, out[-2000:]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16_msgs_direct'])
+def test_sharded_exchange_on_rccl_with_one_rank(tmp_path, mode):
+    """The sharded optimiser's exchange through RCCL ITSELF (backend "nccl"), which a one-GPU box only allows with one rank:
+    reduce_scatter_tensor into the packed gradient piece, the all-reduce of `rep` and of the norm partials, all_gather_into_tensor
+    of the updated weights into the (bf16 / fp32) weight buffer, asynchronous works waited for from recorded plans -- every
+    collective degenerates to a copy on RCCL's stream, the calls, dtypes, views and stream hand-offs are the 8-GPU job's.  Against
+    the plain one-GPU engine: the same gradients, the squared norm summed in another order."""
+    script = tmp_path / 'one.py'
+    script.write_text(f'''
+import os, sys, torch, numpy as np
+sys.path.insert(0, {ROOT!r})
+from jamie_amd import distributed as jd, _native as nv
+from jamie_amd.engine import TrainEngine
+from jamie_amd.model import edModelVar
+os.environ.pop('JAMIE_DIST_BACKEND', None)
+os.environ['WORLD_SIZE'] = '2'                      # (init_from_env skips a one-rank world)
+torch.cuda.set_device(0)
+torch.distributed.init_process_group('nccl', rank=0, world_size=1)
+assert torch.distributed.get_backend() == 'nccl'
+dev = torch.device('cuda', 0)
+mode = {mode!r}
+dims, L, B, N = ((264, 136) if mode == 'f32' else (328, 264)), 8, 128, 1024
+g = torch.Generator(device=dev).manual_seed(50)
+data = [torch.randn(N, d, generator=g, device=dev) for d in dims]
+compute = 'f32' if mode == 'f32' else 'bf16'
+res = {{}}
+for label in ('plain', 'sharded'):
+    torch.manual_seed(3)
+    model = edModelVar(dims, L, device=dev)
+    eng = TrainEngine(model, B, seed=11, compute_dtype=compute, grad_bf16=False)
+    ar = None
+    if label == 'sharded':
+        ar = jd.ShardedGradExchange(comm_dtype=torch.bfloat16 if mode != 'f32' else None, single_rank_ok=True)
+        assert ar.single and ar.world == 1
+        eng.enable_sharded_optimizer(ar)
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    for s in range(2):
+        nv.sample_indices(idx, N, 0, False, eng.state, 200)
+        eng.load_batch(data, [idx, idx])
+        eng.step(None, None, None, ar)
+    if label == 'sharded':
+        assert eng._direct_now == (mode != 'f32')
+    plan = eng.make_plan(data, idx, N, False, ar)
+    for s in range(2):
+        eng.run_plan(plan)
+    eng.flush()
+    torch.cuda.synchronize()
+    assert int(eng.state[1].item()) == 5
+    res[label] = (model.flat.clone(), eng.exp_avg.clone(), eng.read_losses()[1])
+a, b = res['plain'][0], res['sharded'][0]
+d = (a - b).abs()
+if mode == 'f32':
+    assert float(d.max()) <= 5 * 2e-3 and float((d > 1e-6).float().mean()) < 2e-3, (float(d.max()), float((d > 1e-6).float().mean()))
+    assert abs(res['plain'][2] - res['sharded'][2]) <= 1e-4 * abs(res['plain'][2])
+else:       # bf16 messages round the gradient once more than the plain engine's fp32 gradient buffer
+    frac = float((d > 5 * 1e-3 * 2.0 ** -8 * 4).float().mean())
+    assert float(d.max()) <= 5 * 2e-3 + 1e-6 and frac < 5e-2, (float(d.max()), frac)
+    assert abs(res['plain'][2] - res['sharded'][2]) <= 2e-2 * abs(res['plain'][2])
+print('RCCL ONE OK', float(d.max()))
+torch.distributed.destroy_process_group()
+''')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29586')
+    env.pop('JAMIE_DIST_BACKEND', None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert 'RCCL ONE OK' in r.stdout
