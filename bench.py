@@ -80,15 +80,17 @@ def synth_shard(n_cells, lo, hi, dims, rank, world, device):
     return out
 
 
-ASSUMED_COLLECTIVE_LATENCY_US = 35.0   # per collective, on top of bytes / bandwidth: a 256-byte all-reduce takes 35 us in a ONE-rank RCCL 2.26.6 group on the box (tools/rccl_probe.py); more ranks will not be faster
+ASSUMED_COLLECTIVE_LATENCY_US = 35.0   # issue -> first byte of a collective on an idle wire: a 256-byte all-reduce takes 35 us in a ONE-rank RCCL 2.26.6 group on the box (tools/rccl_probe.py)
+ASSUMED_COLLECTIVE_GAP_US = 5.0        # between collectives queued back to back (the next one's launch hides under the current transfer)
 
 
 def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_other, other_name):
     """Exposure model of the data-parallel exchange for `world` GPUs from ONE GPU's timeline (bench.py --dry-run-world).
     The dry run's HIP events give, relative to the step's first launch, when the backward pass announces each gradient message,
     where the step starts waiting for them (`finish`), when the updated weights' all-gathers are issued (sharded optimiser) and
-    where the NEXT forward pass needs each gathered region (`wait:<layer>`).  All collectives go over ONE wire, in issue order,
-    each taking ASSUMED_COLLECTIVE_LATENCY_US + bytes / algbw with, for an ASSUMED bus bandwidth ASSUMED_BUS_GBS (a ring over
+    where the NEXT forward pass needs each gathered region (`wait:<layer>`).  All collectives go over ONE wire, in issue order:
+    a collective starts ASSUMED_COLLECTIVE_LATENCY_US after it is issued, or ASSUMED_COLLECTIVE_GAP_US after the one before it
+    ends, whichever is later, and then takes bytes / algbw with, for an ASSUMED bus bandwidth ASSUMED_BUS_GBS (a ring over
     xGMI is per-link bound: tools/rccl_probe.py measures the real figure): all-reduce algbw = busbw n / (2 (n - 1)),
     reduce-scatter and all-gather algbw = busbw n / (n - 1).  A few steady-state steps are simulated: the main stream stalls where
     it waits for a collective that has not finished, and the stall pushes everything behind it.  Collectives and kernels are
@@ -96,13 +98,18 @@ def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_other, other_n
     n = world
     bw_ar = ASSUMED_BUS_GBS * n / (2.0 * (n - 1))
     bw_half = ASSUMED_BUS_GBS * n / (n - 1.0)
-    lat = ASSUMED_COLLECTIVE_LATENCY_US * 1e-3            # ms
+    lat, gap = ASSUMED_COLLECTIVE_LATENCY_US * 1e-3, ASSUMED_COLLECTIVE_GAP_US * 1e-3            # ms
     ev = sorted(trace_ms, key=lambda e: e[2])
+    # the traced steps run a little longer than the timed ones (event records): positions are kept as fractions of the step
+    t_end = [t for k, _, t in ev if k == 'step_end']
+    if t_end and t_end[0] > 0:
+        ev = [(k, b, t * step_ms_dry / t_end[0]) for k, b, t in ev if k != 'step_end']
     sharded = any(k == 'reduce_scatter' for k, _, _ in ev)
     out = {'world': n, 'optimizer': 'sharded' if sharded else 'replicated', 'assumed_bus_bandwidth_GBps': ASSUMED_BUS_GBS,
-           'assumed_collective_latency_us': ASSUMED_COLLECTIVE_LATENCY_US,
+           'assumed_collective_latency_us': ASSUMED_COLLECTIVE_LATENCY_US, 'assumed_gap_between_queued_collectives_us': ASSUMED_COLLECTIVE_GAP_US,
            'all_reduce_algorithm_bandwidth_GBps': bw_ar, 'reduce_scatter_all_gather_algorithm_bandwidth_GBps': bw_half,
            'events': [{'kind': k, 'bytes': int(b), 'at_us': 1e3 * t} for k, b, t in ev],
+           'traced_step_us': 1e3 * step_ms_dry,
            'step_us_dry_run': 1e3 * step_ms_dry, 'step_us_one_gpu': 1e3 * step_ms_one}
 
     def simulate(scale):
@@ -118,7 +125,7 @@ def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_other, other_n
                         shift += end - now
                         stalls['forward_waits_us'] += 1e3 * (end - now)
                 elif k in ('reduce_scatter', 'message'):
-                    wire = max(wire, now) + lat + (b * scale / 1e6) / (bw_half if k == 'reduce_scatter' else bw_ar)
+                    wire = max(wire + gap, now + lat) + (b * scale / 1e6) / (bw_half if k == 'reduce_scatter' else bw_ar)
                 elif k == 'finish':
                     if wire > now:
                         shift += wire - now
@@ -128,7 +135,7 @@ def dp_model(trace_ms, step_ms_dry, step_ms_one, world, msg_scale_other, other_n
                         stalls['norm_all_reduce_us'] += 1e3 * lat
                         wire = max(wire, t0 + t + shift)
                 elif k == 'all_gather':
-                    wire = max(wire, now) + lat + (b / 1e6) / bw_half
+                    wire = max(wire + gap, now + lat) + (b / 1e6) / bw_half
                     order.append(wire)
             names = [k[5:] for k, _, _ in ev if k.startswith('wait:')]
             gathered = dict(zip(names, order))
@@ -496,8 +503,10 @@ def main():
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(nv.current_stream())
             step()
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(nv.current_stream())
             torch.cuda.synchronize()
-            traces.append([(k, b, e0.elapsed_time(ev)) for k, b, ev in allreduce.trace])
+            traces.append([(k, b, e0.elapsed_time(ev)) for k, b, ev in allreduce.trace] + [('step_end', 0, e0.elapsed_time(e1))])
         allreduce.enable_trace(False)
         med = [(traces[0][i][0], traces[0][i][1], float(np.median([t[i][2] for t in traces]))) for i in range(len(traces[0]))]
         # the one-GPU step on the same box, for the efficiency the model predicts
