@@ -313,7 +313,7 @@ int jamie_optim_blocks(long long n);   /* number of partials jamie_grad_sqnorm w
 int jamie_grad_sqnorm(const float* g, long long n, float* partials, int n_partials, uint64_t* state,
                       void* stream);
 /* The same over `count` ranges [offsets[i], offsets[i] + lengths[i]) of g only: one partial per chunk of 4096
- * elements (jamie_sqnorm_range_blocks() of them, <= 128).  Used with the dW launches of jamie_gemm_bf16 that write
+ * elements, or of the smallest multiple of 4096 that keeps the chunk count at <= 128 (jamie_sqnorm_range_blocks() of them).  Used with the dW launches of jamie_gemm_bf16 that write
  * the sum of squares of every stored tile into `partial` (EPI_STORE + partial): together they cover the gradient, and
  * jamie_clip_adam sums all of them -- clip_grad_norm_ (jamie.py:739) without a second pass over the weight gradients. */
 int jamie_grad_sqnorm_ranges(const float* g, const long long* offsets /*host*/, const long long* lengths /*host*/, int count,

@@ -270,15 +270,28 @@ __global__ __launch_bounds__(256) void grad_sqnorm_ranges_kernel(const float* __
     sqnorm_range_chunk(g, g16, r, (int)blockIdx.x, partials, state, red);
 }
 
+// Chunk length of a range list: JAMIE_SQ_CHUNK (4096 elements per workgroup) where that gives at most 128 chunks -- every
+// BASELINE configuration in bf16 mode --, else the smallest multiple of it that does (fp32 mode at config 5's dimensions: the
+// skinny head / latent matrices are ranges there, 1.5 M elements -> 12288 per workgroup)
+static long long sq_chunk_len(const long long* lengths, int count) {
+    for (long long c = JAMIE_SQ_CHUNK;; c += JAMIE_SQ_CHUNK) {
+        long long nb = 0;
+        for (int i = 0; i < count; ++i) nb += (lengths[i] + c - 1) / c;
+        if (nb <= 128 || c >= (1LL << 30)) return c;
+    }
+}
+
 static int fill_ranges(const long long* offsets, const long long* lengths, int count, bool g16, SqRanges* r, int* nb_out) {
     int nb = 0;
+    JAMIE_ARG(count <= 128, "more than 128 ranges");
+    const long long chunk = sq_chunk_len(lengths, count);
     for (int i = 0; i < count; ++i) {
         JAMIE_ARG(offsets[i] >= 0 && lengths[i] >= 0, "negative range");
         JAMIE_ARG(!g16 || offsets[i] % 4 == 0, "bf16 copies need range offsets that are multiples of 4");
-        for (long long o = 0; o < lengths[i]; o += JAMIE_SQ_CHUNK) {
-            JAMIE_ARG(nb < 128, "more than 128 chunks of 4096 elements");
+        for (long long o = 0; o < lengths[i]; o += chunk) {
+            JAMIE_ARG(nb < 128, "more than 128 chunks");
             r->off[nb] = offsets[i] + o;
-            r->len[nb] = (int)(lengths[i] - o < JAMIE_SQ_CHUNK ? lengths[i] - o : JAMIE_SQ_CHUNK);
+            r->len[nb] = (int)(lengths[i] - o < chunk ? lengths[i] - o : chunk);
             ++nb;
         }
     }
@@ -371,7 +384,8 @@ extern "C" int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const 
 
 extern "C" int jamie_sqnorm_range_blocks(const long long* lengths, int count) {
     int nb = 0;
-    for (int i = 0; i < count; ++i) nb += (int)((lengths[i] + JAMIE_SQ_CHUNK - 1) / JAMIE_SQ_CHUNK);
+    const long long chunk = sq_chunk_len(lengths, count);
+    for (int i = 0; i < count; ++i) nb += (int)((lengths[i] + chunk - 1) / chunk);
     return nb;
 }
 

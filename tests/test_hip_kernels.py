@@ -827,6 +827,30 @@ def test_gemm_bf16_range_norm_rider(nv):
     close(outs[True][0], dy.float().cpu().double().t() @ a.float().cpu().double(), 1e-3, 1e-2, 'dW')
 
 
+def test_range_norm_takes_longer_chunks_for_long_range_lists(nv):
+    """jamie_grad_sqnorm_ranges over more than 128 x 4096 elements (fp32 mode at config 5's dimensions: the skinny head / latent
+    matrices are ranges there): the chunk becomes the smallest multiple of 4096 that keeps the count at <= 128; the partial sums
+    still add up to the sum of squares of the ranges, the bf16 copies are the rounded ranges, the step counter advances once."""
+    g = torch.Generator().manual_seed(8)
+    n = 1_600_000
+    flat = dev(torch.randn(n, generator=g))
+    spec = [(8, 900_000), (900_100, 4), (1_000_000, 500_001)]
+    ranges = nv.SqRanges(spec)
+    assert ranges.blocks <= 128 and ranges.blocks == sum(-(-ln // 12288) for _, ln in spec)
+    part = torch.full((ranges.blocks,), float('nan'), device='cuda')
+    state = torch.tensor([1, 8, 0, 0], dtype=torch.int64, device='cuda')
+    g16 = torch.zeros(n, device='cuda', dtype=torch.bfloat16)
+    nv.grad_sqnorm_ranges(flat, ranges, part, state, g16)
+    f = flat.cpu().double()
+    want = sum(float((f[o:o + ln] ** 2).sum()) for o, ln in spec)
+    assert abs(float(part.double().sum()) - want) <= 1e-6 * want and int(state[1].item()) == 9
+    for o, ln in spec:
+        assert torch.equal(g16[o:o + ln], flat[o:o + ln].to(torch.bfloat16))
+    assert float(g16[:8].float().abs().sum()) == 0.0
+    small = nv.SqRanges([(0, 4100), (8200, 3)])                  # short lists keep the 4096-element chunk
+    assert small.blocks == 3
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 compute mode
 # ------------------------------------------------------------------------------------------------
