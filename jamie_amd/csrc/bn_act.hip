@@ -18,6 +18,13 @@
 
 #include "bn_fwd_strip.h"
 
+#ifdef JAMIE_BN_STAMP
+__device__ unsigned long long jamie_bn_dbg_stamps[4096 * BN_NSTAMP];
+extern "C" int jamie_debug_bn_stamps(unsigned long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(jamie_bn_dbg_stamps), sizeof(unsigned long long) * BN_NSTAMP * n_blocks);
+}
+#endif
+
 // cache policy bits of the float4 kernels' once-read loads (split-K slabs, saved pre-activations, upstream gradients): 2 = nt
 // (they are dead once read; default policy, 0: the step 602.6 instead of 599.4 us on one box, three interleaved rounds,
 // profiles/r03_ab_bn_nt_loads.log)
@@ -420,8 +427,14 @@ __device__ __forceinline__ void prefetch_block(const PfRanges& r, int blk, int n
         if (i < r.n) prefetch_range(r.p[i], r.bytes[i], blk, nblk);
 }
 
+// (A/B knob -DJAMIE_BN_FWD_WAVES=4: at most 128 VGPRs for R = 4, i.e. two 512-thread workgroups per CU instead of one -- the
+//  compiler's own allocation is 130 registers; measured slower, also with the second-slot workgroups holding their loads back
+//  by 3-6 us: DESIGN.md §4, profiles/r03_stamps_bn_fwd*.log, r03_ab_bn_stagger_rejected.log)
+#ifndef JAMIE_BN_FWD_WAVES
+#define JAMIE_BN_FWD_WAVES 1
+#endif
 template <int R, int CQ>
-__global__ __launch_bounds__(128 * CQ) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
+__global__ __launch_bounds__(128 * CQ, (R <= 4 ? JAMIE_BN_FWD_WAVES : 1)) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                                float slope, const uint64_t* rng, PfRanges pf, int n_main) {
     if ((int)blockIdx.x >= n_main) {
         prefetch_block(pf, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);

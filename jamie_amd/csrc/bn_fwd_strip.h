@@ -113,6 +113,18 @@ __device__ __forceinline__ void strip_out_bf16x4(const float4 (&val)[R], unsigne
     }
 }
 
+// Diagnostic build only (-DJAMIE_BN_STAMP, tools/stamp_bn.py): thread 0 of every workgroup stamps s_memrealtime at the phases of
+// the forward strip (entry / slabs summed / statistics done / stores issued / stores retired); no stamp exists in the product build.
+#ifdef JAMIE_BN_STAMP
+#define BN_NSTAMP 8
+extern __device__ unsigned long long jamie_bn_dbg_stamps[4096 * BN_NSTAMP];
+#define BN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) jamie_bn_dbg_stamps[blockIdx.x * BN_NSTAMP + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define BN_STAMPV(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096) jamie_bn_dbg_stamps[blockIdx.x * BN_NSTAMP + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define BN_STAMP(k) do {} while (0)
+#define BN_STAMPV(k, v) do {} while (0)
+#endif
+
 // One strip: columns col0 .. col0 + 15 (those < N; `active` false: the team only takes part in the barriers).
 // The summed pre-activation goes back to slab 0 (read again by the backward pass), the batch statistics to save_mean /
 // save_invstd, the running statistics are updated in place, the activation goes out as fp32 and / or bf16.
@@ -123,6 +135,9 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     const int cq = t & (CQ - 1), rp = t / CQ;
     const int col = col0 + 4 * cq;
     const bool cok = active && col < P.N;             // N % 4 == 0: a quad is wholly in or out
+    BN_STAMP(0);
+    BN_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));
+    BN_STAMPV(6, P.N * 10 + P.nslab);
     const int B = P.B, N = P.N, nslab = P.nslab;
     const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -199,6 +214,10 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < R; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
+#ifdef JAMIE_BN_STAMP
+    if (sum.x == 1.2345e-30f) BN_STAMP(7);      // (keeps the sums live in front of the stamp: the loads have landed)
+    BN_STAMP(1);
+#endif
     float4 mean = col_reduce4<CQ>(sum, sh, t);
     const float fB = (float)B;
     mean.x /= fB; mean.y /= fB; mean.z /= fB; mean.w /= fB;
@@ -213,6 +232,7 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     float4 var = col_reduce4<CQ>(sq, sh, t);
     var.x /= fB; var.y /= fB; var.z /= fB; var.w /= fB;
     const float4 invstd = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
+    BN_STAMP(2);
     if (cok && rp == 0) {
         const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, vv[4] = {var.x, var.y, var.z, var.w};
         const float iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
@@ -253,4 +273,10 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
         v[j] = make_float4(y[0], y[1], y[2], y[3]);
     }
     if (P.out_bf || P.outT_bf) strip_out_bf16x4<R, CQ>(v, P.out_bf, P.outT_bf, tl, B, N, col0, t, cok);
+#ifdef JAMIE_BN_STAMP
+    BN_STAMP(3);
+    __builtin_amdgcn_s_waitcnt(0);           // (vmcnt = lgkmcnt = expcnt = 0: the stores have been acknowledged)
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BN_STAMP(4);
+#endif
 }
