@@ -455,6 +455,8 @@ __global__ __launch_bounds__(128 * CQ, (R <= 4 ? JAMIE_BN_FWD_WAVES : 1)) void b
 // `cs` / `cs_begin`: workgroups cs_begin .. are EXTRA ones that compute column sums (jamie_bn_act_bwd_cs: the decoder's
 // output-bias gradient = column sums of d x_hat rides in the first BatchNorm-backward launch of the step instead of being a
 // launch of its own at the head of the backward pass; 47 short workgroups beside 375 long ones)
+// (two workgroups per CU, 120 VGPRs: limited to one per CU by 84 KB of unused LDS the step takes 10 us longer,
+//  profiles/r03_ab_bn_bwd_one_per_cu_rejected.log -- the opposite of the forward kernel)
 template <int R, int CQ>
 __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, float p_drop, float slope, const uint64_t* rng,
                                                                ColsumGroup cs, int cs_begin, PfRanges pf, int pf_begin) {
