@@ -629,9 +629,10 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
 // instead of two, and the address path, not the balance, sets these kernels' time.  32 columns on 1024 threads (CQ = 8: whole
 // lines per row, 188 workgroups): 592 -> 601 us.  JAMIE_BN_CQ=2 / 8 select them (tuning knob; the transposed bf16 copies are laid
 // out for 16-column strips and always take CQ = 4).
-static int bn_pick_cq(long long strips16, bool needs16) {
+static int bn_pick_cq(long long strips16, bool needs16, bool fwd) {
     (void)strips16;
-    const char* e = getenv("JAMIE_BN_CQ");
+    const char* e = getenv(fwd ? "JAMIE_BN_CQ_FWD" : "JAMIE_BN_CQ_BWD");          // (per direction; JAMIE_BN_CQ: both)
+    if (!e) e = getenv("JAMIE_BN_CQ");
     const int v = e ? atoi(e) : 4;
     return (!needs16 && (v == 2 || v == 8)) ? v : 4;
 }
@@ -678,7 +679,7 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].outT_bf16 != nullptr;
-    int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16) : 4;
+    int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16, true) : 4;
     if (cq == 8 && maxB > BN4_MAXR * BN4_RP) cq = 4;
     if (cq == 2) {                 // 8-column strips: the workgroup ranges of the problems again
         blocks = 0;
@@ -784,7 +785,7 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].dhT_bf16 != nullptr;
-    int cq = wide4 ? bn_pick_cq(blocks, needs16) : 4;
+    int cq = wide4 ? bn_pick_cq(blocks, needs16, false) : 4;
     if (cq == 8 && maxB > BN4_MAXR * BN4_RP) cq = 4;
     if (cq == 2) {
         blocks = 0;
