@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 // kernels AFTER them).  The master weights' store too (ST_NT bit 1; in the first build hipcc had silently dropped the hint from
 // the four scalar nt stores it merged): no difference (r03_ab_adam_p_nt.log), left at the default policy.  Loads (LD_NT bit 0:
 // master weights, bit 1: the bf16 gradient): the GRADIENT non-temporal takes 9 us off the kernel and 12 off the step (178 -> 169,
-// 610 -> 598 us: r03_ab_adam_ldnt.log; it is dead once read); the master weights non-temporal cost the kernel 9 us: LD_NT = 2.
+// 610 -> 598 us: r03_ab_adam_ldnt.log; it is dead once read); the master weights non-temporal cost the kernel 9 us.  Bit 2: the fp32 gradient (fp32 compute mode, fp32 messages) non-temporal as well:
+// config 2 in fp32 1506 -> 1495 us per step, config 5's dimensions 7287 -> 7243 (r03_ab_adam_g32_nt.log): LD_NT = 6.
 // The bf16 weight copy non-temporal or not: no difference once the moments' stores are (W16_NT stays 1).  Starting the streams
 // at the second layer so that the first layer's bf16 weights are written last (state[2]): +5 us, rejected
 // (r03_ab_adam_rotate_rejected.log).
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 #define JAMIE_ADAM_ST_NT 1
 #endif
 #ifndef JAMIE_ADAM_LD_NT
-#define JAMIE_ADAM_LD_NT 2
+#define JAMIE_ADAM_LD_NT 6
 #endif
 template <int U, int T, bool RIDE>
 __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -148,7 +149,12 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
 #endif
                     gg[u] = make_float4(bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y));
                 } else {
+#if JAMIE_ADAM_LD_NT & 4      // (the fp32 gradient: dead once read, like the bf16 one)
+                    gg[u] = make_float4(__builtin_nontemporal_load(&g[4 * i]), __builtin_nontemporal_load(&g[4 * i + 1]),
+                                        __builtin_nontemporal_load(&g[4 * i + 2]), __builtin_nontemporal_load(&g[4 * i + 3]));
+#else
                     gg[u] = g4[i];
+#endif
                 }
             }
         }
