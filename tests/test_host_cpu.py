@@ -398,3 +398,40 @@ def test_f32_split_k_plans_come_from_the_launch_model():
     assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)]) == (F32_CFG_ROWS, [2, 1])         # config 5, d -> 2d
     assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)]) == (F32_CFG_ROWS, [4, 2])         # config 5, 2d -> d
     assert plan_f32_rows(B, [(400, 200), (200, 100)]) == (-1, None)                          # small layers: the library default
+
+
+def test_dp_model_prices_a_timeline_by_hand():
+    """bench.dp_model (the exposure model printed by bench.py --dry-run-world): a replicated and a sharded timeline small enough to
+    price by hand -- a collective starts 35 us after it is issued or 5 us after the one queued before it ends, takes
+    bytes / algorithm bandwidth, and the main stream stalls where it waits."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, bus = 8, bench.ASSUMED_BUS_GBS
+    lat, gap = bench.ASSUMED_COLLECTIVE_LATENCY_US * 1e-3, bench.ASSUMED_COLLECTIVE_GAP_US * 1e-3
+    bw_ar, bw_half = bus * n / (2.0 * (n - 1)), bus * n / (n - 1.0)             # GB/s = MB/ms
+    # replicated: one 30 MB all-reduce announced at 0.30 ms, the step waits at 0.40 ms, a dry step takes 0.60 ms
+    ev = [('message', 30e6, 0.30), ('finish', 0, 0.40), ('step_end', 0, 0.60)]
+    m = bench.dp_model(ev, 0.60, 0.55, n, 2.0, 'fp32_messages')
+    stall = 0.30 + lat + 30.0 / bw_ar - 0.40
+    assert m['optimizer'] == 'replicated'
+    assert m['as_run']['predicted_step_us'] == pytest.approx(1e3 * (0.60 + stall), rel=1e-9)
+    assert m['as_run']['predicted_speedup'] == pytest.approx(n * 0.55 / (0.60 + stall), rel=1e-9)
+    stall2 = 0.30 + lat + 60.0 / bw_ar - 0.40
+    assert m['fp32_messages']['predicted_step_us'] == pytest.approx(1e3 * (0.60 + stall2), rel=1e-9)
+    # the traced step may run longer than the timed one: positions scale with it
+    m2 = bench.dp_model([(k, b, 2 * t) for k, b, t in ev], 0.60, 0.55, n, 2.0, 'fp32_messages')
+    assert m2['as_run']['predicted_step_us'] == pytest.approx(m['as_run']['predicted_step_us'], rel=1e-9)
+    # sharded: the reduce-scatter hides under the backward pass; the norm's all-reduce and the first all-gather do not
+    ev = [('wait:enc0', 0, 0.02), ('reduce_scatter', 10e6, 0.20), ('finish', 0, 0.40), ('all_gather', 10e6, 0.45), ('step_end', 0, 0.50)]
+    m = bench.dp_model(ev, 0.50, 0.55, n, 2.0, 'fp32_messages')
+    assert m['optimizer'] == 'sharded' and m['as_run']['stalls']['gradient_wait_us'] == 0.0
+    assert m['as_run']['stalls']['norm_all_reduce_us'] == pytest.approx(1e3 * lat)
+    # steady state: step length T solves  T = 0.50 + lat + wait,  all-gather issued at 0.45 + lat into the step, needed at T + 0.02
+    ag_end = 0.45 + lat + lat + 10.0 / bw_half          # (relative to the step's start; the wire is idle when it is issued)
+    T = 0.50 + lat
+    wait = max(0.0, ag_end - (T + 0.02))
+    assert m['as_run']['stalls']['forward_waits_us'] == pytest.approx(1e3 * wait, abs=1e-6)
+    assert m['as_run']['predicted_step_us'] == pytest.approx(1e3 * (T + wait), abs=1e-6)
+    assert gap > 0
