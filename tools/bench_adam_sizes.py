@@ -17,6 +17,14 @@ for n in (40345136, 80000000, 120000000, 160000000, 233477632):
     for _ in range(10): nv.clip_adam(p, g, m, v, part, hyper, state, None)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
-    print(f'n = {n:10d}: {us:8.1f} us  {28 * n / us / 1e6:6.2f} TB/s', flush=True)
-    del p, g, m, v
+    print(f'n = {n:10d}: fp32 gradient {us:8.1f} us  {28 * n / us / 1e6:6.2f} TB/s', end='', flush=True)
+    g16, w16 = g.to(torch.bfloat16), torch.zeros(n, device='cuda', dtype=torch.bfloat16)      # bf16 mode: bf16 gradient + bf16 weight copy
+    for _ in range(3): nv.clip_adam(p, g16, m, v, part, hyper, state, w16)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10): nv.clip_adam(p, g16, m, v, part, hyper, state, w16)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    print(f'   bf16 gradient + bf16 weight copy {us:8.1f} us  {28 * n / us / 1e6:6.2f} TB/s', flush=True)
+    del p, g, m, v, g16, w16
     torch.cuda.empty_cache()
