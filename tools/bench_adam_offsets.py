@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from jamie_amd import _native as nv
 nv.require_gpu()
-n = 40345136
+n = int(os.environ.get("N", "40345136"))
 hyper = torch.zeros(16); hyper[8:14] = torch.tensor([1e-3, .9, .999, 1e-8, 1.0, 1.0]); hyper = hyper.cuda()
 state = torch.tensor([0, 1, 0, 0], dtype=torch.int64, device='cuda')
 part = torch.zeros(nv.optim_blocks(n), device='cuda')
@@ -43,7 +43,7 @@ K = 1024
 placements = {'all aligned': (0, 0, 0, 0, 0), '256 B steps': (0, 256, 512, 768, 1024), '1 KB steps': (0, K, 2 * K, 3 * K, 4 * K),
               '4 KB steps': (0, 4 * K, 8 * K, 12 * K, 16 * K), '64 KB steps': (0, 64 * K, 128 * K, 192 * K, 256 * K),
               '512 KB steps': (0, 512 * K, 1024 * K, 1536 * K, 2048 * K), 'odd mix': (0, 4352, 70 * K + 256, 1300 * K + 512, 33 * K)}
-for g16 in (True, False):
+for g16 in ((True,) if os.environ.get("G16_ONLY") else (True, False)):
     for rep in range(2):
         for name, offs in placements.items():
             print(f'g16={int(g16)} {name:14s} {run(offs, g16):7.1f} us', flush=True)
