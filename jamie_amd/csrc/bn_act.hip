@@ -629,12 +629,21 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
 // instead of two, and the address path, not the balance, sets these kernels' time.  32 columns on 1024 threads (CQ = 8: whole
 // lines per row, 188 workgroups): 592 -> 601 us.  JAMIE_BN_CQ=2 / 8 select them (tuning knob; the transposed bf16 copies are laid
 // out for 16-column strips and always take CQ = 4).
+// Forward, round 3: the forward kernel runs ONE workgroup per CU (130 VGPRs), so 16-column strips take ceil(strips / 256) rounds of
+// ~9 us; a 32-column strip costs 1.6 x as much but halves the count.  Where that saves rounds -- the 2d-wide layers of config 2:
+// 375 strips = two rounds against 188 = one -- the 32-column kernel is taken: 20.9 -> 17.3 us per launch, while the d-wide layers
+// (188 strips: one round either way) keep 16 columns (12.6 / 11.1 us against 16.1 / 13.3; profiles/r03_by_grid_bn_fwd_cq8.txt).
+// Backward (two workgroups per CU): 16 columns always (32: +6 us per step).
 static int bn_pick_cq(long long strips16, bool needs16, bool fwd) {
-    (void)strips16;
     const char* e = getenv(fwd ? "JAMIE_BN_CQ_FWD" : "JAMIE_BN_CQ_BWD");          // (per direction; JAMIE_BN_CQ: both)
     if (!e) e = getenv("JAMIE_BN_CQ");
-    const int v = e ? atoi(e) : 4;
-    return (!needs16 && (v == 2 || v == 8)) ? v : 4;
+    if (e) {
+        const int v = atoi(e);
+        return (!needs16 && (v == 2 || v == 8)) ? v : 4;
+    }
+    if (!fwd || needs16) return 4;
+    const long long r16 = (strips16 + 255) / 256, r32 = ((strips16 + 1) / 2 + 255) / 256;
+    return (double)r32 * 1.6 < (double)r16 ? 8 : 4;
 }
 
 static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p_drop, float momentum, float eps, float slope,
