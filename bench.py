@@ -4,9 +4,13 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c5dims] [--no-cpu-baseline]
 
-N > 1 is launched by the driver as
+N > 1 runs one rank per GPU.  Either a launcher starts the ranks,
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
+or plain `python bench.py --gpus N` starts them itself: with WORLD_SIZE unset the parent process -- before it makes any
+GPU call -- checks that N devices are visible (it exits non-zero otherwise: it never prints an N = 1 line for an N > 1
+request), starts N children of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set,
+relays rank 0's JSON line and exits non-zero if any rank fails (`spawn_ranks`).
 One rank per GPU; cells are sharded by rows; every rank trains on B = 512 cells per step (weak scaling)
 and the flat gradient is all-reduced once per step over RCCL.  A "step" is one pass of the hot path over
 one batch: device sampler -> row gather -> forward -> losses -> backward -> (all-reduce) -> clip + Adam.
@@ -38,6 +42,7 @@ DEFAULT_DTYPE = {'c5': 'f32'}
 ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the exposure model (dp_model): stated, not measured
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+LEG_BUDGET_S = 240.0             # N > 1: a sub-record leg (another data-parallel arrangement, timed behind the headline) is abandoned after this long
 
 
 def synth_shard(n_cells, lo, hi, dims, rank, world, device):
@@ -321,6 +326,64 @@ def rccl_record(world, log_dir):
     return rec
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): be the launcher.  Called BEFORE anything
+    touches the GPU (counting devices does not initialise HIP); the children are fresh processes of this script, never an
+    exec of a process that holds the device.  Rank 0's stdout is relayed (the ONE JSON line), every rank's stderr goes to
+    ours.  Returns the exit code: 0 only if every rank exited 0."""
+    import signal
+    import socket
+    import subprocess
+    share = os.environ.get('JAMIE_SHARE_GPU') == '1'           # test hook: the ranks share cuda:0 (jamie_amd/distributed.py)
+    have = torch.cuda.device_count()
+    if have < (1 if share else n):
+        print(f'bench.py: --gpus {n} but {have} GPU(s) visible to this process; refusing to print a line for fewer GPUs '
+              f'than requested', file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')         # dmabuf IPC: what RCCL needs on this pool's hosts
+    base.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    # rank 0's output is read while the ranks run (a full pipe must never block it); a rank that dies leaves the others in a
+    # collective that cannot complete: they are ended (exact pids / their own process groups) after a grace period
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    rc, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at, rc = time.time(), bad[0].returncode
+        if failed_at is not None and time.time() - failed_at > 15.0:
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+    rd.join(10.0)
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f'bench.py: rank {r} exited with code {p.returncode}', file=sys.stderr)
+            rc = rc or p.returncode or 1
+    text = (out0[0] if out0 else b'').decode(errors='replace')
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if rc == 0 and not any(ln.startswith('{') for ln in text.splitlines()):
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -341,10 +404,11 @@ def main():
     ap.add_argument('--dry-run-world', type=int, default=0,
                     help='one GPU: run the per-rank step of an N-rank job with the collectives skipped (message casts, side stream, '
                          'one-pass norm of the "reduced" gradient): the compute-side cost of data parallelism; NOT a benchmark line')
-    ap.add_argument('--dp-optimizer', default='auto', choices=['auto', 'sharded', 'replicated'],
-                    help='N > 1: sharded = reduce-scatter the large gradient regions, clip + Adam over 1/N of the parameters per rank, '
-                         'all-gather the updated weights under the next forward pass (distributed.ShardedGradExchange); replicated = '
-                         'all-reduce + the full update on every rank; auto = sharded where the world size divides the regions')
+    ap.add_argument('--dp-optimizer', default='replicated', choices=['auto', 'sharded', 'replicated'],
+                    help='N > 1: replicated (the headline: north_star\'s ONE all-reduce of the gradient per step + the full update on '
+                         'every rank); sharded = reduce-scatter the large gradient regions, clip + Adam over 1/N of the parameters per '
+                         'rank, all-gather the updated weights under the next forward pass (distributed.ShardedGradExchange; timed '
+                         'behind the headline as the `sharded_optimizer` sub-record); auto = sharded where the world size divides the regions')
     ap.add_argument('--no-f32-record', action='store_true', help='skip the short fp32 (parity configuration) leg')
     ap.add_argument('--pipeline', action='store_true',
                     help='clip + Adam on a second stream under the next forward pass (+2-3 %; default: main stream, so '
@@ -360,6 +424,11 @@ def main():
     args = ap.parse_args()
     if args.dtype is None:
         args.dtype = DEFAULT_DTYPE.get(args.config, 'bf16')
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: start the ranks from here, before this process makes any GPU call
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # RCCL's own account of the communicator it builds (read back into the JSON line at N > 1): init-time log only
     log_dir = None
@@ -370,8 +439,10 @@ def main():
                           NCCL_DEBUG_FILE=os.path.join(log_dir, 'rccl_%h_%p.log'))
     from jamie_amd import distributed as jd
     rank, world, local = jd.init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world > 1 and os.environ.get('JAMIE_SHARE_GPU') != '1' and torch.cuda.device_count() < world:
+        raise SystemExit(f'--gpus {world} but {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     from jamie_amd import _native as nv
@@ -488,7 +559,7 @@ def main():
             step()
         barrier()
     if dp_opt == 'sharded':           # (outside the timed region: the replicated buffers current again, no all-gather left in flight)
-        eng.flush()
+        eng.flush(collective=True)
         barrier()
     ls, total, _ = eng.read_losses()
     if not np.isfinite(total):
@@ -605,20 +676,29 @@ def main():
         # N > 1: the same job in its other data-parallel arrangements, timed right behind the headline on every rank (a step is
         # a collective), so that one invocation reports them all:
         #   grad_comm_f32       (bf16 compute, bf16 messages in the headline) fp32 gradient messages: exact sums, twice the bytes
+        #   sharded_optimizer   (replicated optimiser in the headline) reduce-scatter + 1/N of clip + Adam per rank + all-gather
         #   replicated_optimizer (sharded optimiser in the headline) all-reduce + the full clip + Adam on every rank
         legs = []
         if args.dtype == 'bf16' and comm is not None and args.grad_comm == 'auto':
             legs.append(('grad_comm_f32', None, args.dp_optimizer, 'the same job with fp32 gradient messages (exact sums)'))
         if dp_opt == 'sharded':
             legs.append(('replicated_optimizer', comm, 'replicated', 'the same job with an all-reduce and the full update on every rank'))
+        elif dp_opt == 'replicated' and mode0 == 'replicated' and args.dp_optimizer == 'replicated':
+            legs.append(('sharded_optimizer', comm, 'auto', 'the same job with the sharded optimiser (reduce-scatter, 1/N of clip + Adam '
+                         'per rank, weight all-gather under the next forward pass)'))
         del plan
-        for key, comm2, mode2, note in legs:
+
+        def run_leg(key, comm2, mode2, note):
             torch.manual_seed(666)
             m2 = edModelVar(dims, L, device=dev, pad_features=pad)
             jd.broadcast_flat(m2.flat)
             e2 = TrainEngine(m2, B, lr=1e-3, seed=666 + 7919 * rank, world_size=world, compute_dtype=args.dtype)
             e2.set_kl_anneal(0.5)
             ar2, opt2 = make_exchange(e2, comm2, mode2)
+            if key == 'sharded_optimizer' and opt2 != 'sharded':      # (not available for this job: layer sizes / world size)
+                if rank == 0:
+                    out[key] = {'value': None, 'note': 'the sharded optimiser is not available for this job (falls back to replicated)'}
+                return
             idx2 = torch.zeros(B, dtype=torch.int32, device=dev)
             p2 = e2.make_plan(data, idx2, hi - lo, rep, ar2)
             n2 = max(10, args.steps // 4)
@@ -635,8 +715,30 @@ def main():
             if rank == 0:
                 out[key] = {'value': world * B * n2 / float(tt.item()), 'unit': 'cells/s', 'ms_per_step': 1e3 * float(tt.item()) / n2,
                             'steps': n2, 'grad_allreduce': 'f32' if comm2 is None else 'bf16', 'dp_optimizer': opt2, 'note': note}
-            e2.flush()
-            del p2, e2, m2, ar2
+            e2.flush(collective=True)
+
+        # the headline is measured: a sub-record leg that hangs (a collective one rank never joins) or throws must not lose it
+        import threading
+        leg_state = {'key': None}
+
+        def bail():
+            if rank == 0:
+                out[leg_state['key']] = {'value': None, 'error': f'leg exceeded {LEG_BUDGET_S:.0f} s and was abandoned'}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        for key, comm2, mode2, note in legs:
+            leg_state['key'] = key
+            watchdog = threading.Timer(LEG_BUDGET_S, bail)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                run_leg(key, comm2, mode2, note)
+            except Exception as err:         # noqa: BLE001
+                if rank == 0:
+                    out[key] = {'value': None, 'error': f'{type(err).__name__}: {err}'[:300]}
+            finally:
+                watchdog.cancel()
     if world == 1:
         # free the timed engine's buffers before the side legs
         del plan

@@ -525,9 +525,15 @@ class TrainEngine:
                 nv.current_stream().wait_event(ev)
         self._both(fn)
 
-    def flush(self):
-        """Make torch's current stream wait for the optimiser stream (parameters, Adam moments, bf16 copies)."""
-        if self._zs is not None:
+    def flush(self, collective=False):
+        """Make torch's current stream wait for the optimiser stream (parameters, Adam moments, bf16 copies).  Local by
+        default: with a sharded optimiser whose packed pieces are newer than the replicated buffers it RAISES unless
+        `collective=True` -- gathering them takes all-gathers that every rank must join (gather_sharded_state), so a
+        rank-local flush (a callback on rank 0, an exception handler) must never start them by itself."""
+        if self._zs is not None and self._zs.get('stale'):
+            if not collective:
+                raise nv.JamieHipError('flush(): the sharded optimiser holds state newer than the replicated buffers; call '
+                                       'flush(collective=True) (or gather_sharded_state()) on EVERY rank first')
             self.gather_sharded_state()
         if self.pipeline and self._opt_pending:
             for ev in self._ev_params:
@@ -734,6 +740,8 @@ class TrainEngine:
             return None
         out = []
         for it in items:
+            if it.startswith('W:') and self._zs is not None:
+                continue          # (sharded optimiser: those weights are ARRIVING by all-gather; a rider would read what RCCL writes)
             if it.startswith('W:'):
                 lo, hi = self.m.layout.regions[it[2:]]
                 lo = (lo + 7) // 8 * 8                   # (16-byte aligned in the bf16 copy)
@@ -796,7 +804,7 @@ class TrainEngine:
     # nothing at all.  JAMIE_FUSED_BN=1 switches it on (tools/ab.sh).
     def _fused_bn_ok(self, sk_key, out_key):
         return (self.bf16 and self.fuse_bf16 and self.B <= 512 and self.M <= 4 and self.gcfg.get(sk_key, -1) in (31, 32)
-                and all(n % 4 == 0 for n in self.dims) and out_key not in self.need_T and not self.pipeline
+                and all(n % 4 == 0 for n in self.dims) and out_key not in self.need_T and not self.pipeline and self._zs is None
                 and os.environ.get('JAMIE_FUSED_BN', '0') == '1')
 
     def _fwd_block(self, a_key, lin, h_key, sk_key, layer, out_key, stream_base, noise, kind, j):

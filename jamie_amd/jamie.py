@@ -53,11 +53,14 @@ class JAMIE:
       compute_dtype 'f32' (default: exact-fp32 MFMA, the parity configuration) or 'bf16' (bf16 MFMA GEMMs with
                    fp32 accumulation, master weights, optimiser, BatchNorm and losses; feature counts, latent
                    size and batch size must be multiples of 8)
-      dp_optimizer 'auto' (default), 'sharded' or 'replicated' (distributed runs): sharded = the large gradient regions are
+      dp_optimizer 'replicated' (default), 'sharded' or 'auto' (distributed runs): replicated = ONE all-reduce of the flat
+                   gradient per step and the full update on every rank (the arrangement north_star names; the only one that
+                   has run on more than one GPU over RCCL so far); sharded = the large gradient regions are
                    reduce-scattered, every rank runs clip + Adam over 1/world of the large weight matrices and the updated
-                   weights are all-gathered under the next forward pass (distributed.ShardedGradExchange); replicated =
-                   all-reduce and the full update on every rank; auto = sharded where it applies (batch_step=True, a world
-                   size that divides the regions, no transposed weight copies), else replicated
+                   weights are all-gathered under the next forward pass (distributed.ShardedGradExchange); auto = sharded
+                   where it applies (batch_step=True, a world size that divides the regions, no transposed weight copies),
+                   else replicated.  With the sharded optimiser `save_checkpoint` / evaluation gather the packed state with
+                   collectives: every rank must call them
       grad_comm_dtype 'auto' (default: the compute dtype), 'f32' or 'bf16': precision of the gradient all-reduce
                    messages when distributed (bf16 halves the 4 P bytes exchanged per step)
     """
@@ -67,7 +70,7 @@ class JAMIE:
                  dropout=None, pca_dim=2 * [512], batch_step=True, use_f_tilde=True, use_early_stop=True,
                  min_epochs=2500, min_increment=1e-8, max_steps_without_increment=500, debug=False,
                  log_debug=100, record_loss=True, enable_memory_logging=False, device='cuda',
-                 sampler='auto', distributed=False, compute_dtype='f32', grad_comm_dtype='auto', dp_optimizer='auto',
+                 sampler='auto', distributed=False, compute_dtype='f32', grad_comm_dtype='auto', dp_optimizer='replicated',
                  preprocess='host', checkpoint_path=None, checkpoint_every=0, **kwargs):
         self.match_result = match_result
         self.PF_Ratio = PF_Ratio
@@ -543,12 +546,12 @@ class JAMIE:
                 if streak >= self.max_steps_without_increment and self.use_early_stop:
                     break
             if self.checkpoint_every and self.checkpoint_path and (epoch + 1) % self.checkpoint_every == 0:
-                eng.flush()                      # (every rank: a sharded optimiser gathers its pieces with collectives)
+                eng.flush(collective=True)       # (every rank: a sharded optimiser gathers its pieces with collectives)
                 if world > 1:
                     jd.average_(self.model.bn_flat)
                 if rank == 0:
                     self.save_checkpoint(self.checkpoint_path, epoch + 1, best_running_loss, streak)
-        eng.flush()
+        eng.flush(collective=True)
         if world > 1:
             # BatchNorm running statistics are per-rank during training (no SyncBN: one collective per step); the model
             # that is evaluated / saved carries their average, so every rank returns the same embeddings
@@ -603,7 +606,9 @@ class JAMIE:
 
     def save_checkpoint(self, f, next_epoch, best_running_loss=np.inf, streak=0):
         """Full training state after `next_epoch` epochs: parameters, BatchNorm statistics, both Adam moments, the
-        device step / RNG counters, the host sampler's RNG, the early-stop bookkeeping and the loss history."""
+        device step / RNG counters, the host sampler's RNG, the early-stop bookkeeping and the loss history.  Rank-local:
+        in a distributed run with the sharded optimiser every rank calls `engine.flush(collective=True)` first (the training
+        loop does), else this raises instead of starting collectives on one rank."""
         eng, m = self.engine, self.model
         eng.flush()
         torch.save({'format': 'jamie_amd.ckpt.v2', 'epoch': int(next_epoch), 'input_dim': list(m.input_dim),
@@ -619,6 +624,9 @@ class JAMIE:
     def _load_checkpoint(self, f, eng):
         ck = torch.load(f, weights_only=False)
         m = self.model
+        if ck.get('format') == 'jamie_amd.ckpt.v1':
+            raise ValueError(f'{f}: checkpoint format v1 (round 2) is not supported after the parameter-layout change of '
+                             f'format v2 (the flat buffers are ordered differently); re-train, or load its state_dict with load_model')
         if ck.get('format') != 'jamie_amd.ckpt.v2':
             raise ValueError(f'{f}: not a jamie_amd training checkpoint')
         if list(ck['input_dim']) != list(m.input_dim) or ck['output_dim'] != m.output_dim or ck['batch_size'] != eng.B \

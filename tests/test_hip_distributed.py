@@ -117,13 +117,13 @@ for label in ('replicated', 'sharded'):
         eng.load_batch(data, [idx, idx])
         eng.step(None, None, None, ar)
         if s == 0:                      # (a flush in the middle of training: the run goes on from the gathered state)
-            eng.flush()
+            eng.flush(collective=True)
             first[label] = (model.flat.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone())
     assert eng._direct_now == (mode == 'bf16_msgs_direct'), (label, eng._direct_now)
     plan = eng.make_plan(data, idx, N, False, ar)
     for s in range(2):
         eng.run_plan(plan)
-    eng.flush()
+    eng.flush(collective=True)
     torch.cuda.synchronize()
     assert int(eng.state[1].item()) == 7
     res[label] = (model.flat.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.read_losses()[1])
@@ -160,7 +160,7 @@ torch.distributed.destroy_process_group()
     assert out.count('SHARDED OK') == n, out[-2000:]
 
 
-@pytest.mark.parametrize('variant', ['diag_numpy', 'diag_device_bf16', 'hybrid_sparse'])
+@pytest.mark.parametrize('variant', ['diag_numpy', 'diag_numpy_default', 'diag_device_bf16', 'hybrid_sparse'])
 def test_facade_distributed_is_rank_invariant(tmp_path, variant):
     """JAMIE(distributed=True) with two ranks: 255 cells -> shards of 128 and 127 rows, i.e. 2 vs 1 batches of 64 per epoch
     if every rank used its own shard size (mismatched collective counts = deadlock); early stopping is decided on the
@@ -182,6 +182,8 @@ data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d
 np.random.seed(7 + rank)
 kw = dict(output_dim=8, batch_size=64, epoch_DNN=60, min_epochs=8, min_increment=0.05, max_steps_without_increment=3,
           pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9, distributed=True)
+if variant != 'diag_numpy_default':            # (the facade's default is the replicated optimiser: north_star's one all-reduce)
+    kw.update(dp_optimizer='auto')
 P = None
 if variant == 'diag_device_bf16':
     kw.update(sampler='device', compute_dtype='bf16')
@@ -201,7 +203,7 @@ torch.distributed.all_gather(others, sig)
 assert torch.equal(others[0], others[1]), float((others[0] - others[1]).abs().max())
 opt = 'sharded' if jm.engine._zs is not None else 'replicated'
 # (dp_optimizer='auto': sharded, except in bf16 mode at these small sizes, where the products read transposed weight copies)
-assert opt == ('replicated' if variant == 'diag_device_bf16' else 'sharded'), opt
+assert opt == ('replicated' if variant in ('diag_device_bf16', 'diag_numpy_default') else 'sharded'), opt
 print('FACADE OK', rank, epochs, jm.sampling_method, opt)
 torch.distributed.destroy_process_group()
 ''')
@@ -212,7 +214,7 @@ torch.distributed.destroy_process_group()
 
 
 def test_facade_distributed_sharded_checkpoint_resume_is_bit_identical(tmp_path):
-    """Two ranks, sharded optimiser (the facade's default under distributed=True): 6 epochs with a checkpoint after the 4th ==
+    """Two ranks, sharded optimiser (`dp_optimizer='auto'`): 6 epochs with a checkpoint after the 4th ==
     4 epochs + checkpoint + resume for 2 more.  The checkpoint is written by rank 0 from the replicated buffers after every rank has gathered its pieces
     (parameters, both Adam moments); on resume the packed pieces are cut from the restored buffers."""
     script = tmp_path / 'resume.py'
@@ -227,7 +229,7 @@ N, dims = 640, (72, 40)
 Z = rng.standard_normal((N, 5))
 data = [Z @ rng.standard_normal((5, d)) + .1 * rng.standard_normal((N, d)) for d in dims]
 kw = dict(output_dim=8, batch_size=64, min_epochs=3, pca_dim=None, use_f_tilde=False, log_DNN=10 ** 9, sampler='device',
-          distributed=True, use_early_stop=False)
+          distributed=True, use_early_stop=False, dp_optimizer='auto')
 ck = {str(tmp_path / 'dp.ckpt')!r}
 with contextlib.redirect_stdout(io.StringIO()):
     # (the straight run checkpoints at the same epoch: a checkpoint averages the per-rank BatchNorm statistics in place)
@@ -299,7 +301,14 @@ for label in ('plain', 'sharded'):
     plan = eng.make_plan(data, idx, N, False, ar)
     for s in range(2):
         eng.run_plan(plan)
-    eng.flush()
+    if label == 'sharded':              # a rank-LOCAL flush must not start collectives by itself (ADVICE r3): it raises while stale
+        try:
+            eng.flush()
+            raise AssertionError('local flush() with stale sharded state did not raise')
+        except nv.JamieHipError as err:
+            assert 'EVERY rank' in str(err)
+    eng.flush(collective=True)
+    eng.flush()                         # (nothing stale any more: local and silent)
     torch.cuda.synchronize()
     assert int(eng.state[1].item()) == 5
     res[label] = (model.flat.clone(), eng.exp_avg.clone(), eng.read_losses()[1])

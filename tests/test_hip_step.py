@@ -325,7 +325,17 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and 'cpu_baseline' not in out
     assert np.isfinite(out['final_loss'])
-    # the default at N > 1 is the sharded optimiser; the same job with the replicated one is timed behind it
+    # the headline at N > 1 is north_star's arrangement (ONE all-reduce of the gradient, the full update on every rank); the
+    # same job with the sharded optimiser is timed behind it
+    assert out['config']['dp_optimizer'] == 'replicated' and out['sharded_optimizer']['dp_optimizer'] == 'sharded'
+    assert out['sharded_optimizer']['value'] > 0
+    # ... and the other way round on request
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29576', os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--steps', '6', '--warmup', '2', '--config', 'c1', '--dtype', 'f32', '--dp-optimizer', 'auto'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
     assert out['config']['dp_optimizer'] == 'sharded' and out['replicated_optimizer']['dp_optimizer'] == 'replicated'
     assert out['replicated_optimizer']['value'] > 0
     # bf16 compute at N > 1: the line also carries the same job timed with fp32 gradient messages
@@ -339,6 +349,40 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert out['grad_comm_f32']['grad_allreduce'] == 'f32' and out['grad_comm_f32']['value'] > 0
     # (config 1 in bf16 multiplies with transposed copies of its small weight matrices: the optimiser stays replicated there)
     assert out['grad_comm_f32']['dp_optimizer'] == out['config']['dp_optimizer'] == 'replicated'
+    assert out['sharded_optimizer']['value'] is None and 'not available' in out['sharded_optimizer']['note']
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver invokes it): the parent starts the two ranks itself
+    before it touches the GPU, relays rank 0's ONE JSON line and reports n_gpus = 2; a request for more GPUs than the box
+    has exits non-zero instead of printing a line for fewer; a failing rank makes the whole invocation fail."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env = dict(clean, JAMIE_DIST_BACKEND='gloo', JAMIE_SHARE_GPU='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+                        '--config', 'c1', '--dtype', 'f32'], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['value'] > 0
+    assert out['rccl']['world'] == 2 and out['rccl']['backend'] == 'gloo'
+    assert out['config']['dp_optimizer'] == 'replicated' and np.isfinite(out['final_loss'])
+    # more GPUs than the box has (one): refused, no JSON line
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--config', 'c1'], capture_output=True, text=True, env=clean, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert 'GPU(s) visible' in r.stderr
+    # a rank that fails takes the invocation down with it (the other rank is not left waiting forever)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--config', 'c1', '--batch', '-3'], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
 
 
 def test_bench_config5_path_two_ranks_at_reduced_cells(tmp_path):

@@ -435,3 +435,19 @@ def test_dp_model_prices_a_timeline_by_hand():
     assert m['as_run']['stalls']['forward_waits_us'] == pytest.approx(1e3 * wait, abs=1e-6)
     assert m['as_run']['predicted_step_us'] == pytest.approx(1e3 * (T + wait), abs=1e-6)
     assert gap > 0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher starts its own ranks (tests/test_hip_step.py::test_bench_starts_its_own_ranks
+    on the GPU box); with fewer than N devices visible -- here: none -- it exits non-zero and prints NO JSON line, rather than a
+    line for fewer GPUs than were asked for (the driver invokes it exactly this way)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2'], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode != 0 and 'GPU(s) visible' in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    # a launcher's WORLD_SIZE that contradicts --gpus is refused as well (it used to be accepted when WORLD_SIZE was 1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2'], capture_output=True,
+                       text=True, env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

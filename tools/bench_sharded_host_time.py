@@ -37,6 +37,6 @@ for label in ('one GPU, no exchange', 'sharded exchange (one-rank RCCL group)', 
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f'{label:52s} host {1e6 * (t1 - t0) / n:7.1f} us/step   host + GPU {1e6 * (t2 - t0) / n:7.1f} us/step', flush=True)
-    eng.flush()
+    eng.flush(collective=True)
     del plan, eng, model
 torch.distributed.destroy_process_group()
