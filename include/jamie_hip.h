@@ -338,6 +338,24 @@ int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* 
 int jamie_gemm_bf16_ranges(const jamie_gemm_problem* problems /*host*/, int count, int cfg, const float* g, void* g_bf16,
                            const long long* offsets /*host*/, const long long* lengths /*host*/, int n_ranges, float* partials,
                            int n_partials, uint64_t* state, const jamie_latent_m* fin /*host or NULL*/, void* stream);
+/* The backward products of one Linear layer -- dX = dy W on W [out, in] as stored (b_tr) and dW = dy^T a on the activations as
+ * stored (a_tr + b_tr): the autograd of model.py:151,161,192,197,207 inside jamie.py:734 -- as ONE PERSISTENT launch: `n_wg`
+ * workgroups (one per CU: 4 loader waves stream operands into an LDS ring by LDS-DMA, 8 consumer waves run the MFMAs and the
+ * stores; hand-off through LDS words, no barrier) each work through a static list of 128 x 128 tiles.  Same arithmetic, bit for
+ * bit, as jamie_gemm_bf16 on the same problems (every problem: b_tr, EPI_STORE, no bias, no accumulate; fp32 slabs, fp32 or bf16
+ * (c_bf16) results, optional per-tile sums of squares in `partial`, tile id = m_tile + tiles_m * n_tile).
+ *   jamie_gemm_bf16_ring_plan: the tile lists (host): sched[w * max_items + i] = (problem << 24) | tile, -1 terminated; every
+ *     problem's tiles are cut into 8 contiguous chunks (workgroups w and w + 8 share an XCD) and dealt longest-first to the least
+ *     loaded workgroup of the chunk's XCD.  Depends on the problems' shapes and split-K only: computed once, kept on the device.
+ *   jamie_gemm_bf16_ring: the launch; `sched` is the DEVICE copy of the plan; g .. fin as in jamie_gemm_bf16_ranges (g = NULL: no
+ *     range-norm riders; with riders chunk j is taken by workgroup j before its tiles); `err`: device word, zero on entry, that
+ *     a hand-off poll which gave up (bounded spins; never observed) would set. */
+int jamie_gemm_bf16_ring_plan(const jamie_gemm_problem* problems /*host*/, int count, int n_wg, int max_items /* <= 48 */,
+                              int32_t* sched /*host, n_wg * max_items*/);
+int jamie_gemm_bf16_ring(const jamie_gemm_problem* problems /*host*/, int count, const int32_t* sched /*device*/, int n_wg,
+                         int max_items, const float* g, void* g_bf16, const long long* offsets /*host*/,
+                         const long long* lengths /*host*/, int n_ranges, float* partials, int n_partials, uint64_t* state,
+                         const jamie_latent_m* fin /*host or NULL*/, unsigned* err, void* stream);
 int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,

@@ -130,6 +130,9 @@ EXPORTS = {
     'jamie_gemm_bf16_ranges': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
     'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'jamie_gemm_bf16_ring_plan': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_gemm_bf16_ring': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
     'jamie_gemm_bf16_skinny': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p]),
     'jamie_gemm_bf16_bn': (C.c_int, [C.POINTER(GemmProblem), C.POINTER(BnFwdProblem), C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -355,6 +358,36 @@ def gemm_bf16(problems, cfg=-1, ranges=None):
               partials.numel(), ptr(state), C.pointer(fin) if fin is not None else None, _stream())
         return
     _call('jamie_gemm_bf16', arr, len(problems), cfg, _stream())
+
+
+RING_MAX_ITEMS = 48
+
+
+def gemm_bf16_ring_plan(problems, n_wg, max_items=RING_MAX_ITEMS):
+    """Static tile lists of the persistent backward launch (jamie_gemm_bf16_ring_plan): an int32 device tensor [n_wg, max_items]
+    ((problem << 24) | tile, -1 terminated), or None where the launch does not fit (more than `max_items` tiles per workgroup)."""
+    import numpy as np
+    arr = (GemmProblem * len(problems))(*problems)
+    host = np.empty(n_wg * max_items, dtype=np.int32)
+    rc = load().jamie_gemm_bf16_ring_plan(arr, len(problems), n_wg, max_items, host.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        return None
+    dev = problems[0]._keep[0].device
+    return torch.from_numpy(host).to(dev)
+
+
+def gemm_bf16_ring(problems, sched, n_wg, err, ranges=None, max_items=RING_MAX_ITEMS):
+    """The backward products of one layer (dX on W as stored, dW on the activations as stored) as ONE persistent launch of
+    `n_wg` workgroups (one per CU) that stream their tile lists `sched` through an LDS ring (jamie_gemm_bf16_ring); `err`: a
+    zeroed uint32 device word that a broken hand-off would set; `ranges` as in gemm_bf16."""
+    arr = (GemmProblem * len(problems))(*problems)
+    if ranges is not None:
+        g, g16, rg, partials, state, fin = ranges
+        _call('jamie_gemm_bf16_ring', arr, len(problems), ptr(sched), n_wg, max_items, ptr(g), ptr(g16), rg.off, rg.len, rg.count,
+              ptr(partials), partials.numel(), ptr(state), C.pointer(fin) if fin is not None else None, ptr(err), _stream())
+        return
+    _call('jamie_gemm_bf16_ring', arr, len(problems), ptr(sched), n_wg, max_items, None, None, None, None, 0, None, 0, None, None,
+          ptr(err), _stream())
 
 
 def gemm_bf16_bn(problems, bn_problems, cfg, p_drop, rng, tickets, mode=2, momentum=0.1, eps=1e-5, slope=0.01):

@@ -61,6 +61,28 @@ struct BnFuse {
 };
 
 #define JB_OOB 0xFFFFFFF0u
+
+// Transposed LDS read (ds_read_b64_tr_b16) as INLINE ASM.  The intrinsic (__builtin_amdgcn_ds_read_tr16_b64) carries no memory
+// operand, so hipcc's wait-count pass assumes it may read what a pending LDS-DMA writes and puts `s_waitcnt vmcnt(0)` in front of
+// every one of them: in the k-row-major products (dX, dW) the k-step's just-issued DMA was drained before the first fragment read
+// -- no prefetch at any ring depth, 1.0-1.2 us per k-step against 0.64 us for the same tile with plain ds_read_b128 fragments
+// (profiles/r04_stamps_probe*.log; the .s of round 3's kernel shows the wait right behind the four global_load_lds).  The asm is
+// invisible to that pass; the reads are ordered by the hand-written `s_waitcnt lgkmcnt(0)` in front of the MFMAs that use them
+// (jb_lds_wait, followed by a sched_barrier: cdna_hip_programming.md 5.4 rule 18).
+typedef short jb_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ jb_s16x4 jb_ds_read_tr16(const unsigned char* p) {
+#ifdef JB_TR_INTRINSIC      // A/B build (tools/ab.sh + JAMIE_LIB): round 3's form, the intrinsic (and its vmcnt(0) per k-step)
+    typedef jb_s16x4 __attribute__((address_space(3)))* trp_t;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)p);
+#else
+    typedef const unsigned char __attribute__((address_space(3)))* lp_t;
+    const unsigned addr = (unsigned)reinterpret_cast<size_t>((lp_t)p);
+    jb_s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+#endif
+}
+__device__ __forceinline__ void jb_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // cache policy of the large-tile kernel's B-operand LDS-DMA where B is the WEIGHTS (read once per pass, HBM-cold behind the
 // optimiser): JB_W_NT = 0 default policy; 1 non-temporal (aux = 2) in the forward launches; 2 in the forward and dX launches
 // (MI355X_MICROARCH.md row nt-weights; A/B builds with -DJB_W_NT=.., tools/ab.sh + JAMIE_LIB).  Never for dW (B = activations,
@@ -529,7 +551,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;    // 16-byte chunks per thread (register tail path)
     constexpr int GL = PA + PB;
     static_assert(PA >= 1 && PB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
-    static_assert(GL * (NB - 1) <= 63 && NB >= 2 && NB <= 4, "vmcnt immediate");
+    static_assert(GL * (NB - 1) <= 63 && NB >= 2 && NB <= 5, "vmcnt immediate");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NB * T_SZ];
     float* red = reinterpret_cast<float*>(smem);
 
@@ -670,7 +692,8 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
         if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 2 ? 2 * GL : 0) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 3 ? 3 * GL : 0) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 3 ? 3 * GL : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 4 ? 4 * GL : 0) : "memory");
     };
 
     f32x16 acc[TM][TN];
@@ -700,8 +723,8 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                 const unsigned char* base = As + s * (16 * BM * 2) + 8 * (tp & 1);
                 const int o0 = (8 * h + tq) * (BM * 2) + ((ch ^ ((tq << 2) | ((2 * h) & 3))) << 4);
                 const int o1 = (8 * h + 4 + tq) * (BM * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o1));
+                const s16x4 lo = jb_ds_read_tr16(base + o0);
+                const s16x4 hi = jb_ds_read_tr16(base + o1);
                 af[fb][i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         } else {
@@ -718,8 +741,8 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                 const unsigned char* base = Bs + s * (16 * BN * 2) + 8 * (tp & 1);
                 const int o0 = (8 * h + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h) & 3))) << 4);
                 const int o1 = (8 * h + 4 + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(base + o1));
+                const s16x4 lo = jb_ds_read_tr16(base + o0);
+                const s16x4 hi = jb_ds_read_tr16(base + o1);
                 const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 bf[fb][j] = __builtin_bit_cast(bf16x8, both);
             }
@@ -749,6 +772,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
             // hipcc waits lgkmcnt(0) (not a counted wait) before the first MFMA of a sub-step while LDS-DMA is
             // pending, so the prefetch of the next fragments is issued AFTER that MFMA: the wait then only covers
             // reads that have had a whole sub-step to land
+            if constexpr (decltype(tr)::value) jb_lds_wait();        // (the asm transposed reads: no compiler-side tracking)
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s & 1][0], af[s & 1][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1156,10 +1180,10 @@ static int launch_dma_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_pro
     return jamie_launch_status("jamie_gemm_bf16_bn");
 }
 
-static const int BT[33][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
+static const int BT[35][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
                               {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128},
                               {64, 64}, {128, 128}, {256, 128}, {256, 128}, {64, 64},
-                              {256, 128}, {128, 128}, {128, 128}, {128, 256}, {64, 64}, {256, 256}, {128, 128}, {128, 128}, {256, 128}, {128, 128}};
+                              {256, 128}, {128, 128}, {128, 128}, {128, 256}, {64, 64}, {256, 256}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128}, {128, 128}};
 
 // measured on the config-2 layer shapes (tools/bench_gemm_bf16.py): 64x64x64 (28 us per grouped launch) beats 128x128x64
 // (41 us) at M = 512 / K = 512; the large tile only wins on large squares (742 vs 488 TFLOP/s at 4096^3)
@@ -1229,6 +1253,8 @@ static int gemm_bf16_impl(const jamie_gemm_problem* pr, int count, int cfg, void
         case 30: return launch_dma<128, 128, 4, 2, 2, 0, 1>(pr, count, st);      // 8 waves of 32x64, 2 buffers
         case 31: return launch_dma<256, 128, 4, 4, 3, 0, 1>(pr, count, st);      // 16 waves of 64x32, 3 buffers
         case 32: return launch_dma<128, 128, 2, 4, 3, 0, 1>(pr, count, st);      // 8 waves of 64x32, 3 buffers
+        case 33: return launch_dma<128, 128, 2, 4, 4, 0, 1>(pr, count, st);      // ... 4 buffers (three k-tiles in flight)
+        case 34: return launch_dma<128, 128, 2, 4, 5, 0, 1>(pr, count, st);      // ... 5 buffers = all 160 KB (four in flight)
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_bf16", cfg, 0);
     }
 }
@@ -1275,7 +1301,7 @@ extern "C" int jamie_gemm_bf16_bn(const jamie_gemm_problem* pr, const jamie_bnac
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, 1 << 30);
-    if (cfg > 32 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
+    if (cfg > 34 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_bf16_tile", cfg, 0);
     *bm = BT[cfg][0]; *bn = BT[cfg][1];
     return 0;
 }

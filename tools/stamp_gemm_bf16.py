@@ -111,8 +111,9 @@ def run_bwd_now(name, wshape, sks, cfg=29, iters=13):
 
 
 if os.environ.get('CASES') == 'bwd_now':
-    run_bwd_now('bwd dec2 (dX K = d, dW d x 2d)', [(x, 2 * x) for x in d], (1, 1))
-    run_bwd_now('bwd dec1 (dX K = 2d, dW 2d x d)', [(2 * x, x) for x in d], (2, 1))
+    cfgb = int(os.environ.get('CFGBWD', '29'))        # (32: the same tiles on 8 waves with THREE buffers = one workgroup per CU)
+    run_bwd_now('bwd dec2 (dX K = d, dW d x 2d)', [(x, 2 * x) for x in d], (1, 1), cfg=cfgb)
+    run_bwd_now('bwd dec1 (dX K = 2d, dW 2d x d)', [(2 * x, x) for x in d], (2, 1), cfg=cfgb)
     sys.exit(0)
 for k in os.environ.get('CASES', 'fwd_d2d,fwd_2dd,bwd_dec1,bwd_dec1_r,bwd_enc1,bwd_enc1_r').split(','):
     shapes, cfg, sks = cases[k]
