@@ -463,6 +463,30 @@ int jamie_col_stats(const void* X, int is_f64, long long N, int d, long long ld,
 int jamie_standardise(const void* X, int is_f64, long long N, int d, long long ld, const double* mean, const double* sd,
                       float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel exchange: RCCL collectives over xGMI behind the C ABI (`jamie_allreduce`; 8(e): cells are
+ * sharded by rows over one process per GPU and the flat gradient is summed over the ranks once per step, between
+ * `batch_loss.backward()` (jamie.py:734) and `clip_grad_norm_` (jamie.py:739).  The reference has no distributed code.)
+ * One foreign call per collective, recordable in a launch plan like a kernel launch.  A communicator owns an RCCL communicator
+ * (ncclCommInitRank on the 128-byte id rank 0 made), a HIP stream of its own and 32 completion events ("slots"): a collective
+ * is enqueued on the communicator's stream BEHIND what `stream` has launched so far, so it overlaps the kernels launched after
+ * it; jamie_comm_wait(slot) makes a stream wait (on the device) for the collective last issued with that slot.  librccl is
+ * bound at run time (the instance already loaded in the process, else /opt/rocm/lib): a missing library is an error from these
+ * entry points, not from loading libjamie_hip.so.  dtype: 0 = fp32, 1 = bf16.  Returns 1000 + ncclResult_t for an RCCL error.
+ * ------------------------------------------------------------------------------------------------ */
+int jamie_comm_version(int* version /*host: RCCL's NCCL_VERSION_CODE*/);
+int jamie_comm_unique_id(void* id128 /*host, 128 bytes, out*/);
+int jamie_comm_create(const void* id128 /*host*/, int rank, int world, void** comm /*host, out*/);
+int jamie_comm_destroy(void* comm);
+/* in-place SUM of buf[0 .. count) over the ranks (the 1/world average is applied inside jamie_clip_adam: hyper[13]) */
+int jamie_allreduce(void* comm, void* buf, long long count, int dtype, int slot, void* stream);
+/* recv[0 .. recv_count) = SUM over ranks of send[rank * recv_count .. (rank + 1) * recv_count)  (sharded optimiser: this rank's
+ * piece of a large weight region's gradient) */
+int jamie_reduce_scatter(void* comm, const void* send, void* recv, long long recv_count, int dtype, int slot, void* stream);
+/* recv[r * send_count .. (r + 1) * send_count) = rank r's send[0 .. send_count)  (sharded optimiser: the updated weights) */
+int jamie_all_gather(void* comm, const void* send, void* recv, long long send_count, int dtype, int slot, void* stream);
+int jamie_comm_wait(void* comm, int slot, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,14 @@ EXPORTS = {
     'jamie_gemm_bf16_skinny': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p]),
     'jamie_gemm_bf16_bn': (C.c_int, [C.POINTER(GemmProblem), C.POINTER(BnFwdProblem), C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_comm_version': (C.c_int, [C.POINTER(C.c_int)]),
+    'jamie_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'jamie_comm_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'jamie_comm_destroy': (C.c_int, [C.c_void_p]),
+    'jamie_allreduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_reduce_scatter': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_all_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_comm_wait': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'jamie_cast_transpose': (C.c_int, [C.POINTER(CastProblem), C.c_int, C.c_void_p]),
     'jamie_mse_cast': (C.c_int, [C.POINTER(MseProblem), C.c_int, C.c_void_p]),
     'jamie_bn_act_fwd': (C.c_int, [C.POINTER(BnFwdProblem), C.c_int, C.c_float, C.c_float, C.c_float,
@@ -388,6 +396,55 @@ def gemm_bf16_ring(problems, sched, n_wg, err, ranges=None, max_items=RING_MAX_I
         return
     _call('jamie_gemm_bf16_ring', arr, len(problems), ptr(sched), n_wg, max_items, None, None, None, None, 0, None, 0, None, None,
           ptr(err), _stream())
+
+
+# ---- RCCL collectives behind the C ABI (csrc/comm.hip): one foreign call per collective, recordable in a launch plan ----
+def _comm_dtype(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise JamieHipError(f'collectives take fp32 or bf16 buffers, not {t.dtype}')
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (bytes): made by rank 0, handed to every rank's comm_create."""
+    buf = (C.c_char * 128)()
+    _check(load().jamie_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_create(uid, rank, world):
+    h = C.c_void_p()
+    _check(load().jamie_comm_create(C.c_char_p(uid), int(rank), int(world), C.byref(h)))
+    return h
+
+
+def comm_destroy(h):
+    if h:
+        load().jamie_comm_destroy(h)
+
+
+def comm_version():
+    v = C.c_int()
+    _check(load().jamie_comm_version(C.byref(v)))
+    return v.value
+
+
+def comm_allreduce(h, buf, slot):
+    _call('jamie_allreduce', h, ptr(buf), buf.numel(), _comm_dtype(buf), int(slot), _stream())
+
+
+def comm_reduce_scatter(h, send, recv, slot):
+    _call('jamie_reduce_scatter', h, ptr(send), ptr(recv), recv.numel(), _comm_dtype(recv), int(slot), _stream())
+
+
+def comm_all_gather(h, send, recv, slot):
+    _call('jamie_all_gather', h, ptr(send), ptr(recv), send.numel(), _comm_dtype(send), int(slot), _stream())
+
+
+def comm_wait(h, slot):
+    _call('jamie_comm_wait', h, int(slot), _stream())
 
 
 def gemm_bf16_bn(problems, bn_problems, cfg, p_drop, rng, tickets, mode=2, momentum=0.1, eps=1e-5, slope=0.01):

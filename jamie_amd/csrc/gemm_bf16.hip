@@ -61,6 +61,7 @@ struct BnFuse {
 };
 
 #define JB_OOB 0xFFFFFFF0u
+__device__ __attribute__((aligned(16))) unsigned int jb_zero16[4];      // what the lanes beyond K of a ragged k-tile's LDS-DMA read
 
 // Transposed LDS read (ds_read_b64_tr_b16) as INLINE ASM.  The intrinsic (__builtin_amdgcn_ds_read_tr16_b64) carries no memory
 // operand, so hipcc's wait-count pass assumes it may read what a pending LDS-DMA writes and puts `s_waitcnt vmcnt(0)` in front of
@@ -651,44 +652,30 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                 for (int i = 0; i < PB; ++i)
                     __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
             }
-        } else {   // partial k-tile: masked loads through registers into the same swizzled image
+        } else {
+            // partial last k-tile: the SAME LDS-DMA fill, with the lanes whose 16-byte chunk lies at k >= kend reading a zero
+            // constant instead (the source address of a DMA is per lane; K is a multiple of 8, so a chunk is in or out whole).
+            // Rounds 1-3 staged this tile through registers: plain loads beside pending LDS-DMA make hipcc wait vmcnt(0), i.e.
+            // the ring drained once per tile, on the workgroups whose K slice is the ragged one (the launch's critical path).
 #pragma unroll
-            for (int j = 0; j < LA; ++j) {
-                const int f = tid + j * NT;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (a_tr) {
-                    const int krow = f / (BM / 8), lc = f % (BM / 8);
-                    if (k0 + krow < kend)
-                        v = *reinterpret_cast<const uint4*>(P.A + (long long)(k0 + krow) * P.lda + min(m0 + lc * 8, P.M - 8));
-                    *reinterpret_cast<uint4*>(As + krow * (BM * 2) + ((lc ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)) = v;
-                } else {
-                    const int row = f >> 3, c = f & 7;
-                    const int gm = min(m0 + row, P.M - 1);
-                    if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.A + (long long)gm * P.lda + k0 + c * 8);
-                    *reinterpret_cast<uint4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
-                }
+            for (int i = 0; i < PA; ++i) {
+                const int piece = wid + NW * i;
+                const int kof = a_tr ? 4 * piece + (lane >> 4) : ((pch ^ (((8 * piece + lrow) >> 1) & 7)) * 8);
+                const unsigned short* src = (k0 + kof < kend) ? a_src[i] + k0 * a_kstep : reinterpret_cast<const unsigned short*>(jb_zero16);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + piece * 1024), 16, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const int f = tid + j * NT;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (b_tr) {      // [k][n] rows; k rows beyond the slice are zero (finite: the A tile is zero there too)
-                    const int krow = f / (BN / 8), lc = f % (BN / 8);
-                    if (k0 + krow < kend)
-                        v = *reinterpret_cast<const uint4*>(P.B + (long long)(k0 + krow) * P.ldb + min(n0 + lc * 8, P.N - 8));
-                    *reinterpret_cast<uint4*>(Bs + krow * (BN * 2) + ((lc ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)) = v;
-                } else {
-                    const int row = f >> 3, c = f & 7;
-                    const int gn = min(n0 + row, P.N - 1);
-                    if (k0 + c * 8 < kend) v = *reinterpret_cast<const uint4*>(P.B + (long long)gn * P.ldb + k0 + c * 8);
-                    *reinterpret_cast<uint4*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
-                }
+            for (int i = 0; i < PB; ++i) {
+                const int piece = wid + NW * i;
+                const int kof = b_tr ? 4 * piece + (lane >> 4) : ((pch ^ (((8 * piece + lrow) >> 1) & 7)) * 8);
+                const unsigned short* src = (k0 + kof < kend) ? b_src[i] + k0 * b_kstep : reinterpret_cast<const unsigned short*>(jb_zero16);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + piece * 1024), 16, 0, 0);
             }
         }
     };
-    // my pieces of tile `tile` have landed; `last` = youngest tile issued so far (only full tiles are DMA)
+    // my pieces of tile `tile` have landed; `last` = youngest tile issued so far (every tile is GL LDS-DMA instructions per wave)
     auto wait_tile = [&](int tile, int last) {
-        const int younger = (tile >= nfull) ? 0 : max(0, min(last, nfull - 1) - tile);
+        const int younger = max(0, min(last, nk - 1) - tile);
         if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB > 2 ? 2 * GL : 0) : "memory");

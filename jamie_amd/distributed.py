@@ -38,6 +38,72 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class NativeComm:
+    """The process group's collectives issued through the C ABI (jamie_allreduce / jamie_reduce_scatter / jamie_all_gather in
+    csrc/comm.hip: thin RCCL calls on a communicator of their own, created with an id that rank 0 broadcasts through the
+    existing torch.distributed group): ONE foreign call per collective (~5 us of host time, against ~28 us through
+    torch.distributed) that a recorded launch plan replays like a kernel launch.  Every collective runs on the communicator's
+    own stream behind an event of the issuing stream; `Work.wait()` makes the CURRENT stream wait for it (device side only)."""
+
+    class Work:
+        def __init__(self, comm, slot):
+            self.comm, self.slot = comm, slot
+
+        def wait(self):
+            from . import _native as nv
+            nv.comm_wait(self.comm.h, self.slot)
+
+    def __init__(self, group=None, device=None):
+        from . import _native as nv
+        self.nv = nv
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(nv.comm_unique_id()), dtype=torch.uint8))
+        if self.world > 1:
+            dist.broadcast(uid, src=0, group=group)
+        self.h = nv.comm_create(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+        self._slot = 0
+
+    @staticmethod
+    def available(group=None):
+        """RCCL is the process group's backend (so every rank has a GPU of its own) and the library binds librccl."""
+        try:
+            if not (dist.is_initialized() and dist.get_backend(group) == 'nccl' and torch.cuda.is_available()):
+                return False
+            from . import _native as nv
+            return nv.comm_version() > 0
+        except Exception:       # noqa: BLE001
+            return False
+
+    def _next(self):
+        self._slot = (self._slot + 1) % 32
+        return self._slot
+
+    def all_reduce(self, buf):
+        s = self._next()
+        self.nv.comm_allreduce(self.h, buf, s)
+        return self.Work(self, s)
+
+    def reduce_scatter(self, dst, src):
+        s = self._next()
+        self.nv.comm_reduce_scatter(self.h, src, dst, s)
+        return self.Work(self, s)
+
+    def all_gather(self, out, piece):
+        s = self._next()
+        self.nv.comm_all_gather(self.h, piece, out, s)
+        return self.Work(self, s)
+
+    def close(self):
+        if self.h:
+            self.nv.comm_destroy(self.h)
+            self.h = None
+
+
 class GradAllReduce:
     """All-reduce (SUM) of the flat gradient buffer in `n_buckets` contiguous chunks issued
     asynchronously; the 1/world average is applied inside the clip+Adam kernel (hyper[grad_scale]).
@@ -78,11 +144,21 @@ class OverlappedGradAllReduce:
     (the last region is only ready when the backward pass ends); bf16 halves it, at the precision the bf16 GEMMs
     produced the gradient with.  Every rank receives the same reduced values, so the replicas stay identical."""
 
-    def __init__(self, group=None, min_bytes=16 << 20, comm_dtype=None, dry_run_world=0):
+    def __init__(self, group=None, min_bytes=16 << 20, comm_dtype=None, dry_run_world=0, native=None, single_rank_ok=False):
         """`dry_run_world` = N > 1 (one process, no process group): everything the N-rank step does on the device EXCEPT the
         collectives themselves -- region bookkeeping, message casts, side stream and events -- so that the per-rank compute
-        path of the data-parallel step can be timed on a one-GPU box (bench.py --dry-run-world)."""
+        path of the data-parallel step can be timed on a one-GPU box (bench.py --dry-run-world).
+        `native=True`: issue the collectives through the C ABI (NativeComm: jamie_allreduce & co.) instead of
+        torch.distributed.  OFF by default: measured on a one-rank RCCL group (tools/bench_sharded_host_time.py,
+        profiles/r04_host_time_native_vs_torch.log) the host pays the same ~28 us per collective either way -- it is RCCL's own
+        enqueue, not torch.distributed's wrapper -- and the three extra event calls per collective make the native path slower
+        (replicated exchange 276 against 214 us of host time per step, sharded 574 against 575).  `single_rank_ok`: run the exchange in a ONE-rank process group too (every collective is then a copy on
+        the backend's stream): the one way to put this code path through RCCL itself on a one-GPU box."""
         self.group = group
+        self.single = bool(single_rank_ok) and dist.is_initialized() and dist.get_world_size(group) == 1
+        self.native = None
+        if native:
+            self.native = NativeComm(group)
         self.min_bytes = min_bytes
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.dry = int(dry_run_world) > 1 and self.world == 1
@@ -112,7 +188,7 @@ class OverlappedGradAllReduce:
     def region_done(self, flat, lo, hi, precast=False):
         """`precast`: the region's gradients are already in `message_buffer()` (every region of a step alike): no cast pass,
         no side stream -- the collective is issued where it stands (RCCL orders it behind the launches before it)."""
-        if self.world == 1:
+        if self.world == 1 and not self.single:
             return
         precast = bool(precast)
         pend = self.pending
@@ -132,7 +208,11 @@ class OverlappedGradAllReduce:
 
     def _collective(self, buf, lo, hi):
         """The collective of one message (`buf` = the message bytes of gradient range [lo, hi)); None in a dry run."""
-        return None if self.dry else dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.dry:
+            return None
+        if self.native is not None and buf.is_cuda:
+            return self.native.all_reduce(buf)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _issue(self, flat, lo, hi, precast=False):
         if self.trace is not None and flat.is_cuda:
@@ -221,12 +301,12 @@ class ShardedGradExchange(OverlappedGradAllReduce):
     the large regions is only current on its owner in bf16 mode: TrainEngine.gather_sharded_state() before anything other
     than the next training step reads `model.flat` (evaluation, checkpoints)."""
 
-    def __init__(self, group=None, comm_dtype=None, dry_run_world=0, dry_run_rank=0, single_rank_ok=False):
+    def __init__(self, group=None, comm_dtype=None, dry_run_world=0, dry_run_rank=0, single_rank_ok=False, native=None):
         """`single_rank_ok`: run the whole exchange in a one-rank process group as well (every collective is then a copy on the
         backend's own stream): the one way to put this code path through RCCL itself on a one-GPU box
         (tests/test_hip_distributed.py::test_sharded_exchange_on_rccl_with_one_rank)."""
-        super().__init__(group, min_bytes=1 << 62, comm_dtype=comm_dtype, dry_run_world=dry_run_world)
-        self.single = bool(single_rank_ok) and self.world == 1 and dist.is_initialized()
+        super().__init__(group, min_bytes=1 << 62, comm_dtype=comm_dtype, dry_run_world=dry_run_world, native=native,
+                         single_rank_ok=single_rank_ok)
         self.rank = int(dry_run_rank) if self.dry or not dist.is_initialized() else dist.get_rank(group)
         self.spans = {}              # (lo, hi) of a sharded region -> this rank's packed gradient piece (length (hi - lo) / world)
         self.gathers = {}            # layer name -> pending all-gather of its updated weights
@@ -268,11 +348,16 @@ class ShardedGradExchange(OverlappedGradAllReduce):
             s = dst.numel()
             dst.copy_(buf[self.rank * s:(self.rank + 1) * s])
             return None
+        if self.native is not None and buf.is_cuda:
+            return self.native.reduce_scatter(dst, buf)
         return dist.reduce_scatter_tensor(dst, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def sum_partials(self, t):
         """In-place sum over the ranks of the partial sums of squares of the pieces each rank owns."""
         if not self.dry and (self.world > 1 or self.single):
+            if self.native is not None and t.is_cuda:
+                self.native.all_reduce(t).wait()
+                return
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def gather(self, name, out, piece):
@@ -285,6 +370,9 @@ class ShardedGradExchange(OverlappedGradAllReduce):
         if self.dry:
             s = piece.numel()
             out[self.rank * s:(self.rank + 1) * s].copy_(piece)
+            return
+        if self.native is not None and out.is_cuda:
+            self.gathers[name] = self.native.all_gather(out, piece)
             return
         self.gathers[name] = dist.all_gather_into_tensor(out, piece, group=self.group, async_op=True)
 

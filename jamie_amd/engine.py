@@ -1478,8 +1478,8 @@ class TrainEngine:
             return
         if allreduce is not None:
             # bf16 messages: the reduced gradient stays in the exchange's bf16 buffer; norm and Adam read it there
-            in_place = (getattr(allreduce, 'comm_dtype', None) == torch.bfloat16 and getattr(allreduce, 'world', 1) > 1
-                        and self.grad.is_cuda)
+            in_place = (getattr(allreduce, 'comm_dtype', None) == torch.bfloat16 and self.grad.is_cuda
+                        and (getattr(allreduce, 'world', 1) > 1 or getattr(allreduce, 'single', False)))
             if in_place:
                 fn = lambda: allreduce.finish(copy_back=False)     # noqa: E731
             else:

@@ -329,3 +329,77 @@ torch.distributed.destroy_process_group()
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert 'RCCL ONE OK' in r.stdout
+
+
+def test_native_collectives_one_rank_rccl(tmp_path):
+    """jamie_allreduce / jamie_reduce_scatter / jamie_all_gather / jamie_comm_wait (csrc/comm.hip: RCCL behind the C ABI, the
+    communicator created with an id broadcast through the torch.distributed group) in a one-rank RCCL group -- all a one-GPU box
+    allows: every collective is then a copy, but the binding, the communicator, the stream / event hand-off, the dtypes and the
+    replay from a recorded plan are the N-GPU job's.  Then the replicated exchange (north_star's ONE all-reduce of the gradient)
+    end to end through it, against the same steps through torch.distributed: identical parameters."""
+    script = tmp_path / 'native.py'
+    script.write_text(f'''
+import os, sys, torch
+sys.path.insert(0, {ROOT!r})
+from jamie_amd import distributed as jd, _native as nv
+from jamie_amd.engine import TrainEngine
+from jamie_amd.model import edModelVar
+os.environ.pop('JAMIE_DIST_BACKEND', None)
+torch.cuda.set_device(0)
+torch.distributed.init_process_group('nccl', rank=0, world_size=1)
+dev = torch.device('cuda', 0)
+assert jd.NativeComm.available() and nv.comm_version() >= 20000
+nc = jd.NativeComm()
+g = torch.Generator(device=dev).manual_seed(1)
+for dt in (torch.float32, torch.bfloat16):
+    x = torch.randn(100003, generator=g, device=dev).to(dt)
+    y = x.clone()
+    nc.all_reduce(y).wait()
+    out = torch.zeros(4096, device=dev, dtype=dt)
+    nc.reduce_scatter(out, x[:4096]).wait()
+    full = torch.zeros(4096, device=dev, dtype=dt)
+    nc.all_gather(full, x[4096:8192]).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and torch.equal(out, x[:4096]) and torch.equal(full, x[4096:8192])
+# recorded and replayed like kernel launches
+z = torch.ones(1024, device=dev)
+nv.begin_record()
+w = nc.all_reduce(z)
+w.wait()
+plan = nv.end_record()
+z.mul_(3.0)
+nv.replay(plan)
+torch.cuda.synchronize()
+assert float(z.sum()) == 3072.0 and len(plan) == 2
+try:
+    nv.comm_allreduce(nc.h, torch.zeros(4, device=dev, dtype=torch.float16), 0)
+    raise AssertionError('fp16 accepted')
+except nv.JamieHipError:
+    pass
+# the replicated exchange through the C ABI == through torch.distributed
+dims, L, B, N = (328, 264), 8, 128, 1024
+data = [torch.randn(N, d, generator=g, device=dev) for d in dims]
+res = {{}}
+for native in (True, False):
+    torch.manual_seed(3)
+    model = edModelVar(dims, L, device=dev)
+    eng = TrainEngine(model, B, seed=11, compute_dtype='bf16')
+    ar = jd.OverlappedGradAllReduce(comm_dtype=torch.bfloat16, single_rank_ok=True, native=native, min_bytes=1 << 16)
+    assert (ar.native is not None) == native and ar.single
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    plan = eng.make_plan(data, idx, N, False, ar)
+    for s in range(3):
+        eng.run_plan(plan)
+    assert eng._direct_now
+    torch.cuda.synchronize()
+    res[native] = (model.flat.clone(), eng.read_losses()[1])
+assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
+nc.close()
+print('NATIVE COMM OK')
+torch.distributed.destroy_process_group()
+''')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29588')
+    env.pop('JAMIE_DIST_BACKEND', None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert 'NATIVE COMM OK' in r.stdout

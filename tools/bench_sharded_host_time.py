@@ -14,14 +14,18 @@ from jamie_amd.model import edModelVar
 dev = torch.device('cuda', 0)
 dims, L, B, N = (2000, 1000), 32, 512, 20000
 data = [torch.randn(N, d, device=dev) for d in dims]
-for label in ('one GPU, no exchange', 'sharded exchange (one-rank RCCL group)', 'replicated exchange (dry run: no collective calls)'):
+native = None if '--torch' not in sys.argv else False          # (--torch: the collectives through torch.distributed, round 3's path)
+print('collectives through', 'torch.distributed' if native is False else 'the C ABI (jamie_allreduce / _reduce_scatter / _all_gather)')
+for label in ('one GPU, no exchange', 'sharded exchange (one-rank RCCL group)', 'replicated exchange (one-rank RCCL group)', 'replicated exchange (dry run: no collective calls)'):
     torch.manual_seed(3)
     model = edModelVar(dims, L, device=dev)
     eng = TrainEngine(model, B, seed=11, compute_dtype='bf16', world_size=1)
     ar = None
     if label.startswith('sharded'):
-        ar = jd.ShardedGradExchange(comm_dtype=torch.bfloat16, single_rank_ok=True)
+        ar = jd.ShardedGradExchange(comm_dtype=torch.bfloat16, single_rank_ok=True, native=native)
         eng.enable_sharded_optimizer(ar)
+    elif label.startswith('replicated exchange (one'):
+        ar = jd.OverlappedGradAllReduce(comm_dtype=torch.bfloat16, single_rank_ok=True, native=native)
     elif label.startswith('replicated'):
         ar = jd.OverlappedGradAllReduce(comm_dtype=torch.bfloat16, dry_run_world=8)
     idx = torch.zeros(B, dtype=torch.int32, device=dev)
