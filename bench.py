@@ -421,6 +421,9 @@ def main():
                     help='bf16: transposed weight copies on a side stream under the next forward pass')
     ap.add_argument('--opt-priority', type=int, default=0, help='HIP stream priority of the optimiser stream')
     ap.add_argument('--cpu-budget', type=float, default=24.0)
+    ap.add_argument('--tune', default=os.environ.get('JAMIE_TUNE', ''),
+                    help='A/B measurements (tools/ab.sh): "key=value+key=value" for jamie_amd.engine.tune() -- tile / split-K plans and the '
+                         'older variant of every adopted change (engine.TUNING); also read from JAMIE_TUNE')
     args = ap.parse_args()
     if args.dtype is None:
         args.dtype = DEFAULT_DTYPE.get(args.config, 'bf16')
@@ -449,6 +452,20 @@ def main():
     nv.require_gpu()
     from jamie_amd.engine import TrainEngine, kl_anneal
     from jamie_amd.model import edModelVar
+    if args.tune:
+        from jamie_amd import engine as _eng
+
+        def _val(v):
+            if v in ('True', 'False', 'None'):
+                return {'True': True, 'False': False, 'None': None}[v]
+            try:
+                return int(v)
+            except ValueError:
+                try:
+                    return float(v)
+                except ValueError:
+                    return v
+        _eng.tune(**{k: _val(v) for k, v in (kv.split('=', 1) for kv in args.tune.split('+') if kv)})
 
     n_cells, dims, L = CONFIGS[args.config]
     if args.cells > 0:

@@ -104,13 +104,6 @@ int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* b
  * ------------------------------------------------------------------------------------------- */
 int jamie_gemm_bf16(const jamie_gemm_problem* problems /*host*/, int count, int cfg, void* stream);
 int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm /*host*/, int* bn /*host*/);
-/* Skinny products C[M, N <= 128] (fp32, written once: no slabs) = A[M, K] B[N, K]^T, both operands K-contiguous bf16, long K:
- * the heads' forward product (fc_mus | fc_vars, model.py:180,185) and the decoder-layer-0 input gradient (autograd of
- * model.py:192) on the transposed bf16 weight copy (jamie_latent_m.dec0_WT_bf16).  One workgroup per 32 x 32 output tile, its
- * 16 waves a K slice each, MFMA fragments loaded straight from global memory, partial tiles added in wave order.  Problems:
- * EPI_STORE, splitk <= 1, no transposed-operand flags; bias optional. */
-int jamie_gemm_bf16_skinny(const jamie_gemm_problem* problems /*host*/, int count, void* stream);
-
 typedef struct {
     const float* src;           /* [R, C] fp32, leading dimension ld, nslab slabs slab_stride apart (summed)   */
     void* dst;                  /* bf16 [R, C] (ldd) or NULL                                                    */
@@ -168,19 +161,6 @@ int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* problems /*host*/, int count
 int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* problems /*host*/, int count, float p_drop, float momentum, float eps,
                         float slope, const uint64_t* rng, const void* const* prefetch /*host*/, const long long* prefetch_bytes /*host*/,
                         int n_prefetch, void* stream);
-
-/* Linear forward + BatchNorm1d(train) + LeakyReLU + Dropout in ONE launch (model.py:151-154 and the three sibling blocks; bf16
- * compute mode, large-tile configurations 31 / 32): jamie_gemm_bf16 on `problems` (plain stores of `splitk` fp32 slabs, bias in
- * slab 0) whose workgroups hand their slabs over INSIDE the launch -- write-through stores, one ticket per 128-column strip -- and
- * then run jamie_bn_act_fwd's strip code on `bn[i]` (whose `h`, `nslab`, `slab_stride`, `B`, `N` must describe problem i's own
- * slab buffer; `outT_bf16` must be NULL; batch <= 512, N a multiple of 4): the same bits as the two launches.
- * mode 1: the LAST workgroup of a strip to arrive reduces the whole strip; mode 2: EVERY workgroup of a strip waits (bounded) for
- * the strip's arrivals and takes a share of its eight 16-column sub-strips by arrival order (needs the strip's tiles_m x splitk
- * workgroups co-resident: they are adjacent in dispatch order).  `tickets`: device uint32 [n_tickets >= 4 + 2 * sum_i
- * ceil(N_i / 128)], zero before the first call; the launch leaves it zero; word 0 != 0 afterwards = a bounded wait gave up. */
-int jamie_gemm_bf16_bn(const jamie_gemm_problem* problems /*host*/, const jamie_bnact_fwd_problem* bn /*host*/, int count /* <= 4 */,
-                       int cfg, float p_drop, float momentum, float eps, float slope, const uint64_t* rng, unsigned* tickets,
-                       int n_tickets, int mode, void* stream);
 
 typedef struct {
     float* da; int nslab; long long slab_stride;     /* grad wrt activation out; dh is written to slab 0 */
@@ -338,24 +318,6 @@ int jamie_grad_sqnorm_ranges_fin(const float* g, void* g_bf16, const long long* 
 int jamie_gemm_bf16_ranges(const jamie_gemm_problem* problems /*host*/, int count, int cfg, const float* g, void* g_bf16,
                            const long long* offsets /*host*/, const long long* lengths /*host*/, int n_ranges, float* partials,
                            int n_partials, uint64_t* state, const jamie_latent_m* fin /*host or NULL*/, void* stream);
-/* The backward products of one Linear layer -- dX = dy W on W [out, in] as stored (b_tr) and dW = dy^T a on the activations as
- * stored (a_tr + b_tr): the autograd of model.py:151,161,192,197,207 inside jamie.py:734 -- as ONE PERSISTENT launch: `n_wg`
- * workgroups (one per CU: 4 loader waves stream operands into an LDS ring by LDS-DMA, 8 consumer waves run the MFMAs and the
- * stores; hand-off through LDS words, no barrier) each work through a static list of 128 x 128 tiles.  Same arithmetic, bit for
- * bit, as jamie_gemm_bf16 on the same problems (every problem: b_tr, EPI_STORE, no bias, no accumulate; fp32 slabs, fp32 or bf16
- * (c_bf16) results, optional per-tile sums of squares in `partial`, tile id = m_tile + tiles_m * n_tile).
- *   jamie_gemm_bf16_ring_plan: the tile lists (host): sched[w * max_items + i] = (problem << 24) | tile, -1 terminated; every
- *     problem's tiles are cut into 8 contiguous chunks (workgroups w and w + 8 share an XCD) and dealt longest-first to the least
- *     loaded workgroup of the chunk's XCD.  Depends on the problems' shapes and split-K only: computed once, kept on the device.
- *   jamie_gemm_bf16_ring: the launch; `sched` is the DEVICE copy of the plan; g .. fin as in jamie_gemm_bf16_ranges (g = NULL: no
- *     range-norm riders; with riders chunk j is taken by workgroup j before its tiles); `err`: device word, zero on entry, that
- *     a hand-off poll which gave up (bounded spins; never observed) would set. */
-int jamie_gemm_bf16_ring_plan(const jamie_gemm_problem* problems /*host*/, int count, int n_wg, int max_items /* <= 48 */,
-                              int32_t* sched /*host, n_wg * max_items*/);
-int jamie_gemm_bf16_ring(const jamie_gemm_problem* problems /*host*/, int count, const int32_t* sched /*device*/, int n_wg,
-                         int max_items, const float* g, void* g_bf16, const long long* offsets /*host*/,
-                         const long long* lengths /*host*/, int n_ranges, float* partials, int n_partials, uint64_t* state,
-                         const jamie_latent_m* fin /*host or NULL*/, unsigned* err, void* stream);
 int jamie_sqnorm_range_blocks(const long long* lengths /*host*/, int count);
 int jamie_clip_adam(float* p, const float* g, float* m, float* v, long long n, const float* partials,
                     int n_partials, const float* hyper, const uint64_t* state,
@@ -486,6 +448,50 @@ int jamie_reduce_scatter(void* comm, const void* send, void* recv, long long rec
 /* recv[r * send_count .. (r + 1) * send_count) = rank r's send[0 .. send_count)  (sharded optimiser: the updated weights) */
 int jamie_all_gather(void* comm, const void* send, void* recv, long long send_count, int dtype, int slot, void* stream);
 int jamie_comm_wait(void* comm, int slot, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * EXPERIMENTS (not in libjamie_hip.so; `-DJAMIE_EXPERIMENTS`, jamie_amd.build.build_experiments() -> libjamie_hip_exp.so):
+ * kernels that were built, tested against the product path and measured SLOWER inside the step.  They stay as source so
+ * that the measurements in profiles/ can be repeated (tests/experiments/, tools/); nothing in jamie_amd/engine.py calls them.
+ * ------------------------------------------------------------------------------------------------ */
+#ifdef JAMIE_EXPERIMENTS
+/* Skinny products C[M, N <= 128] (fp32, written once: no slabs) = A[M, K] B[N, K]^T, both operands K-contiguous bf16, long K:
+ * the heads' forward product (fc_mus | fc_vars, model.py:180,185) and the decoder-layer-0 input gradient (autograd of
+ * model.py:192) on the transposed bf16 weight copy (jamie_latent_m.dec0_WT_bf16).  One workgroup per 32 x 32 output tile, its
+ * 16 waves a K slice each, MFMA fragments loaded straight from global memory, partial tiles added in wave order.  Problems:
+ * EPI_STORE, splitk <= 1, no transposed-operand flags; bias optional. */
+int jamie_gemm_bf16_skinny(const jamie_gemm_problem* problems /*host*/, int count, void* stream);
+/* Linear forward + BatchNorm1d(train) + LeakyReLU + Dropout in ONE launch (model.py:151-154 and the three sibling blocks; bf16
+ * compute mode, large-tile configurations 31 / 32): jamie_gemm_bf16 on `problems` (plain stores of `splitk` fp32 slabs, bias in
+ * slab 0) whose workgroups hand their slabs over INSIDE the launch -- write-through stores, one ticket per 128-column strip -- and
+ * then run jamie_bn_act_fwd's strip code on `bn[i]` (whose `h`, `nslab`, `slab_stride`, `B`, `N` must describe problem i's own
+ * slab buffer; `outT_bf16` must be NULL; batch <= 512, N a multiple of 4): the same bits as the two launches.
+ * mode 1: the LAST workgroup of a strip to arrive reduces the whole strip; mode 2: EVERY workgroup of a strip waits (bounded) for
+ * the strip's arrivals and takes a share of its eight 16-column sub-strips by arrival order (needs the strip's tiles_m x splitk
+ * workgroups co-resident: they are adjacent in dispatch order).  `tickets`: device uint32 [n_tickets >= 4 + 2 * sum_i
+ * ceil(N_i / 128)], zero before the first call; the launch leaves it zero; word 0 != 0 afterwards = a bounded wait gave up. */
+int jamie_gemm_bf16_bn(const jamie_gemm_problem* problems /*host*/, const jamie_bnact_fwd_problem* bn /*host*/, int count /* <= 4 */,
+                       int cfg, float p_drop, float momentum, float eps, float slope, const uint64_t* rng, unsigned* tickets,
+                       int n_tickets, int mode, void* stream);
+/* The backward products of one Linear layer -- dX = dy W on W [out, in] as stored (b_tr) and dW = dy^T a on the activations as
+ * stored (a_tr + b_tr): the autograd of model.py:151,161,192,197,207 inside jamie.py:734 -- as ONE PERSISTENT launch: `n_wg`
+ * workgroups (one per CU: 4 loader waves stream operands into an LDS ring by LDS-DMA, 8 consumer waves run the MFMAs and the
+ * stores; hand-off through LDS words, no barrier) each work through a static list of 128 x 128 tiles.  Same arithmetic, bit for
+ * bit, as jamie_gemm_bf16 on the same problems (every problem: b_tr, EPI_STORE, no bias, no accumulate; fp32 slabs, fp32 or bf16
+ * (c_bf16) results, optional per-tile sums of squares in `partial`, tile id = m_tile + tiles_m * n_tile).
+ *   jamie_gemm_bf16_ring_plan: the tile lists (host): sched[w * max_items + i] = (problem << 24) | tile, -1 terminated; every
+ *     problem's tiles are cut into 8 contiguous chunks (workgroups w and w + 8 share an XCD) and dealt longest-first to the least
+ *     loaded workgroup of the chunk's XCD.  Depends on the problems' shapes and split-K only: computed once, kept on the device.
+ *   jamie_gemm_bf16_ring: the launch; `sched` is the DEVICE copy of the plan; g .. fin as in jamie_gemm_bf16_ranges (g = NULL: no
+ *     range-norm riders; with riders chunk j is taken by workgroup j before its tiles); `err`: device word, zero on entry, that
+ *     a hand-off poll which gave up (bounded spins; never observed) would set. */
+int jamie_gemm_bf16_ring_plan(const jamie_gemm_problem* problems /*host*/, int count, int n_wg, int max_items /* <= 48 */,
+                              int32_t* sched /*host, n_wg * max_items*/);
+int jamie_gemm_bf16_ring(const jamie_gemm_problem* problems /*host*/, int count, const int32_t* sched /*device*/, int n_wg,
+                         int max_items, const float* g, void* g_bf16, const long long* offsets /*host*/,
+                         const long long* lengths /*host*/, int n_ranges, float* partials, int n_partials, uint64_t* state,
+                         const jamie_latent_m* fin /*host or NULL*/, unsigned* err, void* stream);
+#endif /* JAMIE_EXPERIMENTS */
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ Drop-in surface (reference Oafish1/JAMIE v4.4.5, jamie/jamie.py): `JAMIE(...).fi
 """
 __version__ = '0.1.0'
 
-from .build import build_library, library_path  # noqa: F401
+from .build import build_experiments, build_library, library_path  # noqa: F401
 
 
 def __getattr__(name):

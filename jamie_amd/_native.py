@@ -130,12 +130,6 @@ EXPORTS = {
     'jamie_gemm_bf16_ranges': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p]),
     'jamie_gemm_bf16_tile': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    'jamie_gemm_bf16_ring_plan': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'jamie_gemm_bf16_ring': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
-    'jamie_gemm_bf16_skinny': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p]),
-    'jamie_gemm_bf16_bn': (C.c_int, [C.POINTER(GemmProblem), C.POINTER(BnFwdProblem), C.c_int, C.c_int, C.c_float, C.c_float,
-                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'jamie_comm_version': (C.c_int, [C.POINTER(C.c_int)]),
     'jamie_comm_unique_id': (C.c_int, [C.c_void_p]),
     'jamie_comm_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -204,6 +198,16 @@ EXPORTS = {
                                  C.c_void_p]),
 }
 
+# entry points of the EXPERIMENTS build only (libjamie_hip_exp.so: jamie_amd/experiments.py binds them when the loaded library has them)
+EXPERIMENT_EXPORTS = {
+    'jamie_gemm_bf16_ring_plan': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'jamie_gemm_bf16_ring': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(LatentM), C.c_void_p, C.c_void_p]),
+    'jamie_gemm_bf16_skinny': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_void_p]),
+    'jamie_gemm_bf16_bn': (C.c_int, [C.POINTER(GemmProblem), C.POINTER(BnFwdProblem), C.c_int, C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+}
+
 _lib = None
 
 
@@ -226,6 +230,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENT_EXPORTS.items():
+        fn = getattr(lib, name, None)    # (present in an experiments build only)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -368,36 +377,6 @@ def gemm_bf16(problems, cfg=-1, ranges=None):
     _call('jamie_gemm_bf16', arr, len(problems), cfg, _stream())
 
 
-RING_MAX_ITEMS = 48
-
-
-def gemm_bf16_ring_plan(problems, n_wg, max_items=RING_MAX_ITEMS):
-    """Static tile lists of the persistent backward launch (jamie_gemm_bf16_ring_plan): an int32 device tensor [n_wg, max_items]
-    ((problem << 24) | tile, -1 terminated), or None where the launch does not fit (more than `max_items` tiles per workgroup)."""
-    import numpy as np
-    arr = (GemmProblem * len(problems))(*problems)
-    host = np.empty(n_wg * max_items, dtype=np.int32)
-    rc = load().jamie_gemm_bf16_ring_plan(arr, len(problems), n_wg, max_items, host.ctypes.data_as(C.c_void_p))
-    if rc != 0:
-        return None
-    dev = problems[0]._keep[0].device
-    return torch.from_numpy(host).to(dev)
-
-
-def gemm_bf16_ring(problems, sched, n_wg, err, ranges=None, max_items=RING_MAX_ITEMS):
-    """The backward products of one layer (dX on W as stored, dW on the activations as stored) as ONE persistent launch of
-    `n_wg` workgroups (one per CU) that stream their tile lists `sched` through an LDS ring (jamie_gemm_bf16_ring); `err`: a
-    zeroed uint32 device word that a broken hand-off would set; `ranges` as in gemm_bf16."""
-    arr = (GemmProblem * len(problems))(*problems)
-    if ranges is not None:
-        g, g16, rg, partials, state, fin = ranges
-        _call('jamie_gemm_bf16_ring', arr, len(problems), ptr(sched), n_wg, max_items, ptr(g), ptr(g16), rg.off, rg.len, rg.count,
-              ptr(partials), partials.numel(), ptr(state), C.pointer(fin) if fin is not None else None, ptr(err), _stream())
-        return
-    _call('jamie_gemm_bf16_ring', arr, len(problems), ptr(sched), n_wg, max_items, None, None, None, None, 0, None, 0, None, None,
-          ptr(err), _stream())
-
-
 # ---- RCCL collectives behind the C ABI (csrc/comm.hip): one foreign call per collective, recordable in a launch plan ----
 def _comm_dtype(t):
     if t.dtype == torch.float32:
@@ -445,21 +424,6 @@ def comm_all_gather(h, send, recv, slot):
 
 def comm_wait(h, slot):
     _call('jamie_comm_wait', h, int(slot), _stream())
-
-
-def gemm_bf16_bn(problems, bn_problems, cfg, p_drop, rng, tickets, mode=2, momentum=0.1, eps=1e-5, slope=0.01):
-    """Linear forward + BatchNorm + LeakyReLU + dropout in one launch (jamie_gemm_bf16_bn): the workgroups of a column strip
-    hand their split-K slabs to each other inside the launch; `tickets`: zeroed int32 device tensor (4 + 2 per 128-column strip)."""
-    arr = (GemmProblem * len(problems))(*problems)
-    barr = (BnFwdProblem * len(bn_problems))(*bn_problems)
-    _call('jamie_gemm_bf16_bn', arr, barr, len(problems), cfg, p_drop, momentum, eps, slope, ptr(rng), ptr(tickets),
-          tickets.numel(), int(mode), _stream())
-
-
-def gemm_bf16_skinny(problems):
-    """C[M, N <= 128] = A B^T on K-contiguous bf16 operands, fp32 written once (jamie_gemm_bf16_skinny)."""
-    arr = (GemmProblem * len(problems))(*problems)
-    _call('jamie_gemm_bf16_skinny', arr, len(problems), _stream())
 
 
 def gemm_bf16_tile(max_m, max_n, cfg=-1):

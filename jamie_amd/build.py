@@ -39,16 +39,33 @@ def build_variant(tag, flags, verbose=False, only=None):
     objs = [os.path.join(odir if (only is None or os.path.basename(s) in only) else OBJ, os.path.basename(s)[:-4] + '.o')
             for s in srcs]
 
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(_HERE, '..', 'include', '*.h'))
+    hnew = max([_mtime(h) for h in headers] + [_mtime(__file__)])
+    stamp = os.path.join(odir, 'FLAGS')
+    fresh = os.path.exists(stamp) and open(stamp).read() == ' '.join(flags)
+
     def cc(so):
-        if only is None or os.path.basename(so[0]) in only:
+        if (only is None or os.path.basename(so[0]) in only) and not (fresh and _mtime(so[1]) >= max(_mtime(so[0]), hnew)):
             subprocess.run([hipcc] + FLAGS + list(flags) + ['-c', so[0], '-o', so[1]], check=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(cc, zip(srcs, objs)))
+    with open(stamp, 'w') as f:
+        f.write(' '.join(flags))
     out = os.path.join(_HERE, f'libjamie_hip_{tag}.so')
-    subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, check=True)
+    if _mtime(out) < max(_mtime(o) for o in objs):
+        subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, check=True)
     if verbose:
         print('built', out)
     return out
+
+
+EXPERIMENT_SOURCES = ['gemm_bf16.hip', 'gemm_bf16_ring.hip', 'skinny.hip', 'bn_act.hip']
+
+
+def build_experiments(verbose=False):
+    """libjamie_hip_exp.so: the product library + the kernels behind `-DJAMIE_EXPERIMENTS` (built, tested, measured slower: see
+    jamie_amd/experiments.py).  Selected with JAMIE_LIB=<its path>; tests/experiments/ and the probe tools use it."""
+    return build_variant('exp', ['-DJAMIE_EXPERIMENTS'], verbose=verbose, only=EXPERIMENT_SOURCES)
 
 
 def build_library(force=False, verbose=False, jobs=None):

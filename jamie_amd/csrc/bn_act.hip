@@ -28,9 +28,7 @@ extern "C" int jamie_debug_bn_stamps(unsigned long long* host_out, int n_blocks)
 // cache policy bits of the float4 kernels' once-read loads (split-K slabs, saved pre-activations, upstream gradients): 2 = nt
 // (they are dead once read; default policy, 0: the step 602.6 instead of 599.4 us on one box, three interleaved rounds,
 // profiles/r03_ab_bn_nt_loads.log)
-#ifndef JAMIE_BN_LD_AUX
 #define JAMIE_BN_LD_AUX 2
-#endif
 
 // Strip order: a problem gets 8 * ceil(strips / 8) workgroups and workgroup lb handles strip (lb & 7) * q + (lb >> 3),
 // q = ceil(strips / 8): blocks are dealt round-robin over the 8 XCDs (lb & 7), so every XCD owns a CONTIGUOUS range of
@@ -400,11 +398,7 @@ __device__ __forceinline__ void col_reduce4x2(float4& a, float4& b, float (*sh2)
 #ifndef BN_PF_UNROLL
 #define BN_PF_UNROLL 4
 #endif
-static int bn_pf_blocks() {         // (tuning knob: JAMIE_PF_BLOCKS)
-    static int n = -1;
-    if (n < 0) { const char* e = getenv("JAMIE_PF_BLOCKS"); n = e ? atoi(e) : BN_PF_BLOCKS; if (n < 1) n = 1; }
-    return n;
-}
+static int bn_pf_blocks() { return BN_PF_BLOCKS; }     // (swept in round 3: 16 / 32 stretch the launch, 128 / 256 no better)
 #define BN_PF_MAX 8
 struct PfRanges { const char* p[BN_PF_MAX]; long long bytes[BN_PF_MAX]; int n; };
 __device__ __forceinline__ void prefetch_range(const char* p, long long bytes, int blk, int nblk) {
@@ -430,9 +424,7 @@ __device__ __forceinline__ void prefetch_block(const PfRanges& r, int blk, int n
 // (A/B knob -DJAMIE_BN_FWD_WAVES=4: at most 128 VGPRs for R = 4, i.e. two 512-thread workgroups per CU instead of one -- the
 //  compiler's own allocation is 130 registers; measured slower, also with the second-slot workgroups holding their loads back
 //  by 3-6 us: DESIGN.md §4, profiles/r03_stamps_bn_fwd*.log, r03_ab_bn_stagger_rejected.log)
-#ifndef JAMIE_BN_FWD_WAVES
 #define JAMIE_BN_FWD_WAVES 1
-#endif
 template <int R, int CQ>
 __global__ __launch_bounds__(128 * CQ, (R <= 4 ? JAMIE_BN_FWD_WAVES : 1)) void bn_act_fwd4_kernel(BnFwdGroup g, float p_drop, float momentum, float eps,
                                                                float slope, const uint64_t* rng, PfRanges pf, int n_main) {
@@ -627,7 +619,7 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
 // workgroups, the others one -- and measured: the step 595 -> 639 us (profiles/r03_ab_bn_strip_width_rejected.log): a
 // wave-instruction then covers 32 rows x 32 bytes instead of 16 rows x 64, every 128-byte line is fetched by four workgroups
 // instead of two, and the address path, not the balance, sets these kernels' time.  32 columns on 1024 threads (CQ = 8: whole
-// lines per row, 188 workgroups): 592 -> 601 us.  JAMIE_BN_CQ=2 / 8 select them (tuning knob; the transposed bf16 copies are laid
+// lines per row, 188 workgroups): 592 -> 601 us.  (The transposed bf16 copies are laid
 // out for 16-column strips and always take CQ = 4).
 // Forward, round 3: the forward kernel runs ONE workgroup per CU (130 VGPRs), so 16-column strips take ceil(strips / 256) rounds of
 // ~9 us; a 32-column strip costs 1.6 x as much but halves the count.  Where that saves rounds -- the 2d-wide layers of config 2:
@@ -635,12 +627,14 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
 // (188 strips: one round either way) keep 16 columns (12.6 / 11.1 us against 16.1 / 13.3; profiles/r03_by_grid_bn_fwd_cq8.txt).
 // Backward (two workgroups per CU): 16 columns always (32: +6 us per step).
 static int bn_pick_cq(long long strips16, bool needs16, bool fwd) {
-    const char* e = getenv(fwd ? "JAMIE_BN_CQ_FWD" : "JAMIE_BN_CQ_BWD");          // (per direction; JAMIE_BN_CQ: both)
+#ifdef JAMIE_EXPERIMENTS      // (the experiments build's tests compare against 16-column strips: JAMIE_BN_CQ=4)
+    const char* e = getenv(fwd ? "JAMIE_BN_CQ_FWD" : "JAMIE_BN_CQ_BWD");
     if (!e) e = getenv("JAMIE_BN_CQ");
     if (e) {
         const int v = atoi(e);
         return (!needs16 && (v == 2 || v == 8)) ? v : 4;
     }
+#endif
     if (!fwd || needs16) return 4;
     const long long r16 = (strips16 + 255) / 256, r32 = ((strips16 + 1) / 2 + 255) / 256;
     return (double)r32 * 1.6 < (double)r16 ? 8 : 4;

@@ -11,9 +11,6 @@
 
 #define BN_CW 16
 // the summed pre-activation (next read by the backward pass) stored non-temporally: -2 us per step (r03_ab_more_nt.log)
-#ifndef JAMIE_BN_HSUM_NT
-#define JAMIE_BN_HSUM_NT 1
-#endif
 #define BN_OOB 0xFFFFFFF0u
 #define BN4_RP 128
 #define BN4_MAXR 4      // rows per thread of the default instance (B <= 512); the kernels are templates on R (4 or 8: B <= 1024)
@@ -251,14 +248,10 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < B && cok) {
             const long long o = (long long)row * N + col;
-#if JAMIE_BN_HSUM_NT
-            if (nslab > 1) {
+            if (nslab > 1) {      // (the summed pre-activation: next read by the backward pass, stored non-temporally)
                 __builtin_nontemporal_store(v[j].x, P.h + o); __builtin_nontemporal_store(v[j].y, P.h + o + 1);
                 __builtin_nontemporal_store(v[j].z, P.h + o + 2); __builtin_nontemporal_store(v[j].w, P.h + o + 3);
             }
-#else
-            if (nslab > 1) *reinterpret_cast<float4*>(P.h + o) = v[j];
-#endif
             const float hv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
             const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};
 #pragma unroll

@@ -120,17 +120,9 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-#ifdef JAMIE_OLD_REDUCE      // A/B build (tools/ab.sh): the round-1 reductions (ds_bpermute butterflies, fencing barriers)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-#define JAMIE_RED_BARRIER() __syncthreads()
-#else
+// (round 1's reductions -- ds_bpermute butterflies, fencing barriers -- cost 3.5 us in clip + Adam alone: profiles/r02_ab_dpp_reductions*.log)
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 #define JAMIE_RED_BARRIER() lds_barrier()
-#endif
 
 // block-wide sum; `red` is >= (blockDim.x/64) floats of LDS; result valid in every thread.  Its barriers order LDS only.
 __device__ __forceinline__ float block_sum(float v, float* red) {

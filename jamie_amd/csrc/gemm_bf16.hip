@@ -12,11 +12,13 @@
 // ragged problems of small models) still read transposed copies made by the cast / BatchNorm kernels.
 //
 // Three kernels: gemm_bf16_kernel (register-staged, padded LDS rows: fallback), gemm_bf16_dma_kernel (LDS-DMA, 64x64 tiles)
-// and gemm_bf16_dma2_kernel (LDS-DMA, 256x128 / 128x128 tiles, hand-counted vmcnt; optional riders; optional in-launch split-K
-// reduction + BatchNorm forward: jamie_gemm_bf16_bn).  Grouped launch, XCD mapping, split-K slabs as in gemm_f32.hip.
+// and gemm_bf16_dma2_kernel (LDS-DMA, 256x128 / 128x128 tiles, hand-counted vmcnt; optional riders; in the experiments build
+// (-DJAMIE_EXPERIMENTS) also the in-launch split-K reduction + BatchNorm forward, jamie_gemm_bf16_bn: measured slower, round 3).  Grouped launch, XCD mapping, split-K slabs as in gemm_f32.hip.
 #include "common.h"
 #include "range_norm.h"
+#ifdef JAMIE_EXPERIMENTS
 #include "bn_fwd_strip.h"
+#endif
 #include <type_traits>
 
 // diagnostic ablations (timing only, wrong results): 1 = no global loads in the k-loop, 2 = no MFMAs,
@@ -46,6 +48,7 @@ struct GemmBDev {
 };
 struct GemmBGroup { GemmBDev p[JAMIE_MAX_GEMM_GROUP]; int count; };
 
+#ifdef JAMIE_EXPERIMENTS
 // In-launch split-K reduction + BatchNorm forward (jamie_gemm_bf16_bn): per problem the BatchNorm strip descriptor whose `h` is
 // the GEMM's slab buffer, and the hand-off state: tickets[0..3] = error block (word 0: a bounded wait gave up), then TWO words
 // per column strip of every problem (arrivals, departures), zero at allocation and zero again when a launch ends.
@@ -59,6 +62,9 @@ struct BnFuse {
     int mode;                 // 1: the LAST workgroup of a strip to arrive reduces the strip; 2: EVERY workgroup waits for its
                               // strip's arrivals and takes a share of the 16-column sub-strips (by arrival order)
 };
+#else
+struct BnFuse;
+#endif
 
 #define JB_OOB 0xFFFFFFF0u
 __device__ __attribute__((aligned(16))) unsigned int jb_zero16[4];      // what the lanes beyond K of a ragged k-tile's LDS-DMA read
@@ -72,36 +78,17 @@ __device__ __attribute__((aligned(16))) unsigned int jb_zero16[4];      // what 
 // (jb_lds_wait, followed by a sched_barrier: cdna_hip_programming.md 5.4 rule 18).
 typedef short jb_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ jb_s16x4 jb_ds_read_tr16(const unsigned char* p) {
-#ifdef JB_TR_INTRINSIC      // A/B build (tools/ab.sh + JAMIE_LIB): round 3's form, the intrinsic (and its vmcnt(0) per k-step)
-    typedef jb_s16x4 __attribute__((address_space(3)))* trp_t;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)p);
-#else
     typedef const unsigned char __attribute__((address_space(3)))* lp_t;
     const unsigned addr = (unsigned)reinterpret_cast<size_t>((lp_t)p);
     jb_s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
-#endif
 }
 __device__ __forceinline__ void jb_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// cache policy of the large-tile kernel's B-operand LDS-DMA where B is the WEIGHTS (read once per pass, HBM-cold behind the
-// optimiser): JB_W_NT = 0 default policy; 1 non-temporal (aux = 2) in the forward launches; 2 in the forward and dX launches
-// (MI355X_MICROARCH.md row nt-weights; A/B builds with -DJB_W_NT=.., tools/ab.sh + JAMIE_LIB).  Never for dW (B = activations,
-// re-read by every tile row): on ALL launches the step took 681 instead of 635 us (profiles/r03_ab_nt_weights_rejected.log).
-#ifndef JB_LONG_PRIO
-#define JB_LONG_PRIO 0
-#endif
-#ifndef JB_LONG_NK
-#define JB_LONG_NK 12
-#endif
-#ifndef JB_W_NT
-#define JB_W_NT 0
-#endif
-// A/B build -DJB_SLAB_SC1=1: the large-tile kernel's plain fp32 stores (split-K slabs, read by the next launch) go out
-// write-through, so that the launch leaves no dirty lines for the kernel boundary to write back
-#ifndef JB_SLAB_SC1
-#define JB_SLAB_SC1 0
-#endif
+// Measured and rejected in round 3 (the A/B builds are gone; logs in profiles/): non-temporal LDS-DMA of the weights operand
+// (r03_ab_nt_weights_rejected.log: forward launches 7 % faster, the step 18-45 us slower: the backward pass finds the weights in
+// the Infinity Cache), issue priority for the long tiles of a grouped launch (r03_ab_long_tile_priority_rejected.log), write-through
+// split-K slab stores (r03_ab_slab_sc1_rejected.log).
 
 // Diagnostic build only (-DJAMIE_GEMMB_STAMP, tools/stamp_gemm_bf16.sh): thread 0 of every workgroup of the large-tile
 // kernel writes s_memrealtime (100 MHz) at entry / tile 0 published / k-loop done / stores issued into a buffer of its
@@ -589,11 +576,6 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     const int kend = min(P.K, kbeg + P.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
-#if JB_LONG_PRIO
-    // the long tiles of a grouped launch (dX: K = features) are its critical path: their waves win the issue arbitration against
-    // the short dW tiles (K = batch) they share a CU with (A/B: -DJB_LONG_PRIO=n, threshold JB_LONG_NK k-steps)
-    if (nk >= JB_LONG_NK) __builtin_amdgcn_s_setprio(JB_LONG_PRIO);
-#endif
     JB_STAMPV(4, pi * 1000 + nk);
     JB_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));   // XCC_ID, HW_ID cu/se bits
 
@@ -621,7 +603,6 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     // both DMA fills and the 32x32x16 transposed reads are conflict-free (cdna_hip_programming.md T10 (b)).
     const bool b_tr = TRM != 0 && P.b_tr != 0;
     const long long b_kstep = b_tr ? (long long)P.ldb : 1;
-    const bool w_nt = JB_W_NT >= 1 && !a_tr && (JB_W_NT >= 2 || !b_tr) && (TRM == 0 || b_tr);
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         if (b_tr) {
@@ -643,15 +624,9 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
 #pragma unroll
             for (int i = 0; i < PA; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0 * a_kstep), (lptr_t)(As + (wid + NW * i) * 1024), 16, 0, 0);
-            if (w_nt) {          // (wave-uniform) the weights of a forward / dX product: streamed, see JB_W_NT
 #pragma unroll
-                for (int i = 0; i < PB; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 2);
-            } else {
-#pragma unroll
-                for (int i = 0; i < PB; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
-            }
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0 * b_kstep), (lptr_t)(Bs + (wid + NW * i) * 1024), 16, 0, 0);
         } else {
             // partial last k-tile: the SAME LDS-DMA fill, with the lanes whose 16-byte chunk lies at k >= kend reading a zero
             // constant instead (the source address of a DMA is per lane; K is a multiple of 8, so a chunk is in or out whole).
@@ -860,7 +835,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                                       // L2 / Infinity Cache, whose write-back ran into the optimiser kernel (229 -> 208 us)
                     __builtin_nontemporal_store(v[0], cp); __builtin_nontemporal_store(v[1], cp + 1);
                     __builtin_nontemporal_store(v[2], cp + 2); __builtin_nontemporal_store(v[3], cp + 3);
-                } else if constexpr (FUSE || JB_SLAB_SC1 != 0) {
+                } else if constexpr (FUSE) {
                     // write-through (sc1): the slab is read by another workgroup of THIS launch (publish-large: no release
                     // fence, no dirty lines to write back before the ticket)
                     const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -899,6 +874,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
         const float tot = block_sum(local, red);
         if (tid == 0) P.partial[t] = tot * P.pscale;
     }
+#ifdef JAMIE_EXPERIMENTS
     if constexpr (FUSE) {
         // ---- hand-off (cdna_hip_programming.md, 'In-launch split-K reduction', sc1 form): every storing wave drains its
         // write-through stores, workgroup barrier, ONE lane takes the strip's ticket (relaxed, agent scope); the reducing
@@ -957,6 +933,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
         JB_STAMP(7);
         return;
     }
+#endif
 #ifdef JAMIE_GEMMB_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -964,11 +941,13 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
 #endif
 }
 
+#ifdef JAMIE_EXPERIMENTS
 // the large-tile kernel with the in-launch split-K reduction + BatchNorm forward (forward launches: no k-row-major operands)
 template <int BM, int BN, int WM, int WN, int TAG, int NB>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_bn_kernel(GemmBGroup g, BnFuse f) {
     gemm_bf16_dma2_body<BM, BN, WM, WN, TAG, NB, 0, true>(g, &f);
 }
+#endif
 
 template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma2_kernel(GemmBGroup g) {
@@ -1107,6 +1086,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, c
     return jamie_launch_status("jamie_gemm_bf16");
 }
 
+#ifdef JAMIE_EXPERIMENTS
 template <int BM, int BN, int WM, int WN, int NB>
 static int launch_dma_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_problem* bn, int count, float p_drop, float momentum,
                          float eps, float slope, const uint64_t* rng, unsigned* tickets, int n_tickets, int mode, hipStream_t st) {
@@ -1166,6 +1146,7 @@ static int launch_dma_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_pro
     hipLaunchKernelGGL((gemm_bf16_dma2_bn_kernel<BM, BN, WM, WN, 1, NB>), dim3(tiles), dim3(WM * WN * 64), 0, st, g, f);
     return jamie_launch_status("jamie_gemm_bf16_bn");
 }
+#endif
 
 static const int BT[35][2] = {{128, 128}, {64, 64}, {64, 64}, {32, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64},
                               {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128},
@@ -1260,6 +1241,7 @@ extern "C" int jamie_gemm_bf16_ranges(const jamie_gemm_problem* pr, int count, i
     return gemm_bf16_impl(pr, count, cfg, stream, &rr, blocks);
 }
 
+#ifdef JAMIE_EXPERIMENTS
 extern "C" int jamie_gemm_bf16_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_problem* bn, int count, int cfg,
                                   float p_drop, float momentum, float eps, float slope, const uint64_t* rng, unsigned* tickets,
                                   int n_tickets, int mode, void* stream) {
@@ -1285,6 +1267,7 @@ extern "C" int jamie_gemm_bf16_bn(const jamie_gemm_problem* pr, const jamie_bnac
         default: return jamie_fail(-1, "%s: tile configuration 31 or 32 [%lld %lld]", "jamie_gemm_bf16_bn", cfg, 0);
     }
 }
+#endif
 
 extern "C" int jamie_gemm_bf16_tile(int max_m, int max_n, int cfg, int* bm, int* bn) {
     if (cfg < 0) cfg = pick_cfg_b(max_m, max_n, 1 << 30);
@@ -1344,17 +1327,10 @@ extern "C" int jamie_cast_transpose(const jamie_cast_problem* pr, int count, voi
 // products read.  Same 64x64 LDS-transposing layout as cast_transpose_kernel.
 // ------------------------------------------------------------------------------------------------
 // once-read loads of the MSE launch (the x_hat slabs, the batch) non-temporal: -2.5 us per step (profiles/r03_ab_more_nt.log;
-// -DJB_MSE_NT=0: default policy)
-#ifndef JB_MSE_NT
-#define JB_MSE_NT 1
-#endif
+// default policy: +2.5)
 __device__ __forceinline__ float4 JB_MSE_LD4(const float* p) {
-#if JB_MSE_NT
     return make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
                        __builtin_nontemporal_load(p + 3));
-#else
-    return *reinterpret_cast<const float4*>(p);
-#endif
 }
 struct MseDev { const float* y; const float* x; float* d; unsigned short* dst; unsigned short* dstT; float* partial;
                 long long slab_stride; int R, C, nslab, blk_begin, tiles_c; float scale, pscale; };

@@ -21,6 +21,8 @@
 //   * the tile lists are balanced on the host by k-steps (longest first within an XCD's share of every problem, so the
 //     panels a tile shares with its neighbours stay in one L2).
 // Results are bit-identical to jamie_gemm_bf16 (same MFMA order inside a tile; the partial k-step adds exact zeros).
+// (experiments build only: -DJAMIE_EXPERIMENTS, jamie_amd.build.build_experiments(); not in the product library)
+#ifdef JAMIE_EXPERIMENTS
 #include "common.h"
 #include "range_norm.h"
 #include <algorithm>
@@ -568,3 +570,5 @@ extern "C" int jamie_gemm_bf16_ring(const jamie_gemm_problem* pr, int count, con
     hipLaunchKernelGGL((gemm_bf16_ring_kernel<RG_NB, RG_LA>), dim3(n_wg), dim3((RG_NLOAD + 8) * 64), 0, (hipStream_t)stream, g, sched, max_items, rr, blocks, err);
     return jamie_launch_status("jamie_gemm_bf16_ring");
 }
+
+#endif  // JAMIE_EXPERIMENTS

@@ -80,15 +80,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_bf16_kernel(const unsigned sh
 // The bf16 weight copy non-temporal or not: no difference once the moments' stores are (W16_NT stays 1).  Starting the streams
 // at the second layer so that the first layer's bf16 weights are written last (state[2]): +5 us, rejected
 // (r03_ab_adam_rotate_rejected.log).
-#ifndef JAMIE_ADAM_W16_NT
-#define JAMIE_ADAM_W16_NT 1
-#endif
-#ifndef JAMIE_ADAM_ST_NT
-#define JAMIE_ADAM_ST_NT 1
-#endif
-#ifndef JAMIE_ADAM_LD_NT
-#define JAMIE_ADAM_LD_NT 6
-#endif
+// (The A/B builds behind these measurements -- -DJAMIE_ADAM_{ST,LD,W16}_NT -- are gone; the adopted policies are written out below.)
 template <int U, int T, bool RIDE>
 __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
@@ -130,31 +122,19 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
                 if (i >= n4) i -= n4;
                 // the moments are read once per step: non-temporal loads (in the step -2..-4 us; the master weights and the
                 // stores of all three measured no better streamed)
-#if JAMIE_ADAM_LD_NT & 1      // (A/B builds: master weights (1) and / or gradient (2) loaded non-temporally as well)
-                pp[u] = make_float4(__builtin_nontemporal_load(&p[4 * i]), __builtin_nontemporal_load(&p[4 * i + 1]),
-                                    __builtin_nontemporal_load(&p[4 * i + 2]), __builtin_nontemporal_load(&p[4 * i + 3]));
-#else
                 pp[u] = p4[i];
-#endif
                 mm[u] = make_float4(__builtin_nontemporal_load(&m[4 * i]), __builtin_nontemporal_load(&m[4 * i + 1]),
                                     __builtin_nontemporal_load(&m[4 * i + 2]), __builtin_nontemporal_load(&m[4 * i + 3]));
                 vv[u] = make_float4(__builtin_nontemporal_load(&v[4 * i]), __builtin_nontemporal_load(&v[4 * i + 1]),
                                     __builtin_nontemporal_load(&v[4 * i + 2]), __builtin_nontemporal_load(&v[4 * i + 3]));
                 if (g_bf16) {      // reduced gradient read straight from the bf16 message buffer (no fp32 copy-back pass)
-#if JAMIE_ADAM_LD_NT & 2
                     const unsigned long long q64 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(g_bf16) + i);
                     const uint2 q = make_uint2((unsigned)q64, (unsigned)(q64 >> 32));
-#else
-                    const uint2 q = reinterpret_cast<const uint2*>(g_bf16)[i];
-#endif
                     gg[u] = make_float4(bf16_lo(q.x), bf16_hi(q.x), bf16_lo(q.y), bf16_hi(q.y));
                 } else {
-#if JAMIE_ADAM_LD_NT & 4      // (the fp32 gradient: dead once read, like the bf16 one)
+                    // (the fp32 gradient: dead once read, like the bf16 one)
                     gg[u] = make_float4(__builtin_nontemporal_load(&g[4 * i]), __builtin_nontemporal_load(&g[4 * i + 1]),
                                         __builtin_nontemporal_load(&g[4 * i + 2]), __builtin_nontemporal_load(&g[4 * i + 3]));
-#else
-                    gg[u] = g4[i];
-#endif
                 }
             }
         }
@@ -206,19 +186,11 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
             upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
             upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z);
             upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
-#if JAMIE_ADAM_ST_NT      // the fp32 streams stored non-temporally (whole 16-byte vectors: four scalar nt stores to p lost the hint
-                          // when hipcc merged them next to the plain vector load of the same address)
+            // the moments stored non-temporally (whole 16-byte vectors), the master weights through the caches
             typedef float adam_f4 __attribute__((ext_vector_type(4)));
-#if JAMIE_ADAM_ST_NT & 2
-            __builtin_nontemporal_store((adam_f4){pp[u].x, pp[u].y, pp[u].z, pp[u].w}, reinterpret_cast<adam_f4*>(p) + i);
-#else
             p4[i] = pp[u];
-#endif
             __builtin_nontemporal_store((adam_f4){mm[u].x, mm[u].y, mm[u].z, mm[u].w}, reinterpret_cast<adam_f4*>(m) + i);
             __builtin_nontemporal_store((adam_f4){vv[u].x, vv[u].y, vv[u].z, vv[u].w}, reinterpret_cast<adam_f4*>(v) + i);
-#else
-            p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
-#endif
             if (p_bf16) {   // bf16 copy of the updated master weights for the bf16-compute GEMMs (+2 B/parameter)
                 const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].x), b1 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].y);
                 const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].z), b3 = __builtin_bit_cast(unsigned short, (__bf16)pp[u].w);
@@ -227,11 +199,7 @@ __global__ __launch_bounds__(T) void clip_adam_kernel(float* __restrict__ p, con
                 // measured no better with nt)
                 const unsigned long long pk = (unsigned long long)((unsigned)b0 | ((unsigned)b1 << 16)) |
                                               ((unsigned long long)((unsigned)b2 | ((unsigned)b3 << 16)) << 32);
-#if JAMIE_ADAM_W16_NT
                 __builtin_nontemporal_store(pk, reinterpret_cast<unsigned long long*>(p_bf16) + i);
-#else
-                reinterpret_cast<unsigned long long*>(p_bf16)[i] = pk;
-#endif
             }
         }
         i0 += nwg * (T * U);

@@ -9,6 +9,8 @@
 // operand layout IS 8 consecutive k of one row: one 16-byte load per fragment; no LDS staging, no barrier in the k-loop, all of a
 // slice's loads in flight together), the 16 partial tiles are added in wave order through LDS (deterministic) and the tile is
 // written ONCE: no slabs.
+// (experiments build only: -DJAMIE_EXPERIMENTS, jamie_amd.build.build_experiments(); not in the product library)
+#ifdef JAMIE_EXPERIMENTS
 #include "common.h"
 
 typedef float sk_f32x16 __attribute__((ext_vector_type(16)));
@@ -102,3 +104,5 @@ extern "C" int jamie_gemm_bf16_skinny(const jamie_gemm_problem* pr, int count, v
     hipLaunchKernelGGL(skinny_nt_bf16_kernel, dim3(blocks), dim3(SK_NW * 64), 0, (hipStream_t)stream, g);
     return jamie_launch_status("jamie_gemm_bf16_skinny");
 }
+
+#endif  // JAMIE_EXPERIMENTS

@@ -7,7 +7,6 @@ All buffers are allocated once per batch size; no step allocates, synchronises o
 """
 import functools
 import math
-import os
 
 import numpy as np
 import torch
@@ -18,6 +17,35 @@ from .model import BN_EPS, BN_MOMENTUM, LRELU_SLOPE
 KL_WEIGHT = 32 * 1e-3       # jamie.py:632
 ALIGN_WEIGHT = 32           # jamie.py:658
 LOSS_NAMES = ['KL', 'Rec', 'CosSim', 'F']
+
+# Tuning knobs of the launch plans and the older variant of every adopted change, for A/B measurements on one box
+# (tools/ab.sh "JAMIE_TUNE=key=value+key=value" -> bench.py --tune; profiles/r0*_ab_*.log).  NOT read from the environment: the package reads
+# no JAMIE_* variable besides the library path and the two test hooks of distributed.py (tests/test_host_cpu.py asserts it).
+# Set them with engine.tune(key=value, ...) BEFORE an engine is built.
+TUNING = {
+    'bf16_rows': None,            # "cfg:s0,s1[;cfg:s0,s1 for the N < K launches]": tile configuration + K slices of the bf16 forward launches
+    'f32_rows': None,             # "[cfg:]s0,s1[;...]": the same for the fp32 forward / dX launches
+    'bwd_k_per_slab': 1700.0,     # K per split-K slab of the bf16 dX products
+    'sk_skinny': None,            # slab count of the skinny head / latent products
+    'f32_dw_cfg': None, 'f32_dx_cfg': None,      # fp32 tile configurations of the dW / dX launches
+    'prefetch': 1,                # BatchNorm prefetch riders: 0 off, 1 the next product's weights, 2 + saved activations
+    'prefetch_f32': '0',          # ... in fp32 mode: '0' off (default: +38 us there), '1' on, 'bwd' backward only
+    'stagger': True,              # flat optimiser buffers start 4 KB apart
+    'adam_rotate': False,         # clip + Adam walks from the second layer's region (+5 us: off)
+    'f32_dx_plan': True, 'f32_fused_norm': True,
+    'fused_da2': True, 'fused_latent': True, 'direct_comm': True, 'cs_ride': True, 'late_dec0_dw': True, 'range_ride': True,
+    'defer_final': True, 'fused_sampler': True, 'gather_ride': True,
+}
+
+
+def tune(**kw):
+    """Set tuning knobs (see TUNING); unknown keys raise.  Plans cached by shape are dropped."""
+    for k, v in kw.items():
+        if k not in TUNING:
+            raise KeyError(f'unknown tuning knob {k!r}')
+        TUNING[k] = v
+    _plan_f32_rows.cache_clear()
+
 
 # hyper buffer slots (device float[16]; see include/jamie_hip.h)
 H_KL, H_REC, H_ALIGN, H_F = 0, 1, 2, 3
@@ -63,8 +91,8 @@ def plan_bf16_rows(B, shapes):
     """shapes = [(N_i, K_i)] of one forward / dX launch -> (cfg, [splitk_i]); cfg -1 = the library default."""
     if not _big_enough(B, shapes):
         return -1, [choose_splitk(B, N, K) for (N, K) in shapes]
-    if os.environ.get('JAMIE_BF16_ROWS'):         # tuning knob (tools/ab.sh): "cfg:s0,s1[;cfg:s0,s1 for the N < K launches]"
-        parts = os.environ['JAMIE_BF16_ROWS'].split(';')
+    if TUNING['bf16_rows']:
+        parts = TUNING['bf16_rows'].split(';')
         part = parts[0] if (all(N >= K for (N, K) in shapes) or len(parts) == 1) else parts[1]
         cfg, sks = part.split(':')
         sks = [int(v) for v in sks.split(',')]
@@ -83,7 +111,7 @@ def plan_bf16_bwd(B, shapes):
     # dX slices of ~1700 of K (config 2: (1, 1), (2, 1), (1, 1) for the three layers): re-swept at the end of round 2, when a
     # slab costs the BatchNorm launch that sums it more than it saves the GEMM (K / 1000: +5.7 us per step, unsplit K = 4000: +25,
     # profiles/r02_bwd_splitk_sweep.log)
-    per = float(os.environ.get('JAMIE_BWD_K_PER_SLAB', '1700'))        # (tuning knob, tools/ab.sh)
+    per = float(TUNING['bwd_k_per_slab'])
     return BF16_CFG_DW, [int(max(1, min(round(K / per), 4, K // 256))) for (N, K) in shapes]
 
 
@@ -149,7 +177,7 @@ def launch_makespan(works, n_cu=N_CU, per_cu=2, solo=0.87):
 
 def plan_f32_rows(B, shapes):
     """(tile configuration, K slices per problem) of an fp32 forward / dX launch; see _plan_f32_rows."""
-    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), os.environ.get('JAMIE_F32_ROWS'))
+    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), TUNING['f32_rows'])
 
 
 @functools.lru_cache(maxsize=256)
@@ -164,8 +192,8 @@ def _plan_f32_rows(B, shapes, _knob):
     8.61 -> 7.60 ms per step, forward launches 94 -> 120 TFLOP/s.  (-1, None): keep the default."""
     if B < 256 or any(N < 512 or K < 512 for (N, K) in shapes):
         return -1, None
-    if os.environ.get('JAMIE_F32_ROWS'):          # tuning knob (tools/ab.sh): "s0,s1[;s0,s1 for the N < K launches]"
-        parts = os.environ['JAMIE_F32_ROWS'].split(';')
+    if _knob:
+        parts = _knob.split(';')
         part = parts[0] if (all(N >= K for (N, K) in shapes) or len(parts) == 1) else parts[1]
         cfg, _, part = part.rpartition(':')                 # ("cfg:s0,s1": another tile configuration)
         sks = [int(v) for v in part.split(',')]
@@ -229,7 +257,7 @@ class TrainEngine:
         n = model.layout.total
         # the streams clip + Adam walks in lock step (p, m, v, g, the bf16 weight copy) start 4 KB apart modulo the allocator's
         # 2 MB alignment: 211 instead of 215-220 us stand-alone (tools/bench_adam_offsets.py, profiles/r02_adam_buffer_placement.log)
-        self._stagger = 0 if os.environ.get('JAMIE_NO_STAGGER') == '1' else 4096
+        self._stagger = 4096 if TUNING['stagger'] else 0
         self.exp_avg = self._flat_alloc(n, torch.float32, 1)
         self.exp_avg_sq = self._flat_alloc(n, torch.float32, 2)
         self.grad = self._flat_alloc(n, torch.float32, 3)
@@ -238,7 +266,7 @@ class TrainEngine:
         self.norm_partials = torch.zeros(self.n_norm, **f32)
         # rng/state: [seed, step, 0, 0]
         self.state = torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=self.dev)
-        if self.bf16 and os.environ.get('JAMIE_ADAM_ROTATE', '0') == '1':        # (A/B switch: measured +5 us per step, off)
+        if self.bf16 and TUNING['adam_rotate']:        # (A/B: measured +5 us per step, off)
             self.set_adam_start(True)
         hyper = torch.zeros(16)
         hyper[H_REC], hyper[H_ALIGN], hyper[H_F] = (self.loss_weights[1], self.loss_weights[2] * ALIGN_WEIGHT,
@@ -258,21 +286,8 @@ class TrainEngine:
         # the heads / dcomb slab counts must agree between the modalities (one latent launch reads both)
         sk_head = min(choose_splitk(B, 2 * L, d) for d in self.dims)
         sk_dcomb = min(choose_splitk(B, L, d) for d in self.dims)
-        if os.environ.get('JAMIE_SK_SKINNY'):          # tuning knob (tools/ab.sh): slab count of the skinny head / latent products
-            sk_head = sk_dcomb = int(os.environ['JAMIE_SK_SKINNY'])
-        # bf16: the two skinny products with K = features -- the heads' forward [B, d] x [2L, d]^T and the decoder-layer-0 input
-        # gradient [B, d] x [d, L] -- CAN take the register-fed kernel (jamie_gemm_bf16_skinny: a 32 x 32 output tile per workgroup,
-        # a K slice per wave, no LDS staging, NO slabs; d comb on the K-contiguous bf16 copy of W_dec0 that the fused latent forward
-        # launch then leaves behind, dec0_WT_bf16) instead of the tiled GEMM with 8 K slices.  Built and tested (VERDICT r2 item 6
-        # asked for it), measured, OFF by default: 11.3 us per launch against 9.8 us for the tiled launch, the step 618.6 against
-        # 616.3 us (profiles/r03_ab_skinny_rejected.log, r03_stats_skinny.txt): MFMA-fragment-shaped loads (32 rows x 32 bytes per
-        # wave-instruction) are bound by the texture addresser, as cdna_hip_programming.md's "x operand through LDS in full lines"
-        # row says.  JAMIE_SKINNY=1 switches it on (tools/ab.sh).
-        skinny = self.bf16 and os.environ.get('JAMIE_SKINNY') == '1'
-        self._skinny_head = skinny and 2 * L <= 128
-        self._skinny_dcomb = skinny and L <= 128
-        if self._skinny_head:
-            sk_head = 1
+        if TUNING['sk_skinny']:
+            sk_head = sk_dcomb = int(TUNING['sk_skinny'])
         # bf16: tile configuration of every large launch + per-modality slab counts (plan_bf16_*)
         self.gcfg, plan_sk = {}, {}
         if self.bf16:
@@ -299,7 +314,7 @@ class TrainEngine:
         # split too and its MSE / gradient come from jamie_mse_cast (a fused epilogue needs an unsplit K: 126 us)
         self.fcfg = {}
         if not self.bf16:
-            dx_nn = [] if os.environ.get('JAMIE_NO_F32_DX_PLAN') == '1' else \
+            dx_nn = [] if not TUNING['f32_dx_plan'] else \
                 [('d_e2', [(2 * d, d) for d in self.dims]), ('d_a1', [(2 * d, d) for d in self.dims])]
             for key, shp in [('enc0', [(2 * d, d) for d in self.dims]), ('enc1', [(d, 2 * d) for d in self.dims]),
                              ('dec1', [(2 * d, d) for d in self.dims]), ('dec2', [(d, 2 * d) for d in self.dims]),
@@ -351,8 +366,6 @@ class TrainEngine:
                 w['comb'] = self.ws[0]['comb']          # M > 2 (identity corr): one combined embedding for all
             if self.bf16:
                 bf = dict(device=self.dev, dtype=torch.bfloat16)
-                if self._skinny_dcomb:
-                    w['dec0_WT'] = torch.zeros(L, d, **bf)
                 for k, nf in (('x', d), ('a1', 2 * d), ('a2', d), ('comb', L), ('e1', d), ('e2', 2 * d), ('dxhat', d),
                               ('de2', 2 * d), ('de1', d), ('dml', 2 * L), ('da2', d), ('da1', 2 * d)):
                     w[k + '_bf'] = torch.empty(B, nf, **bf)
@@ -385,7 +398,7 @@ class TrainEngine:
         skinny_lins = ('head', 'dec0') if (self.bf16 and getattr(self, 'skinny_tr', False)) else ()
         # (fp32 mode: the TN dW launches of the large layers take the 128 x 128 tile then -- the same speed as the 64 x 64 one
         #  inside the step, profiles/r02_f32_dw_tile_sweep.log, and a quarter of the partial sums)
-        f32_fused = (not self.bf16 and world_size == 1 and B >= 256 and os.environ.get('JAMIE_NO_F32_FUSED_NORM') != '1'
+        f32_fused = (not self.bf16 and world_size == 1 and B >= 256 and TUNING['f32_fused_norm']
                      and all(min(model.p[f'm{i}.{lin}.W'].shape) >= 512 for lin in big for i in range(self.M)))
         self._f32_dw_fused = f32_fused
         if f32_fused or (self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values())):
@@ -451,7 +464,6 @@ class TrainEngine:
         self.rsum = torch.empty(B, **f32); self.qsum = torch.empty(B, **f32)
         self.fc1 = torch.empty(B, L, **f32); self.fte = torch.empty(B, L, **f32)
         self.corr = torch.empty(B, B, **f32)
-        self._bn_tickets = {}            # per fused Linear + BatchNorm launch: the hand-off counters (_fwd_block)
         self.accumulate = False          # True: gradients add to the buffer (batch_step=False, jamie.py:736-749)
         self._dsig_tmp = torch.zeros(self.M, **f32)
         self._timing = None
@@ -734,8 +746,8 @@ class TrainEngine:
         touch of the weights, and the riders delay the BatchNorm launch): bf16 mode only.  The saved activations on top of the
         weights (JAMIE_PREFETCH=2): 631.9 against 628.3 us with the weights alone (632.6 without): the extra ranges stretch the
         BatchNorm launches by what the next launches gain -- the default (1) prefetches the weights only.  JAMIE_PREFETCH=0: off."""
-        mode = os.environ.get('JAMIE_PREFETCH', '1')
-        f32_mode = os.environ.get('JAMIE_PREFETCH_F32', '0')          # (A/B knob: '1' = in fp32 mode too, 'bwd' = its backward only)
+        mode = str(TUNING['prefetch'])
+        f32_mode = str(TUNING['prefetch_f32'])
         if mode == '0' or self.pipeline or (not self.bf16 and f32_mode == '0'):
             return None
         out = []
@@ -769,7 +781,7 @@ class TrainEngine:
                 pr.out, pr.out_bf16 = None, nv.ptr(w[out_key + '_bf'])
                 pr.outT_bf16 = nv.ptr(w[out_key + '_T']) if out_key in self.need_T else None
             probs.append(pr)
-        if not self.bf16 and os.environ.get('JAMIE_PREFETCH_F32', '0') == 'bwd':
+        if not self.bf16 and str(TUNING['prefetch_f32']) == 'bwd':
             prefetch = ()
         nv.bn_act_fwd(probs, self.p_drop, self.state, BN_MOMENTUM, BN_EPS, LRELU_SLOPE, self._prefetch(*prefetch))
 
@@ -792,54 +804,14 @@ class TrainEngine:
             probs.append(pr)
         nv.bn_act_bwd(probs, self.p_drop, self.state, LRELU_SLOPE, colsums, self._prefetch(*prefetch))
 
-    # ---- Linear forward + BatchNorm + LeakyReLU + dropout as ONE launch (jamie_gemm_bf16_bn): the split-K slices of a column
-    # strip hand their fp32 slabs to each other inside the launch and run the BatchNorm strip code themselves -- no BatchNorm
-    # launch, no kernel boundary.  Built, bit-identical to the two launches (tests), measured, and OFF by default: on one box,
-    # interleaved, the step takes 638 us with the launch pairs, 676 us with the hand-off in which every slice takes a share of the
-    # strip (JAMIE_FUSED_BN_MODE=2) and 759 us when the last slice to arrive reduces the strip (mode 1)
-    # (profiles/r03_ab_fused_bn_rejected.log).  In-kernel stamps (profiles/r03_stamps_fused_bn_v1.log, 256 x 128 tiles): write-through slab
-    # stores 5.5 us instead of 3.6, the wait for the strip's other slices 2-6 us, the strip phase itself 17.5 us (7.7 us on the
-    # 128 x 128 launches) against 11.4 us for the whole BatchNorm launch: the slabs cross the fabric either way (another CU wrote
-    # them), and inside the launch that traffic is serialised behind the slowest slice of every strip instead of overlapping
-    # nothing at all.  JAMIE_FUSED_BN=1 switches it on (tools/ab.sh).
-    def _fused_bn_ok(self, sk_key, out_key):
-        return (self.bf16 and self.fuse_bf16 and self.B <= 512 and self.M <= 4 and self.gcfg.get(sk_key, -1) in (31, 32)
-                and all(n % 4 == 0 for n in self.dims) and out_key not in self.need_T and not self.pipeline and self._zs is None
-                and os.environ.get('JAMIE_FUSED_BN', '0') == '1')
-
     def _fwd_block(self, a_key, lin, h_key, sk_key, layer, out_key, stream_base, noise, kind, j):
-        """out = Dropout(LeakyReLU(BatchNorm(a W^T + b)))  (model.py:151-154 and siblings): one launch where the large-tile
-        bf16 plan applies, else the product and the BatchNorm launch."""
-        if not self._fused_bn_ok(sk_key, out_key):
-            self._fwd_gemm(a_key, lin, h_key, sk_key)
-            self._bn_fwd(layer, h_key, out_key, stream_base, noise, kind, j,
-                         prefetch={'enc0': ('W:enc1',), 'dec1': ('W:dec2', 'x')}.get(lin, ()))      # (x: the MSE launch reads it)
-            self._cast(out_key)
-            return
-        probs, bns = [], []
-        for i, d in enumerate(self.dims):
-            w, P, bn = self.ws[i], self.m.p, self.m.bn
-            W, h = P[f'm{i}.{lin}.W'], w[h_key]
-            nout, nin = W.shape
-            probs.append(nv.gemm_problem(w[a_key + '_bf'], self.wbf[f'm{i}.{lin}.W'], h, self.B, nout, nin, nin, nin, nout,
-                                         bias=P[f'm{i}.{lin}.b'], splitk=w['sk'][sk_key], slab_stride=self.B * nout))
-            pr = nv.BnFwdProblem()
-            pr.h, pr.nslab, pr.slab_stride = nv.ptr(h), h.shape[0], h.shape[1] * h.shape[2]
-            pr.gamma, pr.beta = nv.ptr(P[f'm{i}.{layer}.g']), nv.ptr(P[f'm{i}.{layer}.b'])
-            pr.running_mean, pr.running_var = nv.ptr(bn[f'm{i}.{layer}.mean']), nv.ptr(bn[f'm{i}.{layer}.var'])
-            pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
-            pr.out, pr.mask = None, nv.ptr(self._mask(noise, kind, i, j))
-            pr.out_bf16, pr.outT_bf16 = nv.ptr(w[out_key + '_bf']), None
-            pr.B, pr.N, pr.rng_stream = self.B, h.shape[2], stream_base + 8 * i
-            bns.append(pr)
-        tk = self._bn_tickets.get(lin)
-        if tk is None:
-            tk = self._bn_tickets[lin] = torch.zeros(4 + 2 * sum((2 * d + 127) // 128 for d in self.dims), dtype=torch.int32,
-                                                     device=self.dev)
-        mode = int(os.environ.get('JAMIE_FUSED_BN_MODE', '2'))
-        cfg = self.gcfg[sk_key]
-        self._launch('enc_gemm', lambda: nv.gemm_bf16_bn(probs, bns, cfg, self.p_drop, self.state, tk, mode,
-                                                          BN_MOMENTUM, BN_EPS, LRELU_SLOPE))
+        """out = Dropout(LeakyReLU(BatchNorm(a W^T + b)))  (model.py:151-154 and siblings): the product (split-K slabs), then the
+        BatchNorm launch that sums them.  (The ONE-launch form with an in-launch split-K hand-off was built and measured slower in
+        round 3: +38 / +120 us per step, profiles/r03_ab_fused_bn_rejected.log; it lives in the experiments build.)"""
+        self._fwd_gemm(a_key, lin, h_key, sk_key)
+        self._bn_fwd(layer, h_key, out_key, stream_base, noise, kind, j,
+                     prefetch={'enc0': ('W:enc1',), 'dec1': ('W:dec2', 'x')}.get(lin, ()))      # (x: the MSE launch reads it)
+        self._cast(out_key)
 
     def _fwd_gemm(self, a_key, lin, out_key, sk_key, with_bias=True):
         """out[B, out_f] (slabs) = a[B, in_f] W^T (+ b)."""
@@ -879,8 +851,8 @@ class TrainEngine:
             nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
         else:
             cfg = self.fcfg.get(sk_key, -1)
-            if cfg < 0 and os.environ.get('JAMIE_F32_DX_CFG') and sk_key in ('d_e2', 'd_a1'):
-                cfg = int(os.environ['JAMIE_F32_DX_CFG'])
+            if cfg < 0 and TUNING['f32_dx_cfg'] is not None and sk_key in ('d_e2', 'd_a1'):
+                cfg = int(TUNING['f32_dx_cfg'])
             nv.gemm(probs, nv.NN, cfg)
 
     def _dw_problems(self, dy_key, a_key, lin):
@@ -912,7 +884,7 @@ class TrainEngine:
 
     def _f32_dw_cfg(self, lin):
         """fp32 dW launch (TN, K = batch): tile configuration (-1: the library's 64 x 64 default)."""
-        env = os.environ.get('JAMIE_F32_DW_CFG')
+        env = TUNING['f32_dw_cfg']
         big = self.B >= 256 and all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 512 for i in range(self.M))
         if big and self._f32_dw_fused:
             return F32_CFG_DW_FUSED           # (the partial sums are laid out for this tile)
@@ -1012,8 +984,6 @@ class TrainEngine:
             d.dbias_head[i] = nv.ptr(self.g[f'm{i}.head.b'])
             if self._fuse_da2():
                 d.head_W[i], d.da2[i] = nv.ptr(self.m.p[f'm{i}.head.W']), nv.ptr(w['da2'])
-                if self._skinny_dcomb:      # (the backward pass then multiplies d g1 by this copy: _backward)
-                    d.dec0_WT_bf16[i] = nv.ptr(w['dec0_WT'])
             if self.bf16:
                 d.dml_bf16[i] = nv.ptr(w['dml_bf'])
                 d.dmlT_bf16[i] = nv.ptr(w['dml_T']) if 'dml' in self.need_T else None
@@ -1024,8 +994,6 @@ class TrainEngine:
         d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
         d.sigma, d.hyper, d.partials = nv.ptr(self.m.p['sigma']), nv.ptr(self.hyper), nv.ptr(self.lat_partials)
         d.dcomb_nslab, d.dcomb_slab_stride = self.ws[0]['sk']['d_comb'], B * L
-        if self._skinny_dcomb and self._fuse_da2():
-            d.dcomb_nslab = 1               # (written once by the skinny launch)
         d.dsigma = nv.ptr(self._dsig_tmp if self.accumulate else self.g['sigma'])
         d.rec_partials, d.n_rec_partials = nv.ptr(self.rec_partials), self.rec_partials.numel()
         d.losses, d.rng_stream = nv.ptr(self.losses), 100
@@ -1035,10 +1003,10 @@ class TrainEngine:
         """The heads' input gradient d a2 = d(mu | logvar) W_head as extra workgroups of the fused latent backward launch
         (exact fp32, K = 2L) instead of a GEMM launch; the heads' dW then rides in the next layer's launch."""
         return (all(d % 4 == 0 for d in self.dims) and all(w['sk']['d_a2'] == 1 for w in self.ws)
-                and (not self.bf16 or self.skinny_tr) and os.environ.get('JAMIE_NO_FUSED_DA2') != '1')
+                and (not self.bf16 or self.skinny_tr) and TUNING['fused_da2'])
 
     def _fused_latent(self, corr, Fblk):
-        if self.M == 2 and os.environ.get('JAMIE_NO_FUSED_LATENT') == '1':      # A/B switch (tools/ab.sh): the general kernels
+        if self.M == 2 and not TUNING['fused_latent']:      # (A/B: the general kernels)
             return False
         return corr is None and Fblk is None and not self.cosine and self.L <= 128
 
@@ -1183,11 +1151,7 @@ class TrainEngine:
         # ---------------- forward ----------------
         self._fwd_block('x', 'enc0', 'h1', 'enc0', 'bn0', 'a1', 10, noise, 'enc_masks', 0)
         self._fwd_block('a1', 'enc1', 'h2', 'enc1', 'bn1', 'a2', 11, noise, 'enc_masks', 1)
-        if self._skinny_head:                                             # (bias added in the latent kernel)
-            nv.gemm_bf16_skinny([nv.gemm_problem(w['a2_bf'], self.wbf[f'm{i}.head.W'], w['ml'], B, 2 * L, d, d, d, 2 * L)
-                                 for i, (w, d) in enumerate(zip(self.ws, self.dims))])
-        else:
-            self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)
+        self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)
         fused = fused_losses and self._fused_latent(corr, Fblk)
         lat = self._latent_desc(corr, Fblk, noise, fused)
         nv.latent_fwd(lat, self.state)
@@ -1241,7 +1205,7 @@ class TrainEngine:
               and (getattr(allreduce, 'world', 1) > 1 or getattr(allreduce, 'single', False)) and self.bf16 and self.grad.is_cuda and not self.accumulate
               and self.gcfg.get('dw', -1) == BF16_CFG_DW and self.skinny_tr and 3 * self.M <= nv.MAX_GEMM_GROUP
               and all(self.gcfg.get(k, -1) == BF16_CFG_DW for k in ('d_e2', 'd_e1', 'd_a1'))
-              and self._fused_latent(None, None) and self._fuse_da2() and os.environ.get('JAMIE_NO_DIRECT_COMM') != '1')
+              and self._fused_latent(None, None) and self._fuse_da2() and TUNING['direct_comm'])
         if not ok:
             return None
         comm = allreduce.message_buffer(self.grad)
@@ -1302,7 +1266,7 @@ class TrainEngine:
         # the decoder's output-bias gradient (column sums of d x_hat) rides in the first BatchNorm-backward launch as extra
         # workgroups (47 short ones beside 375 long ones) instead of being a launch of its own at the head of the backward
         # pass (with a gradient exchange too: the biases live in region `rep`, which is announced last)
-        ride = os.environ.get('JAMIE_NO_CS_RIDE') != '1'
+        ride = bool(TUNING['cs_ride'])
         cs_items = [(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))]
         if not ride:
             nv.colsum_group(cs_items, acc)
@@ -1321,12 +1285,7 @@ class TrainEngine:
         # launch, and what is left here is the short d comb product alone
         late_dw = []
         fused_tail = isinstance(lat, nv.LatentM) and bool(lat.da2[0])
-        if fused_tail and self._skinny_dcomb and bool(lat.dec0_WT_bf16[0]):
-            probs = [nv.gemm_problem(w['de1_bf'], w['dec0_WT'], w['dcomb'][0], B, L, d, d, d, L)
-                     for w, d in zip(self.ws, self.dims)]
-            nv.gemm_bf16_skinny(probs)
-            late_dw.append(('de1', 'comb', 'dec0'))
-        elif fused_tail and (self._direct_now or os.environ.get('JAMIE_NO_LATE_DEC0_DW') != '1'):
+        if fused_tail and (self._direct_now or TUNING['late_dec0_dw']):
             self._dx_gemm('de1', 'dec0', 'dcomb', 'd_comb')
             late_dw.append(('de1', 'comb', 'dec0'))
         else:
@@ -1358,7 +1317,7 @@ class TrainEngine:
         #  events, profiles/r02_ab_range_norm_side_stream_rejected.log)
         # ... but as EXTRA workgroups of that last dW launch the range norm (and the latent finalisation) costs nothing: every
         # other gradient exists by now
-        ride = (self._fuse_now and self.bf16 and self._dw_cfg('enc0') == BF16_CFG_DW and os.environ.get('JAMIE_NO_RANGE_RIDE') != '1')
+        ride = (self._fuse_now and self.bf16 and self._dw_cfg('enc0') == BF16_CFG_DW and TUNING['range_ride'])
         self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else dr.get('enc0'))
         self._ranges_done = ride
         self._region(allreduce, 'rep')        # (adjacent to enc0: an all-reduce exchange merges the two into one message)
@@ -1459,7 +1418,7 @@ class TrainEngine:
         # launch that follows in this very step when that launch exists (bf16 mode, one GPU, fused gradient norm)
         defer = (self.fused_norm and self.sq_ranges_nofin.blocks <= 128 and allreduce is None and not self.accumulate
                  and self._fused_latent(corr, Fblk)
-                 and os.environ.get('JAMIE_NO_DEFER_FINAL') != '1')
+                 and TUNING['defer_final'])
         lat = self._forward(corr, Fblk, noise, True)
         if defer and isinstance(lat, nv.LatentM):
             lat.defer_final = 1
@@ -1508,13 +1467,13 @@ class TrainEngine:
         if not prefetch:
             # the sampler of the NEXT batch rides in this step's clip + Adam launch (one extra workgroup: the same index
             # stream, no launch of its own); the first batch is drawn here, before the recording
-            fused = not self.pipeline and (replace or idx.numel() <= 2048) and os.environ.get('JAMIE_NO_FUSED_SAMPLER') != '1'
+            fused = not self.pipeline and (replace or idx.numel() <= 2048) and TUNING['fused_sampler']
             # ... and where the latent backward launch can carry the sampler (fused M-modality kernels, identity
             # correspondence, no weight transposes waiting for Adam's output) the next batch's GATHER rides in clip + Adam
             # too: the batch buffers are free once the last dW product has run, and the step is then fwd + bwd + norm + Adam
             early = (fused and not self.wT and not replace and self._fused_latent(corr, None)
                      and all(x.shape[1] % 4 == 0 and x.dtype == torch.float32 for x in data)
-                     and os.environ.get('JAMIE_NO_GATHER_RIDE') != '1')
+                     and TUNING['gather_ride'])
             if fused:
                 nv.sample_indices(idx, n_rows, 0, replace, self.state, 200)
             if early:
@@ -1589,7 +1548,4 @@ class TrainEngine:
     def read_losses(self):
         """Device sync: [KL, Rec, CosSim, F] (weighted), total, running min of total."""
         v = self.losses.tolist()
-        for lin, tk in self._bn_tickets.items():      # (a bounded in-launch wait that gave up leaves word 0 set)
-            if int(tk[0].item()) != 0:
-                raise nv.JamieHipError(f'fused Linear + BatchNorm launch of layer {lin}: a split-K hand-off wait timed out')
         return v[:4], v[4], v[5]

@@ -318,14 +318,15 @@ class edModelVar:
         x = torch.as_tensor(x)
         return x.to(self.device, torch.float32).contiguous()
 
+    EVAL_GEMM_CFG = None
+
     @staticmethod
     def _eval_cfg(n, nout, k):
         """fp32 GEMM tile for the eval path: many rows make these large, square-ish products, where the 128x128x32 tile
         (16 waves of 32x32) runs at 120-130 TFLOP/s against ~110 for the 64x64 default of the skinny training shapes
-        (tools/bench_gemm_sq.py, tools/bench_infer.py); JAMIE_EVAL_GEMM_CFG overrides (diagnostics)."""
-        import os
-        if 'JAMIE_EVAL_GEMM_CFG' in os.environ:
-            return int(os.environ['JAMIE_EVAL_GEMM_CFG'])
+        (tools/bench_gemm_sq.py, tools/bench_infer.py); the class attribute EVAL_GEMM_CFG overrides (diagnostics)."""
+        if edModelVar.EVAL_GEMM_CFG is not None:
+            return int(edModelVar.EVAL_GEMM_CFG)
         return 12 if (n >= 2048 and nout >= 512 and k >= 512) else -1
 
     def _lin_bn_act(self, i, x, lin, bn):

@@ -103,9 +103,7 @@ def _check_products_against_stored_operands(eng, model, noise, p):
         # the two products inside the fused latent launches are exact fp32: decoder layer 0 forward, the heads' input gradient
         assert _rel(w['g1'][0], w['comb'] @ P_[f'm{i}.dec0.W'].t() + P_[f'm{i}.dec0.b']) < 1e-5, (i, 'dec0 forward (fp32)')
         assert _rel(w['da2'][0], w['dml'] @ P_[f'm{i}.head.W']) < 1e-5, (i, 'heads input gradient (fp32)')
-        nd = 1 if getattr(eng, '_skinny_dcomb', False) else w['sk']['d_comb']     # (the skinny launch writes d comb once)
-        if getattr(eng, '_skinny_dcomb', False):       # the transposed bf16 copy of W_dec0 the fused latent forward launch left
-            assert torch.equal(w['dec0_WT'], wb[f'm{i}.dec0.W'].t().contiguous()), (i, 'dec0_WT')
+        nd = w['sk']['d_comb']
         for dy, lin, out in (('dxhat', 'dec2', w['de2'].sum(0)), ('de2', 'dec1', w['de1'].sum(0)),
                              ('de1', 'dec0', w['dcomb'][:nd].sum(0)), ('da2', 'enc1', w['da1'].sum(0))):
             want = bfl(w[dy + '_bf']) @ bfl(wb[f'm{i}.{lin}.W'])

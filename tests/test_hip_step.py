@@ -1160,63 +1160,3 @@ def test_fused_gradient_norm_equals_the_norm_of_the_gradient(jam, grad_bf16):
             eng3.forward_backward()
             eng3.accumulate = True
             eng3.forward_backward()                         # accumulating onto bf16-written gradients is refused
-
-
-@pytest.mark.parametrize('dims,L,B', [((2000, 1000), 32, 512), ((520, 264), 16, 256)])
-def test_fused_linear_batchnorm_launch_is_bit_identical_to_two_launches(jam, monkeypatch, dims, L, B):
-    """bf16 compute mode: the forward Linear + BatchNorm + LeakyReLU + dropout launches with the in-launch split-K hand-off
-    (jamie_gemm_bf16_bn; both hand-off modes) leave exactly the parameters, moments, running statistics and losses of the
-    product + BatchNorm launch pairs they replace, over several recorded-plan steps with Philox noise."""
-    from jamie_amd.engine import TrainEngine
-    from jamie_amd.model import edModelVar
-    N = 4096
-    g = torch.Generator().manual_seed(1)
-    data = [torch.randn(N, d, generator=g).cuda() for d in dims]
-    out = []
-    monkeypatch.setenv('JAMIE_BN_CQ', '4')           # (the fused launch runs 16-column strips: the same summation order)
-    for fused, mode in (('0', '2'), ('1', '1'), ('1', '2')):
-        monkeypatch.setenv('JAMIE_FUSED_BN', fused)
-        monkeypatch.setenv('JAMIE_FUSED_BN_MODE', mode)
-        torch.manual_seed(9)
-        model = edModelVar(dims, L)
-        eng = TrainEngine(model, B, compute_dtype='bf16', seed=21)
-        assert eng._fused_bn_ok('enc0', 'a1') == (fused == '1')
-        eng.set_kl_anneal(0.5)
-        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
-        plan = eng.make_plan(data, idx, N)
-        for _ in range(5):
-            eng.run_plan(plan)
-        out.append((model.flat.clone(), eng.exp_avg.clone(), {k: v.clone() for k, v in model.bn.items()}, eng.read_losses()))
-    for o in out[1:]:
-        assert torch.equal(out[0][0], o[0]) and torch.equal(out[0][1], o[1]) and out[0][3] == o[3]
-        for k in out[0][2]:
-            assert torch.equal(out[0][2][k], o[2][k]), k
-
-
-def test_skinny_products_leave_the_step_within_rounding(jam, monkeypatch):
-    """JAMIE_SKINNY=1 (the register-fed kernel for the heads' forward product and d comb, written once instead of 8 K-slice
-    slabs; the transposed bf16 copy of W_dec0 from the fused latent forward launch): same step up to fp32 summation order."""
-    from jamie_amd.engine import TrainEngine
-    from jamie_amd.model import edModelVar
-    dims, L, B, N = (520, 264), 32, 256, 2048
-    g = torch.Generator().manual_seed(1)
-    data = [torch.randn(N, d, generator=g).cuda() for d in dims]
-    out = []
-    for on in ('0', '1'):
-        monkeypatch.setenv('JAMIE_SKINNY', on)
-        torch.manual_seed(9)
-        model = edModelVar(dims, L)
-        eng = TrainEngine(model, B, compute_dtype='bf16', seed=21)
-        assert eng._skinny_head == (on == '1')
-        eng.set_kl_anneal(0.5)
-        idx = torch.zeros(B, dtype=torch.int32, device='cuda')
-        plan = eng.make_plan(data, idx, N)
-        eng.run_plan(plan)
-        if on == '1':
-            for i in range(2):
-                assert eng.ws[i]['dec0_WT'].shape == (L, dims[i])
-        out.append((eng.grad_flat().clone(), eng.read_losses()[0]))
-    # (another summation order in two products: downstream bf16 operands round to the other neighbour here and there)
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-3)
-    rel = float((out[0][0] - out[1][0]).norm() / out[0][0].norm())
-    assert rel < 1e-2, rel

@@ -25,14 +25,63 @@ def lib():
 def test_library_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, 'include', 'jamie_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    declared = set(re.findall(r'\b(jamie_[a-z0-9_]+)\s*\(', hdr))
+    # the experiments block (-DJAMIE_EXPERIMENTS: kernels measured slower, not in the product library) is declared apart
+    m = re.search(r'#ifdef JAMIE_EXPERIMENTS(.*?)#endif', hdr, flags=re.S)
+    exp_decl = set(re.findall(r'\b(jamie_[a-z0-9_]+)\s*\(', m.group(1)))
+    declared = set(re.findall(r'\b(jamie_[a-z0-9_]+)\s*\(', hdr[:m.start()] + hdr[m.end():]))
     assert len(declared) >= 15
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    assert exp_decl == set(lib.EXPERIMENT_EXPORTS) and not (exp_decl & declared)
     handle = lib.load()
     for name in declared:
         assert hasattr(handle, name), name
+    if not os.environ.get('JAMIE_LIB'):
+        # the default library exports ONLY what the header's product part declares (rejected experiments out)
+        for name in exp_decl:
+            assert not hasattr(handle, name), name
+        out = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r' T (jamie_[a-z0-9_]+)$', out, flags=re.M))
+        assert exported == declared, exported ^ declared
+    import jamie_amd
+    exp_lib = os.path.join(os.path.dirname(jamie_amd.library_path()), 'libjamie_hip_exp.so')
+    if os.path.exists(exp_lib):
+        import ctypes
+        h2 = ctypes.CDLL(exp_lib)
+        for name in declared | exp_decl:
+            assert hasattr(h2, name), name
     assert handle.jamie_version() >= 100
     assert handle.jamie_max_partials() >= 1024
+
+
+def test_package_reads_no_environment_switches():
+    """jamie_amd/*.py read NO JAMIE_* variable besides the library path and the two test hooks of the data-parallel launcher
+    (29 switches used to select measured-and-rejected variants; those are engine.TUNING keys now, set by
+    engine.tune() / bench.py --tune), the C sources read the environment in the experiments build only, and nothing in the
+    product imports the experiments module."""
+    allow = {'JAMIE_HIP_LIB', 'JAMIE_LIB', 'JAMIE_DIST_BACKEND', 'JAMIE_SHARE_GPU', 'JAMIE_HIPCC_FLAGS'}
+    pkg = os.path.join(ROOT, 'jamie_amd')
+    for f in sorted(os.listdir(pkg)):
+        if not f.endswith('.py'):
+            continue
+        txt = open(os.path.join(pkg, f)).read()
+        code = re.sub('(\'\'\'|\"\"\").*?\\1', '', txt, flags=re.S)
+        code = re.sub(r'#.*', '', code)
+        for name in re.findall(r'JAMIE_[A-Z0-9_]+', code):
+            assert name in allow or name in ('JAMIE_MAX_GEMM_GROUP', 'JAMIE_EXPERIMENTS'), (f, name)
+        if 'environ' in code:
+            for name in re.findall(r"environ(?:\.get)?[\[(]\s*'([A-Z0-9_]+)'", code):
+                assert name in allow | {'HIPCC', 'WORLD_SIZE', 'RANK', 'LOCAL_RANK'}, (f, name)
+        if f != 'experiments.py':
+            assert not re.search(r'^\s*(from\s+\.\s+import\s+.*\bexperiments\b|from\s+\.experiments|import\s+.*experiments)', code, flags=re.M), f
+    for f in sorted(os.listdir(os.path.join(pkg, 'csrc'))):
+        if f.endswith(('.hip', '.h')):
+            txt = open(os.path.join(pkg, 'csrc', f)).read()
+            outside = re.sub(r'#ifdef JAMIE_EXPERIMENTS.*?#endif', '', txt, flags=re.S)
+            assert 'getenv' not in outside, f
+    from jamie_amd import engine
+    with pytest.raises(KeyError):
+        engine.tune(no_such_knob=1)
+    engine.tune(prefetch=1)
 
 
 def test_ctypes_struct_sizes_match_header(lib, tmp_path):

@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from jamie_amd import _native as nv
+from jamie_amd import _native as nv, experiments as ex
 nv.require_gpu()
 torch.manual_seed(0)
 n_wg = torch.cuda.get_device_properties(0).multi_processor_count
@@ -20,8 +20,8 @@ def run(kind, M, N, K):
         ref = dy.float() @ W.float()
     nv.gemm_bf16(mk(o1), 29)
     p2 = mk(o2)
-    sc = nv.gemm_bf16_ring_plan(p2, n_wg)
-    nv.gemm_bf16_ring(p2, sc, n_wg, err)
+    sc = ex.gemm_bf16_ring_plan(p2, n_wg)
+    ex.gemm_bf16_ring(p2, sc, n_wg, err)
     torch.cuda.synchronize()
     bad = (o1 != o2)
     print(f'{kind} M{M} N{N} K{K}: cfg29 vs fp32 matmul max {float((o1 - ref).abs().max()):.3g}; ring mismatches {int(bad.sum())} of {bad.numel()}, err {int(err[0])}')

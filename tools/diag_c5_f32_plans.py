@@ -1,4 +1,4 @@
-"""GPU diagnostic: one fp32 step at config 5's dimensions against the oracle under two split-K plans (JAMIE_F32_ROWS):
+"""GPU diagnostic: one fp32 step at config 5's dimensions against the oracle under two split-K plans (engine.tune(f32_rows=...)):
 relative L2 of every gradient tensor and of the post-step weights.  Usage: python tools/diag_c5_f32_plans.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,8 +9,8 @@ from oracle import jamie_oracle as orc
 import test_hip_configs as T
 B, dims, L, p = 512, (5000, 2000), 64, 0.6
 for plan in ('1,1;2,1', ''):
-    if plan: os.environ['JAMIE_F32_ROWS'] = plan
-    else: os.environ.pop('JAMIE_F32_ROWS', None)
+    from jamie_amd import engine as _e
+    _e.tune(f32_rows=plan or None)
     model, eng, P, Bf = T._pair(jam, dims, L, B, 'f32')
     opt = orc.Adam(P.values(), 1e-3)
     X = T._synth(B, dims, seed=5)

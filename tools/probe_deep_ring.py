@@ -4,7 +4,7 @@ bit-identical; per-launch time by HIP events over rotating operand sets (cold op
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from jamie_amd import _native as nv
+from jamie_amd import _native as nv, experiments as ex
 nv.require_gpu()
 B = 512
 d = tuple(int(v) for v in os.environ.get('DIMS', '2000,1000').split(','))
@@ -61,10 +61,10 @@ for name, wshape, sks in (('dec2', [(x, 2 * x) for x in d], (1, 1)), ('dec1', [(
     # the persistent loader / consumer ring launch (jamie_gemm_bf16_ring) on the same problems
     n_wg = torch.cuda.get_device_properties(0).multi_processor_count
     err = torch.zeros(4, dtype=torch.int32, device='cuda')
-    scheds = [nv.gemm_bf16_ring_plan(st[0], n_wg) for st in sets]
+    scheds = [ex.gemm_bf16_ring_plan(st[0], n_wg) for st in sets]
     assert all(sc is not None for sc in scheds)
     for o in sets[0][1]: o.zero_()
-    nv.gemm_bf16_ring(sets[0][0], scheds[0], n_wg, err)
+    ex.gemm_bf16_ring(sets[0][0], scheds[0], n_wg, err)
     torch.cuda.synchronize()
     assert int(err[0].item()) == 0, ('ring hand-off error word', int(err[0].item()))
     bad = [i for i, (a, b) in enumerate(zip(ref, sets[0][1])) if not torch.equal(a, b)]
@@ -75,9 +75,9 @@ for name, wshape, sks in (('dec2', [(x, 2 * x) for x in d], (1, 1)), ('dec1', [(
     ts = []
     for rep in range(5):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        for i in range(NBUF): nv.gemm_bf16_ring(sets[i][0], scheds[i], n_wg, err)
+        for i in range(NBUF): ex.gemm_bf16_ring(sets[i][0], scheds[i], n_wg, err)
         ev[0].record()
-        for i in range(4 * NBUF): nv.gemm_bf16_ring(sets[i % NBUF][0], scheds[i % NBUF], n_wg, err)
+        for i in range(4 * NBUF): ex.gemm_bf16_ring(sets[i % NBUF][0], scheds[i % NBUF], n_wg, err)
         ev[1].record(); torch.cuda.synchronize()
         ts.append(ev[0].elapsed_time(ev[1]) / (4 * NBUF) * 1e3)
     print(f'{name}: RING    {np.median(ts):7.1f} us per launch (min {min(ts):.1f})  == cfg 29: {"ok" if not bad else "MISMATCH"}  err word {int(err[0].item())}', flush=True)

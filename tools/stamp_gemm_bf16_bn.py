@@ -4,7 +4,7 @@ Per workgroup: entry, tile 0 published, k-loop done, slab stores drained, ticket
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from jamie_amd import _native as nv
+from jamie_amd import _native as nv, experiments as ex
 nv.require_gpu()
 lib = nv.load()
 B, d = 512, (2000, 1000)
@@ -43,7 +43,7 @@ def run(name, shapes, cfg, sks, mode, iters=9):
     if mode == 0:
         launch = lambda s: (nv.gemm_bf16(s[0], cfg), nv.bn_act_fwd(s[1], 0.6, state))      # noqa: E731
     else:
-        launch = lambda s: nv.gemm_bf16_bn(s[0], s[1], cfg, 0.6, state, tickets, mode)     # noqa: E731
+        launch = lambda s: ex.gemm_bf16_bn(s[0], s[1], cfg, 0.6, state, tickets, mode)     # noqa: E731
     for i in range(iters):
         launch(sets[i % NBUF])
     torch.cuda.synchronize()

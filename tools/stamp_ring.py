@@ -4,7 +4,7 @@ end of each tile's k-loop and of its stores, loader wave 0 its start and end."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from jamie_amd import _native as nv
+from jamie_amd import _native as nv, experiments as ex
 nv.require_gpu()
 lib = nv.load()
 B, d = 512, (2000, 1000)
@@ -25,11 +25,11 @@ n_wg = torch.cuda.get_device_properties(0).multi_processor_count
 err = torch.zeros(4, dtype=torch.int32, device='cuda')
 for name, wshape, sks, dx in (('dec2', [(x, 2 * x) for x in d], (1, 1), True), ('enc0 dW only', [(2 * x, x) for x in d], (1, 1), False)):
     sets = [problems(wshape, sks, dx) for _ in range(NBUF)]
-    sch = [nv.gemm_bf16_ring_plan(p, n_wg) for p in sets]
-    for i in range(13): nv.gemm_bf16_ring(sets[i % NBUF], sch[i % NBUF], n_wg, err)
+    sch = [ex.gemm_bf16_ring_plan(p, n_wg) for p in sets]
+    for i in range(13): ex.gemm_bf16_ring(sets[i % NBUF], sch[i % NBUF], n_wg, err)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); nv.gemm_bf16_ring(sets[13 % NBUF], sch[13 % NBUF], n_wg, err); e1.record(); torch.cuda.synchronize()
+    e0.record(); ex.gemm_bf16_ring(sets[13 % NBUF], sch[13 % NBUF], n_wg, err); e1.record(); torch.cuda.synchronize()
     buf = (C.c_ulonglong * (64 * 512))()
     fn = lib.jamie_debug_ring_stamps
     fn.argtypes = [C.c_void_p, C.c_int]

@@ -8,6 +8,6 @@ run() {
   echo "[$1] $(echo "$out" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(1e3*d['ms_per_step'],1), 'us/step')")"
 }
 for r in 1 2; do
-  for c in 1 10 11 12 4 0 3; do run "JAMIE_F32_DW_CFG=$c"; done
+  for c in 1 10 11 12 4 0 3; do run "JAMIE_TUNE=f32_dw_cfg=$c"; done
 done
-for c in 1 10 11 12 4; do run "JAMIE_F32_DX_CFG=$c"; done
+for c in 1 10 11 12 4; do run "JAMIE_TUNE=f32_dx_cfg=$c"; done

@@ -3,7 +3,7 @@ ablations are timing only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from jamie_amd import _native as nv
+from jamie_amd import _native as nv, experiments as ex
 nv.require_gpu()
 B, NBUF = 512, 6
 d = tuple(int(v) for v in os.environ.get("DIMS", "2000,1000").split(","))
@@ -22,13 +22,13 @@ err = torch.zeros(4, dtype=torch.int32, device='cuda')
 out = []
 for name, wshape, sks, dx in (('dec2', [(x, 2 * x) for x in d], (1, 1), True), ('dec1', [(2 * x, x) for x in d], (2, 1), True), ('enc0dW', [(2 * x, x) for x in d], (1, 1), False)):
     sets = [problems(wshape, sks, dx) for _ in range(NBUF)]
-    sch = [nv.gemm_bf16_ring_plan(p, n_wg) for p in sets]
+    sch = [ex.gemm_bf16_ring_plan(p, n_wg) for p in sets]
     ts = []
     for rep in range(5):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        for i in range(NBUF): nv.gemm_bf16_ring(sets[i], sch[i], n_wg, err)
+        for i in range(NBUF): ex.gemm_bf16_ring(sets[i], sch[i], n_wg, err)
         ev[0].record()
-        for i in range(4 * NBUF): nv.gemm_bf16_ring(sets[i % NBUF], sch[i % NBUF], n_wg, err)
+        for i in range(4 * NBUF): ex.gemm_bf16_ring(sets[i % NBUF], sch[i % NBUF], n_wg, err)
         ev[1].record(); torch.cuda.synchronize()
         ts.append(ev[0].elapsed_time(ev[1]) / (4 * NBUF) * 1e3)
     out.append(f'{name} {np.median(ts):.1f}')
