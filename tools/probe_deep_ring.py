@@ -58,6 +58,8 @@ for name, wshape, sks in (('dec2', [(x, 2 * x) for x in d], (1, 1)), ('dec1', [(
             ev[1].record(); torch.cuda.synchronize()
             ts.append(ev[0].elapsed_time(ev[1]) / (4 * NBUF) * 1e3)
         print(f'{name}: cfg {cfg}  {np.median(ts):7.1f} us per launch (min {min(ts):.1f})  == cfg 29: ok', flush=True)
+    if os.environ.get('NO_RING') == '1' or not ex.available():
+        continue
     # the persistent loader / consumer ring launch (jamie_gemm_bf16_ring) on the same problems
     n_wg = torch.cuda.get_device_properties(0).multi_processor_count
     err = torch.zeros(4, dtype=torch.int32, device='cuda')
