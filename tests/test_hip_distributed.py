@@ -403,3 +403,22 @@ torch.distributed.destroy_process_group()
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert 'NATIVE COMM OK' in r.stdout
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_present(tmp_path):
+    """The real multi-GPU path -- backend "nccl" = RCCL, one GPU per rank -- end to end through `bench.py --gpus 2` (which starts its
+    own ranks): runs wherever the box has two or more GPUs, skipped on the one-GPU boxes of the pool.  Both
+    data-parallel arrangements and both message dtypes are timed in the one line; the ranks must agree on a finite loss."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one GPU visible: RCCL with more than one rank needs a GPU per rank')
+    clean = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'JAMIE_DIST_BACKEND',
+                                                               'JAMIE_SHARE_GPU')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5'],
+                       capture_output=True, text=True, env=clean, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['rccl']['backend'] == 'nccl' and out['rccl']['world'] == 2
+    assert out['config']['dp_optimizer'] == 'replicated' and out['value'] > 0 and out['final_loss'] == out['final_loss']
+    assert out['grad_comm_f32']['value'] and out['sharded_optimizer']['value']
