@@ -185,9 +185,11 @@ class OverlappedGradAllReduce:
             self._casts.clear()          # (the prepared cast launches hold raw pointers into the old buffer)
         return self.comm
 
-    def region_done(self, flat, lo, hi, precast=False):
+    def region_done(self, flat, lo, hi, precast=False, force=False):
         """`precast`: the region's gradients are already in `message_buffer()` (every region of a step alike): no cast pass,
-        no side stream -- the collective is issued where it stands (RCCL orders it behind the launches before it)."""
+        no side stream -- the collective is issued where it stands (RCCL orders it behind the launches before it).
+        `force`: issue the message now, whatever its size (the first part of the LAST layer's gradient: what is still on the
+        wire when the backward pass ends is then the small second part only)."""
         if self.world == 1 and not self.single:
             return
         precast = bool(precast)
@@ -202,7 +204,7 @@ class OverlappedGradAllReduce:
         elif pend is not None:
             self._issue(*pend)
         self.pending = (flat, lo, hi, precast)
-        if (hi - lo) * (flat.element_size() if self.comm_dtype is None else 2) >= self.min_bytes:
+        if force or (hi - lo) * (flat.element_size() if self.comm_dtype is None else 2) >= self.min_bytes:
             self._issue(*self.pending)
             self.pending = None
 
@@ -318,7 +320,7 @@ class ShardedGradExchange(OverlappedGradAllReduce):
                 raise ValueError(f'sharded region [{lo}, {hi}) does not split into {self.world} pieces of {dst.numel()}')
         self.spans = {(int(lo), int(hi)): dst for lo, hi, dst in spans}
 
-    def region_done(self, flat, lo, hi, precast=False):
+    def region_done(self, flat, lo, hi, precast=False, force=False):
         if self.world == 1 and not self.single:
             return
         if (lo, hi) in self.spans:               # a sharded region is one message, never merged with its neighbours
@@ -332,7 +334,7 @@ class ShardedGradExchange(OverlappedGradAllReduce):
                 self._issue(*self.pending)
             self.pending = (flat, lo, hi, bool(precast))
             return
-        super().region_done(flat, lo, hi, precast)
+        super().region_done(flat, lo, hi, precast, force)
 
     def _kind(self, lo, hi):
         return 'reduce_scatter' if (lo, hi) in self.spans else 'message'

@@ -35,6 +35,7 @@ TUNING = {
     'f32_dx_plan': True, 'f32_fused_norm': True,
     'fused_da2': True, 'fused_latent': True, 'direct_comm': True, 'cs_ride': True, 'late_dec0_dw': True, 'range_ride': True,
     'defer_final': True, 'fused_sampler': True, 'gather_ride': True,
+    'split_last_dw': True,        # data parallel (replicated): the last layer's dW in two launches, its first part on the wire early
 }
 
 
@@ -855,9 +856,11 @@ class TrainEngine:
                 cfg = int(TUNING['f32_dx_cfg'])
             nv.gemm(probs, nv.NN, cfg)
 
-    def _dw_problems(self, dy_key, a_key, lin):
+    def _dw_problems(self, dy_key, a_key, lin, only=None):
         probs = []
         for i, d in enumerate(self.dims):
+            if only is not None and i not in only:
+                continue
             w = self.ws[i]
             dy, a, dW = w[dy_key], w[a_key], self.g[f'm{i}.{lin}.W']
             nout, nin = dW.shape
@@ -868,10 +871,10 @@ class TrainEngine:
                                              store_nt=True, partial=self._dw_partial(i, lin)))
         return probs
 
-    def _dw_gemm(self, dy_key, a_key, lin, extra=None, ranges=None):
+    def _dw_gemm(self, dy_key, a_key, lin, extra=None, ranges=None, only=None):
         """dW[out_f, in_f] = dy[B, out_f]^T a[B, in_f] into the flat gradient buffer.  `extra` = [(dy_key, a_key, lin)] of
         skinny layers whose dW rides in the same launch; `ranges` (bf16 large-tile launch only): the range-norm work rides too."""
-        probs = self._dw_problems(dy_key, a_key, lin)
+        probs = self._dw_problems(dy_key, a_key, lin, only)
         for ex in (extra or []):
             if len(probs) + self.M <= nv.MAX_GEMM_GROUP and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(ex[2])):
                 probs += self._dw_problems(*ex)
@@ -1318,6 +1321,36 @@ class TrainEngine:
         # ... but as EXTRA workgroups of that last dW launch the range norm (and the latent finalisation) costs nothing: every
         # other gradient exists by now
         ride = (self._fuse_now and self.bf16 and self._dw_cfg('enc0') == BF16_CFG_DW and TUNING['range_ride'])
+        # Data parallel with the replicated optimiser: this is the LAST gradient of the pass, and whatever of it is still on the wire
+        # when the pass ends is exposed in full.  The first M - 1 modalities' weight gradients (config 2: 16 of the layer's 20 MB
+        # as bf16) go out in a launch of their own and their message is issued at once; the last modality's launch carries the
+        # riders, and only its part (+ `rep`) is announced at the end.  (Reasoned, not measured: no multi-GPU box.)
+        split = (allreduce is not None and hasattr(allreduce, 'region_done') and self._zs is None and self.M >= 2
+                 and TUNING['split_last_dw'] and not self.accumulate
+                 and (getattr(allreduce, 'world', 1) > 1 or getattr(allreduce, 'single', False)))
+        if split:
+            lo, hi = self.m.layout.regions['enc0']
+            cut = self.m.layout.entries[f'm{self.M - 1}.enc0.W'][0]
+            self._dw_gemm('da1', 'x', 'enc0', only=range(self.M - 1))
+            if self._direct_now:
+                fn = lambda: allreduce.region_done(self.grad, lo, cut, precast=True, force=True)   # noqa: E731
+            else:
+                fn = lambda: allreduce.region_done(self.grad, lo, cut, force=True)   # noqa: E731
+            nv.record_callable(fn)
+            fn()
+            self._dw_gemm('da1', 'x', 'enc0', only=[self.M - 1], ranges=dr.get('enc0'))
+            self._ranges_done = False
+            rlo, rhi = self.m.layout.regions['rep']
+            for a, b in ((cut, hi), (rlo, rhi)):
+                if self._direct_now:
+                    fn = lambda a=a, b=b: allreduce.region_done(self.grad, a, b, precast=True)   # noqa: E731
+                else:
+                    fn = lambda a=a, b=b: allreduce.region_done(self.grad, a, b)   # noqa: E731
+                nv.record_callable(fn)
+                fn()
+            self._norm_ready = self._fuse_now
+            self.m.num_batches_tracked += 1
+            return
         self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else dr.get('enc0'))
         self._ranges_done = ride
         self._region(allreduce, 'rep')        # (adjacent to enc0: an all-reduce exchange merges the two into one message)
