@@ -849,7 +849,8 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                                                   ((unsigned long long)(bfr(v[2]) | (bfr(v[3]) << 16)) << 32);
                     unsigned long long* c16 = reinterpret_cast<unsigned long long*>(
                         reinterpret_cast<unsigned short*>(Cout) + (long long)m * P.ldc + nc);
-                    __builtin_nontemporal_store(pk, c16);
+                    if (P.store_nt) __builtin_nontemporal_store(pk, c16);
+                    else *c16 = pk;
                 } else if (P.store_nt) {     // streamed past the caches: plain stores left 161 MB of dirty gradient lines per step in
                                       // L2 / Infinity Cache, whose write-back ran into the optimiser kernel (229 -> 208 us)
                     __builtin_nontemporal_store(v[0], cp); __builtin_nontemporal_store(v[1], cp + 1);

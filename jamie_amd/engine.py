@@ -35,6 +35,7 @@ TUNING = {
     'f32_dx_plan': True, 'f32_fused_norm': True,
     'fused_da2': True, 'fused_latent': True, 'direct_comm': True, 'cs_ride': True, 'late_dec0_dw': True, 'range_ride': True,
     'defer_final': True, 'fused_sampler': True, 'gather_ride': True,
+    'dw_store_nt': True,          # weight gradients stored non-temporally (next read by the optimiser, a backward pass later)
     'split_last_dw': True,        # data parallel (replicated): the last layer's dW in two launches, its first part on the wire early
 }
 
@@ -913,11 +914,11 @@ class TrainEngine:
         if self._dw_tr(lin):      # dy [B, out], a [B, in] row-major as produced: no transposed copies
             if self._direct_now:      # data parallel, bf16 messages: straight into the exchange buffer (no fp32 copy, no cast pass)
                 return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], self._direct['views'][f'm{i}.{lin}.W'], nout, nin,
-                                       self.B, nout, nin, nin, a_tr=True, b_tr=True, store_nt=True, c_bf16=True)
+                                       self.B, nout, nin, nin, a_tr=True, b_tr=True, store_nt=bool(TUNING['dw_store_nt']), c_bf16=True)
             g16 = self._g16_now and f'm{i}.{lin}' in self.dw_partial
             return nv.gemm_problem(w[dy_key + '_bf'], w[a_key + '_bf'], self.g16[f'm{i}.{lin}.W'] if g16 else dW, nout, nin,
                                    self.B, nout, nin, nin, accumulate=self.accumulate, partial=self._dw_partial(i, lin),
-                                   a_tr=True, b_tr=True, store_nt=True, c_bf16=g16)
+                                   a_tr=True, b_tr=True, store_nt=bool(TUNING['dw_store_nt']), c_bf16=g16)
         # (dy^T) (a^T)^T on the [features, B] copies, K (= batch) contiguous
         return nv.gemm_problem(w[dy_key + '_T'], w[a_key + '_T'], dW, nout, nin, self.B, self.B, self.B, nin,
                                accumulate=self.accumulate, partial=self._dw_partial(i, lin), store_nt=True)
