@@ -37,6 +37,8 @@ TUNING = {
     'defer_final': True, 'fused_sampler': True, 'gather_ride': True,
     'dw_store_nt': True,          # weight gradients stored non-temporally (next read by the optimiser, a backward pass later)
     'split_last_dw': True,        # data parallel (replicated): the last layer's dW in two launches, its first part on the wire early
+    'f32_dw_group': 4,            # fp32, no gradient exchange: the large layers' dW products wait and go out `n` layers per launch
+                                  # (4 layers = 2560 tiles of 128 x 128 = 5.0 rounds of 512 slots; one layer = 1.25 rounds); 1: off
 }
 
 
@@ -120,6 +122,11 @@ def plan_bf16_bwd(B, shapes):
 F32_CFG_ROWS = 12           # 128x128x32 tile on 16 waves of 32x32 (gemm_f32.hip; 8 waves of 64x32, cfg 4, is 5-7 % slower)
 F32_CFG_DW = 1              # fp32 dW (TN, K = batch): 64x64x32 tile (sweep: tools/sweep_f32_dw.sh)
 F32_CFG_DW_FUSED = 12       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
+
+
+def _f32_fused_cfg():
+    """Tile configuration of the fp32 dW launches that also write their tiles' sums of squares (TUNING['f32_dw_cfg'] overrides)."""
+    return int(TUNING['f32_dw_cfg']) if TUNING['f32_dw_cfg'] not in (None, '') else F32_CFG_DW_FUSED
 
 
 def launch_makespan(works, n_cu=N_CU, per_cu=2, solo=0.87):
@@ -404,7 +411,7 @@ class TrainEngine:
                      and all(min(model.p[f'm{i}.{lin}.W'].shape) >= 512 for lin in big for i in range(self.M)))
         self._f32_dw_fused = f32_fused
         if f32_fused or (self.bf16 and world_size == 1 and all(self.gcfg.get(k, -1) in BF16_TILE for k in big.values())):
-            bm_d, bn_d = nv.gemm_tile(nv.TN, 1 << 20, 1 << 20, B, F32_CFG_DW_FUSED) if f32_fused else BF16_TILE[self.gcfg['dw']]
+            bm_d, bn_d = nv.gemm_tile(nv.TN, 1 << 20, 1 << 20, B, _f32_fused_cfg()) if f32_fused else BF16_TILE[self.gcfg['dw']]
             self.dw_partial, off, covered = {}, 0, []
             for lin in tuple(big) + skinny_lins:
                 for i in range(self.M):
@@ -472,6 +479,7 @@ class TrainEngine:
         self._timing_every, self._timing_step = 1, 0
         self.pipeline = False            # enable_pipeline(): optimiser on its own stream, overlapped with the next forward
         self._zs = None                  # enable_sharded_optimizer(): packed shard state of a data-parallel run
+        self._dw_wait = None             # fp32 backward pass: the large layers' dW products waiting for _flush_dw
         self.side_transposes, self._wT_pending, self._wT_stale = False, False, False
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
@@ -886,12 +894,26 @@ class TrainEngine:
         else:
             nv.gemm(probs, nv.TN, self._f32_dw_cfg(lin))
 
+    def _flush_dw(self, last):
+        """fp32: the large layers' dW products that waited (+ `last`, the first layer's), TUNING['f32_dw_group'] layers per launch,
+        the latest gradients first.  One layer is 640 tiles of 128 x 128 at config 2 = 1.25 rounds of the chip's 512 slots (half
+        the chip idles through the second round); four layers are 5.0 rounds."""
+        todo = ([last] if last else []) + self._dw_wait[::-1]
+        self._dw_wait = None
+        per = max(1, min(int(TUNING['f32_dw_group']), nv.MAX_GEMM_GROUP // self.M))
+        while todo:
+            chunk, todo = todo[:per], todo[per:]
+            probs = []
+            for dy_key, a_key, lin in chunk:
+                probs += self._dw_problems(dy_key, a_key, lin)
+            nv.gemm(probs, nv.TN, _f32_fused_cfg())
+
     def _f32_dw_cfg(self, lin):
         """fp32 dW launch (TN, K = batch): tile configuration (-1: the library's 64 x 64 default)."""
         env = TUNING['f32_dw_cfg']
         big = self.B >= 256 and all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 512 for i in range(self.M))
         if big and self._f32_dw_fused:
-            return F32_CFG_DW_FUSED           # (the partial sums are laid out for this tile)
+            return _f32_fused_cfg()           # (the partial sums are laid out for this tile)
         return (int(env) if env else F32_CFG_DW) if big else -1
 
     def _dw_cfg(self, lin):
@@ -934,6 +956,13 @@ class TrainEngine:
         """dW (into the gradient buffer) and dX (slabs) of one Linear layer.  In bf16 mode both are the same
         K-contiguous NT product, so the four problems (2 modalities x {dW, dX}) go out as ONE grouped launch.
         `extra` = [(dy_key, a_key, lin)]: the dW problems of skinny layers ride in the same launch."""
+        if not self.bf16 and self._dw_wait is not None and self._f32_dw_cfg(lin) == _f32_fused_cfg():
+            # fp32: the weight gradient is not on the critical chain -- it waits for the end of the pass (_flush_dw)
+            self._dw_wait.append((dy_key, a_key, lin))
+            if extra:
+                self._dw_gemm(*extra[0], extra=extra[1:])
+            self._dx_gemm(dy_key, lin, out_key, sk_key)
+            return
         if not self.bf16 or 2 * self.M > nv.MAX_GEMM_GROUP:
             self._dw_gemm(dy_key, a_key, lin, extra, ranges)
             self._dx_gemm(dy_key, lin, out_key, sk_key)
@@ -1260,6 +1289,8 @@ class TrainEngine:
             self.refresh_weights_bf16(transposes_only=True)
             self._wT_stale = False
         self._fuse_now = self.fused_norm and allreduce is None      # a reduced gradient needs its norm taken afterwards
+        self._dw_wait = [] if (not self.bf16 and allreduce is None and int(TUNING['f32_dw_group']) > 1
+                               and self.M <= nv.MAX_GEMM_GROUP) else None
         self._g16_now = self.grad_bf16 and self._fuse_now and not self.accumulate
         if self.accumulate and self._g16_pending:
             raise nv.JamieHipError('gradients accumulate onto a backward pass that wrote bf16 weight gradients: call '
@@ -1352,7 +1383,13 @@ class TrainEngine:
             self._norm_ready = self._fuse_now
             self.m.num_batches_tracked += 1
             return
-        self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else dr.get('enc0'))
+        if self._dw_wait is not None:
+            big_last = self._f32_dw_cfg('enc0') == _f32_fused_cfg()
+            self._flush_dw(('da1', 'x', 'enc0') if big_last else None)
+            if not big_last:
+                self._dw_gemm('da1', 'x', 'enc0')
+        else:
+            self._dw_gemm('da1', 'x', 'enc0', ranges=self._range_args()[1] if ride else dr.get('enc0'))
         self._ranges_done = ride
         self._region(allreduce, 'rep')        # (adjacent to enc0: an all-reduce exchange merges the two into one message)
         self._region(allreduce, 'enc0')
