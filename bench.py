@@ -41,6 +41,7 @@ CONFIGS = {
 DEFAULT_DTYPE = {'c5': 'f32'}
 ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the exposure model (dp_model): stated, not measured
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1, true>'      # engine.F32_CFG_ROWS = 17 on the large layers
 PEAK_HBM_GBS = 8000.0
 SETTLE_STEPS = 100               # plan replays inside job construction, before the W warm-up steps (clock / cache steady state)
 LEG_BUDGET_S = 240.0             # N > 1: a sub-record leg (another data-parallel arrangement, timed behind the headline) is abandoned after this long
@@ -287,7 +288,7 @@ def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20):
     total = eng.read_losses()[1]
     return {'value': cells_s, 'unit': 'cells/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
             'dtype': 'f32', 'final_loss': total,
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1> (Linear d<->2d forward '
+            'roofline': {'bound': 'mfma', 'kernel': F32_ROOFLINE_KERNEL + ' (Linear d<->2d forward '
                                                      'GEMM, both modalities in one launch; 4 launches/step)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': tm['median'], 'flop_per_launch': gemm_flop,
@@ -648,7 +649,7 @@ def main():
                 traffic = None
         if args.dtype == 'f32':
             achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1> (Linear d<->2d forward '
+            roof = {'bound': 'mfma', 'kernel': F32_ROOFLINE_KERNEL + ' (Linear d<->2d forward '
                                               'GEMM, both modalities in one launch; 4 launches/step)',
                     'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop,

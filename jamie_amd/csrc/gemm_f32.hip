@@ -18,7 +18,8 @@
 //   * split-K writes fp32 slabs (deterministic; the consumer kernel sums them).
 #include "common.h"
 
-// diagnostic ablations (tools/ablate_gemm.sh): 1 = no global loads in the k-loop, 2 = no MFMAs, 3 = no LDS writes
+// diagnostic ablations of the register-staged k-loop (tools/ablate_gemm.sh; results are wrong, timings only), a bit mask:
+// 1 = no global loads in the k-loop, 2 = no MFMAs, 4 = no LDS writes, 8 = no barrier, 16 = no fragment reads
 #ifndef JAMIE_GEMM_ABL
 #define JAMIE_GEMM_ABL 0
 #endif
@@ -33,9 +34,17 @@ __device__ unsigned long long jamie_dbg_stamps_f32[8192 * 8];
 extern "C" int jamie_debug_stamps_f32(unsigned long long* host_out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(jamie_dbg_stamps_f32), sizeof(unsigned long long) * 8 * n_blocks);
 }
+// k-loop phases of waves 0, 5, 10, 15 of every workgroup at its middle k-step: [wave slot][loop top, MFMAs issued, tile stored, past barrier]
+__device__ unsigned long long jamie_dbg_kstamps_f32[8192 * 16];
+#define JF_KSTAMP(kt, nk, k) do { if ((kt) == (nk) / 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 5 == 0 && blockIdx.x < 8192) \
+    jamie_dbg_kstamps_f32[blockIdx.x * 16 + ((threadIdx.x >> 6) / 5) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int jamie_debug_kstamps_f32(unsigned long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(jamie_dbg_kstamps_f32), sizeof(unsigned long long) * 16 * n_blocks);
+}
 #else
 #define JF_STAMP(k) do {} while (0)
 #define JF_STAMPV(k, v) do {} while (0)
+#define JF_KSTAMP(kt, nk, k) do {} while (0)
 #endif
 
 struct GemmDev {
@@ -74,8 +83,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // invalid rows / k-slices are expressed as an out-of-range offset and the in-row tails as selects.  (The
 // guarded flat-load version serialises every load behind its own branch + s_waitcnt vmcnt(0).)
 #define JAMIE_OOB 0xFFFFFFF0u
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned scalar_off = 0) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)scalar_off, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 // applied when the tile is written to LDS (AFTER the MFMAs of the previous tile), so that the loads stay
@@ -89,13 +98,17 @@ __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
     return f;
 }
 
-// FAST = true : operands addressed through buffer descriptors (needs 16-byte aligned bases, ld % 4 == 0,
-//               < 4 GiB per operand, no row gather); FAST = false: guarded flat loads (any shape/alignment).
+// FAST = 1 / 2 : operands addressed through buffer descriptors (needs 16-byte aligned bases, ld % 4 == 0,
+//               < 4 GiB per operand, no row gather); 2: no operand row ends inside a float4 either (K % 4 == 0 for a
+//               K-contiguous operand, M / N % 4 == 0 otherwise: every layer of every BASELINE configuration) -- the LDS
+//               writes need no masks; FAST = 0: guarded flat loads (any shape/alignment).
 // TAG = 1 marks launches in which every problem is one of the big d <-> 2d Linear products: the same code under
 // a second kernel symbol, so that per-kernel profiles (rocprofv3 --stats) of the dominant GEMMs are not mixed with
 // the skinny heads / latent products.
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool FAST, int TAG>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
+// MID = true: the k-loop with its one barrier in the MIDDLE of a k-step's MFMA stream (see the loop).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int FAST, int TAG, bool MID = false>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 16 ? 8 : 1)))      // (16 waves: two workgroups per CU)
+void gemm_f32_kernel(GemmGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_LD = A_KC ? BK + 4 : BM + 4;
@@ -116,6 +129,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     // tiles), and a weight panel is fetched from HBM into one L2 only.  Remainders are dealt round-robin
     // (rotation o_p) so the chunk sizes add up to exactly the number of blocks each XCD receives.
     JF_STAMP(0);
+    JF_STAMPV(6, __builtin_amdgcn_s_memtime());      // shader-clock ticks (slot 7 at the end): the clock the launch ran at
+
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     int slot = bid >> 3;
@@ -198,36 +213,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     }
 
     // ---- FAST path: buffer descriptors (wave-uniform) and per-thread byte offsets ----
+    // A vector instruction beside the MFMAs costs the matrix pipe ~2.5 cycles whatever the occupancy (tools/micro/mfma_valu.hip:
+    // 155 TF with none, 144 with 2 per MFMA, 133 with 4; scalar instructions and LDS reads are free), so the k-loop keeps its
+    // per-thread offsets CONSTANT: the tile's position along K is the loads' SCALAR offset, the rows beyond M / N are an
+    // out-of-range offset from the start, and a load costs one compare + select (k >= K -> out of range -> 0).  (The select, not
+    // num_records, bounds k: whether the range check sees the scalar offset differs between descriptions of the hardware; the
+    // out-of-range constant is out of range either way.)
+    unsigned a_vo[LA], b_vo[LB];
     __amdgpu_buffer_rsrc_t a_rs, b_rs;
-    unsigned a_off[LA], b_off[LB];
     if (FAST) {
         a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (int)P.a_bytes, 0x00020000);
         b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (int)P.b_bytes, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < LA; ++j) a_off[j] = (unsigned)((a_ptr[j] - P.A) * 4);
+        for (int j = 0; j < LA; ++j)
+            a_vo[j] = a_lim[j] ? (unsigned)((a_ptr[j] - P.A) * 4) + (A_KC ? 0u : (unsigned)a_k[j] * (unsigned)P.lda * 4u) : JAMIE_OOB;
 #pragma unroll
-        for (int j = 0; j < LB; ++j) b_off[j] = (unsigned)((b_ptr[j] - P.B) * 4);
+        for (int j = 0; j < LB; ++j)
+            b_vo[j] = b_lim[j] ? (unsigned)((b_ptr[j] - P.B) * 4) + (B_KC ? 0u : (unsigned)b_k[j] * (unsigned)P.ldb * 4u) : JAMIE_OOB;
     }
-
+    // (running scalar offsets, advanced by every load_tile call -- calls come in k order, one BK apart)
+    const unsigned a_step = __builtin_amdgcn_readfirstlane((A_KC ? (unsigned)BK : (unsigned)BK * (unsigned)P.lda) * 4u);
+    const unsigned b_step = __builtin_amdgcn_readfirstlane((B_KC ? (unsigned)BK : (unsigned)BK * (unsigned)P.ldb) * 4u);
+    unsigned a_so = __builtin_amdgcn_readfirstlane((unsigned)(kbeg / BK) * a_step);
+    unsigned b_so = __builtin_amdgcn_readfirstlane((unsigned)(kbeg / BK) * b_step);
     float4 ra[LA], rb[LB];
     auto load_tile = [&](int k0) {
         if (FAST) {
+            const int kleft = kend - k0;         // (scalar; one compare + select per load: only the last k-tile's lanes beyond K)
 #pragma unroll
-            for (int j = 0; j < LA; ++j) {
-                const int k = k0 + a_k[j];
-                if (A_KC)
-                    ra[j] = buf_ld4(a_rs, a_lim[j] ? a_off[j] + (unsigned)k0 * 4u : JAMIE_OOB);
-                else
-                    ra[j] = buf_ld4(a_rs, k < kend ? a_off[j] + (unsigned)k * (unsigned)P.lda * 4u : JAMIE_OOB);
-            }
+            for (int j = 0; j < LA; ++j) ra[j] = buf_ld4(a_rs, a_k[j] < kleft ? a_vo[j] : JAMIE_OOB, a_so);
 #pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const int k = k0 + b_k[j];
-                if (B_KC)
-                    rb[j] = buf_ld4(b_rs, b_lim[j] ? b_off[j] + (unsigned)k0 * 4u : JAMIE_OOB);
-                else
-                    rb[j] = buf_ld4(b_rs, k < kend ? b_off[j] + (unsigned)k * (unsigned)P.ldb * 4u : JAMIE_OOB);
-            }
+            for (int j = 0; j < LB; ++j) rb[j] = buf_ld4(b_rs, b_k[j] < kleft ? b_vo[j] : JAMIE_OOB, b_so);
+            a_so += a_step; b_so += b_step;
             return;
         }
 #pragma unroll
@@ -261,13 +278,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             float4 v = ra[j];
-            if (FAST) v = mask4(v, A_KC ? kend - (k0 + a_k[j]) : a_lim[j]);   // in-row tails (k or m)
+            if (FAST == 1) v = mask4(v, A_KC ? kend - (k0 + a_k[j]) : a_lim[j]);   // in-row tails (k or m)
             *reinterpret_cast<float4*>(&As[a_lds[j]]) = v;
         }
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             float4 v = rb[j];
-            if (FAST) v = mask4(v, B_KC ? kend - (k0 + b_k[j]) : b_lim[j]);
+            if (FAST == 1) v = mask4(v, B_KC ? kend - (k0 + b_k[j]) : b_lim[j]);
             *reinterpret_cast<float4*>(&Bs[b_lds[j]]) = v;
         }
     };
@@ -284,12 +301,91 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
         load_tile(kbeg);
         store_tile(0, kbeg);
     }
+    if constexpr (MID) {
+        // One barrier per k-step, between the MFMAs of the last-but-one and the last k-group.  A k-step of the loop below leaves
+        // the matrix pipe idle twice (in-kernel stamps, tools/stamp_gemm_f32.py: ~250 ns after its barrier until the first
+        // fragments of the new tile are back from LDS, ~240 ns in front of it while the next tile is written: 20 % of a k-step
+        // of one workgroup, and two workgroups per CU only win back half).  Here the next tile is written to LDS right behind
+        // the FIRST k-group's MFMAs (its global loads were issued a k-step earlier; the loads of the tile after it go out as
+        // soon as the staging registers are free), every fragment read of the current tile is issued before the barrier
+        // (k-group g+1 is fetched under the MFMAs of g), and the first fragments of the NEXT tile are fetched right behind it,
+        // under the last k-group's MFMAs.  Hazards: the buffer written in k-step kt was last read in k-step kt-1, whose reads
+        // all completed in front of that step's barrier; the buffer read behind the barrier was written in front of it.
+        constexpr int G = BK / 8;
+        static_assert(G % 2 == 0, "k-groups alternate between two fragment sets");
+        if (nk > 1) load_tile(kbeg + BK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        JF_STAMP(1);
+        float af[2][TM][4], bf[2][TN][4];
+        auto read_frags = [&](int buf, const float* As, const float* Bs, int kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (A_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + r) * A_LD + kk + 4 * h]);
+                    af[buf][i][0] = v.x; af[buf][i][1] = v.y; af[buf][i][2] = v.z; af[buf][i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[buf][i][s] = As[(kk + 4 * h + s) * A_LD + wm0 + i * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + r) * B_LD + kk + 4 * h]);
+                    bf[buf][j][0] = v.x; bf[buf][j][1] = v.y; bf[buf][j][2] = v.z; bf[buf][j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[buf][j][s] = Bs[(kk + 4 * h + s) * B_LD + wn0 + j * 32 + r];
+                }
+            }
+        };
+        if (nk > 0) read_frags(0, smem, smem + A_SZ, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            const float* As = smem + cur * (A_SZ + B_SZ);
+            const float* Bs = As + A_SZ;
+            const float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+            JF_KSTAMP(kt, nk, 0);
+#pragma unroll
+            for (int gk = 0; gk < G; ++gk) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (gk + 1 < G) read_frags((gk + 1) & 1, As, Bs, (gk + 1) * 8);
+                else if (more) read_frags(0, An, An + A_SZ, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gk & 1][i][s], bf[gk & 1][j][s], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gk == 0) {
+                    if (more) store_tile(cur ^ 1, kbeg + (kt + 1) * BK);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + 2 < nk) load_tile(kbeg + (kt + 2) * BK);
+                    JF_KSTAMP(kt, nk, 1);
+                }
+                if (gk == G - 2) {
+                    JF_KSTAMP(kt, nk, 2);
+                    // (the builtin, not inline asm: the compiler's wait-count pass then knows that the last k-group's fragments
+                    //  have arrived and waits with lgkmcnt(2), not (0), in front of its MFMAs -- behind the next tile's first reads)
+                    __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
+                    __builtin_amdgcn_s_barrier();
+                    JF_KSTAMP(kt, nk, 3);
+                }
+            }
+        }
+    } else {
     __syncthreads();
     JF_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more && JAMIE_GEMM_ABL != 1) load_tile(kbeg + (kt + 1) * BK);
+        JF_KSTAMP(kt, nk, 0);
+        if (more && !(JAMIE_GEMM_ABL & 1)) load_tile(kbeg + (kt + 1) * BK);
         const float* As = smem + cur * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
         // fragments are fetched one k-group (8 k) ahead of the MFMAs that consume them, so the LDS latency
@@ -317,11 +413,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
                 }
             }
         };
+#if JAMIE_GEMM_ABL & 16
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("v_mov_b32 %0, 1.0" : "=v"(af[q][i][s]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("v_mov_b32 %0, 1.0" : "=v"(bf[q][j][s]));
+            }
+#else
         read_frags(0, 0);
+#endif
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
             __builtin_amdgcn_sched_barrier(0);   // pin: reads of group g+1 are ISSUED before the MFMAs of group g
-            if (gk + 1 < BK / 8) read_frags((gk + 1) & 1, (gk + 1) * 8);
+            if (gk + 1 < BK / 8 && !(JAMIE_GEMM_ABL & 16)) read_frags((gk + 1) & 1, (gk + 1) * 8);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -330,7 +438,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                     {
-#if JAMIE_GEMM_ABL == 2
+#if JAMIE_GEMM_ABL & 2
                         asm volatile("" ::"v"(af[gk & 1][i][s]), "v"(bf[gk & 1][j][s]));
 #else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gk & 1][i][s], bf[gk & 1][j][s], acc[i][j], 0, 0, 0);
@@ -338,8 +446,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
                     }
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the masks / LDS writes (and their vmcnt wait) after the MFMAs
-        if (more && JAMIE_GEMM_ABL != 3) store_tile(cur ^ 1, kbeg + (kt + 1) * BK);
-        __syncthreads();
+        JF_KSTAMP(kt, nk, 1);
+        if (more && !(JAMIE_GEMM_ABL & 4)) store_tile(cur ^ 1, kbeg + (kt + 1) * BK);
+        JF_KSTAMP(kt, nk, 2);
+        if (!(JAMIE_GEMM_ABL & 8)) __syncthreads();
+        JF_KSTAMP(kt, nk, 3);
+    }
     }
 
     JF_STAMP(2);
@@ -396,6 +508,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmGroup g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     JF_STAMP(3);
+    JF_STAMPV(7, __builtin_amdgcn_s_memtime());
+
 #endif
 }
 
@@ -632,13 +746,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool MID = false>
 static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     GemmGroup g;
     memset(&g, 0, sizeof(g));
     g.count = count;
     int tiles = 0;
-    bool fast = true, big = true;
+    bool fast = true, big = true, tails = false;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];
         GemmDev& d = g.p[i];
@@ -651,6 +765,7 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         int kc = (s.K + d.splitk - 1) / d.splitk;
         kc = ((kc + BK - 1) / BK) * BK;
         if (kc < BK) kc = BK;
+        if ((A_KC ? s.K : s.M) % 4 != 0 || (B_KC ? s.K : s.N) % 4 != 0) tails = true;
         d.kchunk = kc;
         d.tiles_m = (s.M + BM - 1) / BM;
         d.tiles_n = (s.N + BN - 1) / BN;
@@ -671,14 +786,17 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
     if (tiles == 0) return 0;
-    if (fast && big)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, true, 1>), dim3(tiles),
+    if (fast && big && !tails)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 1, MID>), dim3(tiles),
+                           dim3(WM * WN * 64), 0, st, g);
+    else if (fast && !tails)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 0, MID>), dim3(tiles),
                            dim3(WM * WN * 64), 0, st, g);
     else if (fast)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, true, 0>), dim3(tiles),
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 1, 0, MID>), dim3(tiles),
                            dim3(WM * WN * 64), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, false, 0>), dim3(tiles),
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 0, 0, false>), dim3(tiles),
                            dim3(WM * WN * 64), 0, st, g);
     return jamie_launch_status("jamie_gemm_f32");
 }
@@ -756,6 +874,8 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
             }
         case 15: return launch_cfg<256, 128, 32, 4, 4, A_KC, B_KC>(pr, count, st);    // 16 waves of 64x32, one workgroup per CU
         case 16: return launch_cfg<128, 256, 32, 4, 4, A_KC, B_KC>(pr, count, st);    // 16 waves of 32x64
+        case 17: return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC, true>(pr, count, st);   // 12 with the barrier in mid k-step
+        case 18: return launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC, true>(pr, count, st);      // 1 likewise
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
 }
@@ -807,10 +927,10 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[17][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
-                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 256}};
+    static const int T[19][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
+                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 256}, {128, 128}, {64, 64}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 16 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 18 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

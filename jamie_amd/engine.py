@@ -28,6 +28,7 @@ TUNING = {
     'bwd_k_per_slab': 1700.0,     # K per split-K slab of the bf16 dX products
     'sk_skinny': None,            # slab count of the skinny head / latent products
     'f32_dw_cfg': None, 'f32_dx_cfg': None,      # fp32 tile configurations of the dW / dX launches
+    'f32_rows_cfg': None,         # ... of the planned forward / dX launches (the planner's K slices stay)
     'prefetch': 1,                # BatchNorm prefetch riders: 0 off, 1 the next product's weights, 2 + saved activations
     'prefetch_f32': '0',          # ... in fp32 mode: '0' off (default: +38 us there), '1' on, 'bwd' backward only
     'stagger': True,              # flat optimiser buffers start 4 KB apart
@@ -119,9 +120,10 @@ def plan_bf16_bwd(B, shapes):
     return BF16_CFG_DW, [int(max(1, min(round(K / per), 4, K // 256))) for (N, K) in shapes]
 
 
-F32_CFG_ROWS = 12           # 128x128x32 tile on 16 waves of 32x32 (gemm_f32.hip; 8 waves of 64x32, cfg 4, is 5-7 % slower)
+F32_CFG_ROWS = 17           # 128x128x32 tile on 16 waves of 32x32, barrier in mid k-step (gemm_f32.hip; 12: the barrier at the end,
+                            # +1.3 % per step; 8 waves of 64x32, cfg 4, is 5-7 % slower)
 F32_CFG_DW = 1              # fp32 dW (TN, K = batch): 64x64x32 tile (sweep: tools/sweep_f32_dw.sh)
-F32_CFG_DW_FUSED = 12       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
+F32_CFG_DW_FUSED = 17       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
 
 
 def _f32_fused_cfg():
@@ -186,11 +188,11 @@ def launch_makespan(works, n_cu=N_CU, per_cu=2, solo=0.87):
 
 def plan_f32_rows(B, shapes):
     """(tile configuration, K slices per problem) of an fp32 forward / dX launch; see _plan_f32_rows."""
-    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), TUNING['f32_rows'])
+    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), TUNING['f32_rows'], TUNING['f32_rows_cfg'])
 
 
 @functools.lru_cache(maxsize=256)
-def _plan_f32_rows(B, shapes, _knob):
+def _plan_f32_rows(B, shapes, _knob, _tile=None):
     """fp32 forward / dX launch with shapes = [(N_i, K_i)]: the 128x128x32 tile (two workgroups per CU) with K slices of one
     common length, chosen by a model of the launch: workgroup work = k-steps + 3 (prologue, store tail), launch time =
     launch_makespan of the grid (every problem's slices in problem order) + what the extra slabs cost their consumer
@@ -220,7 +222,7 @@ def _plan_f32_rows(B, shapes, _knob):
         cost = launch_makespan(works) * kstep_us + slabs
         if best is None or cost < best[0] - 1e-9:
             best = (cost, list(sk))
-    return (F32_CFG_ROWS, best[1]) if best else (-1, None)
+    return (int(_tile) if _tile not in (None, '') else F32_CFG_ROWS, best[1]) if best else (-1, None)
 
 
 def kl_anneal(epoch, min_epochs, epoch_DNN):

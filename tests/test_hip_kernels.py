@@ -57,12 +57,14 @@ def test_gemm_layouts(nv, layout, M, N, K):
     close(out, ref, rtol=1e-5, atol=2e-6 * scale)
 
 
-@pytest.mark.parametrize('cfg', [4, 10, 11, 12, 15, 16])
+@pytest.mark.parametrize('cfg', [4, 10, 11, 12, 15, 16, 17, 18])
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
 def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
     """The register-staged fp32 kernel on its larger tiles (128x128 on 8 / 16 waves, 64x128, 128x64, 256x128, 128x256) in every
-    operand layout, ragged edges and split-K slabs included, against fp64."""
-    for (M, N, K, sk) in ((512, 520, 264, 1), (300, 200, 100, 1), (512, 384, 1000, 3)):
+    operand layout, ragged edges and split-K slabs included, against fp64.  17 / 18 = 12 / 1 with the k-loop whose barrier sits in
+    the middle of a k-step (one, two, odd and even numbers of k-steps): the same products in the same order, bit for bit."""
+    twin = {17: 12, 18: 1}.get(cfg)
+    for (M, N, K, sk) in ((512, 520, 264, 1), (300, 200, 100, 1), (512, 384, 1000, 3), (130, 72, 20, 1), (64, 200, 40, 1), (100, 100, 65, 1)):
         g = torch.Generator().manual_seed(M + N + K + cfg)
         a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
         out = torch.full((sk, M, N), float('nan'), device='cuda')
@@ -75,6 +77,15 @@ def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
             nv.gemm([nv.gemm_problem(dev(a.t()), dev(b), out, M, N, K, M, N, N, **kw)], nv.TN, cfg)
         torch.cuda.synchronize()
         close(out.sum(0), a.double() @ b.double(), rtol=1e-5, atol=2e-6 * float(np.sqrt(K)), msg=f'{layout} cfg {cfg} {(M, N, K, sk)}')
+        if twin is not None:
+            ref = torch.full((sk, M, N), float('nan'), device='cuda')
+            if layout == 'NT':
+                nv.gemm([nv.gemm_problem(dev(a), dev(b.t()), ref, M, N, K, K, K, N, **kw)], nv.NT, twin)
+            elif layout == 'NN':
+                nv.gemm([nv.gemm_problem(dev(a), dev(b), ref, M, N, K, K, N, N, **kw)], nv.NN, twin)
+            else:
+                nv.gemm([nv.gemm_problem(dev(a.t()), dev(b), ref, M, N, K, M, N, N, **kw)], nv.TN, twin)
+            assert torch.equal(out, ref), f'{layout} cfg {cfg} != cfg {twin} at {(M, N, K, sk)}'
 
 
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES + [(512, 2000, 1000), (130, 72, 1002), (64, 64, 20)])

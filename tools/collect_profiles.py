@@ -10,7 +10,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', tag)
 dst = os.path.join(root, 'profiles')
 bench = json.load(open(os.path.join(src, 'bench.json')))
-KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1>' if bench['dtype'] == 'f32' else 'clip_adam_kernel'
+KERNEL = bench['roofline']['kernel'].split(' (')[0] if bench['dtype'] == 'f32' else 'clip_adam_kernel'
 def avg_counter(d, counter):
     f = glob.glob(os.path.join(src, d, '*', '*_counter_collection.csv'))[0]
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
