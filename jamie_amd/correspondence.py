@@ -57,7 +57,7 @@ class PrimeDual:
         st.m, st.n, st.rho, st.epsilon = m, n, self.rho, self.epsilon
         self._state = st
         # large squares: the 128x128x32 tile on 16 waves (tools/bench_prime_dual.py); small problems: the 64x64 default
-        self.gemm_cfg = (12 if min(m, n) >= 1024 else -1) if gemm_cfg is None else int(gemm_cfg)
+        self.gemm_cfg = (17 if min(m, n) >= 1024 else -1) if gemm_cfg is None else int(gemm_cfg)
         P = nv.gemm_problem
         self._t1 = [P(self.F, self.FKy, self.T1, n, n, m, n, n, n)]             # T1 [n,n] = F^T FKy        (TN)
         self._g1 = [P(self.FKy, self.T1, self.G1, m, n, n, n, n, n)]            # G1 [m,n] = FKy T1         (NN)

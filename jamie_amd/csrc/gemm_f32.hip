@@ -886,7 +886,7 @@ static int pick_cfg(int layout, int max_m, int max_n, int max_k) {
     // measured on MI355X at the config-2 layer shapes (tools/bench_gemm.py, profiles/): the 64x64x32 tile
     // (3-4 workgroups per CU, finest load balance between the two modalities) wins or ties every layout
     (void)layout; (void)max_m; (void)max_n; (void)max_k;
-    return 1;
+    return 1;         // (18, the same tile with the barrier in mid k-step: no difference on these short launches)
 }
 
 extern "C" int jamie_gemm_f32_cfg(const jamie_gemm_problem* pr, int count, int layout, int cfg, void* stream) {

@@ -327,7 +327,7 @@ class edModelVar:
         (tools/bench_gemm_sq.py, tools/bench_infer.py); the class attribute EVAL_GEMM_CFG overrides (diagnostics)."""
         if edModelVar.EVAL_GEMM_CFG is not None:
             return int(edModelVar.EVAL_GEMM_CFG)
-        return 12 if (n >= 2048 and nout >= 512 and k >= 512) else -1
+        return 17 if (n >= 2048 and nout >= 512 and k >= 512) else -1
 
     def _lin_bn_act(self, i, x, lin, bn):
         W, b = self.p[f'm{i}.{lin}.W'], self.p[f'm{i}.{lin}.b']

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from jamie_amd.model import edModelVar
 N, dims, L = 100000, (2000, 1000), 32
+if os.environ.get('EVAL_CFG'):           # fp32 GEMM tile configuration of the eval path (diagnostics: 12 against 17)
+    edModelVar.EVAL_GEMM_CFG = int(os.environ['EVAL_CFG'])
 torch.manual_seed(0)
 model = edModelVar(dims, L).eval()
 g = torch.Generator(device='cuda').manual_seed(1)
