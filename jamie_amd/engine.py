@@ -28,6 +28,7 @@ TUNING = {
     'bwd_k_per_slab': 1700.0,     # K per split-K slab of the bf16 dX products
     'sk_skinny': None,            # slab count of the skinny head / latent products
     'f32_dw_cfg': None, 'f32_dx_cfg': None,      # fp32 tile configurations of the dW / dX launches
+    'f32_dw_small_cfg': None,     # ... of the skinny layers' dW launch (decoder layer 0, heads)
     'f32_rows_cfg': None,         # ... of the planned forward / dX launches (the planner's K slices stay)
     'prefetch': 1,                # BatchNorm prefetch riders: 0 off, 1 the next product's weights, 2 + saved activations
     'prefetch_f32': '0',          # ... in fp32 mode: '0' off (default: +38 us there), '1' on, 'bwd' backward only
@@ -916,7 +917,8 @@ class TrainEngine:
         big = self.B >= 256 and all(min(self.m.p[f'm{i}.{lin}.W'].shape) >= 512 for i in range(self.M))
         if big and self._f32_dw_fused:
             return _f32_fused_cfg()           # (the partial sums are laid out for this tile)
-        return (int(env) if env else F32_CFG_DW) if big else -1
+        small = TUNING['f32_dw_small_cfg']
+        return (int(env) if env else F32_CFG_DW) if big else (int(small) if small not in (None, '') else -1)
 
     def _dw_cfg(self, lin):
         """Tile configuration of the dW launch of layer `lin` (-1: the library default for small / skinny problems)."""
@@ -1342,6 +1344,8 @@ class TrainEngine:
         else:
             self._bwd_gemms('dml', 'head', 'a2', 'da2', 'd_a2')
             self._region(allreduce, 'head')
+        # (fp32, deferred dW: the skinny layers' dW launch -- 0.3 GFLOP, 16 dependent k-steps, 20 us -- on a second stream beside this
+        #  BatchNorm backward launch costs 30 us more than it saves: profiles/r04_ab_f32_skinny_dw_side_stream_rejected.log)
         self._bn_bwd('bn1', 'da2', 'h2', 'enc1', 11, noise, 'enc_masks', 1, prefetch=('W:enc1', 'a1_bf', 'h1', 'x_bf'))   # da2[0] <- dh2p
         self._cast('da2')
         self._bwd_gemms('da2', 'enc1', 'a1', 'da1', 'd_a1', extra=late_dw, ranges=dr.get('enc1'))
