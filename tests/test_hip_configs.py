@@ -699,7 +699,7 @@ def test_eval_fast_path_many_rows_vs_oracle(jam):
     are both crossed; rtol 1e-4 / atol 1e-5 against the oracle from identical weights (north_star's inference claim)."""
     dims, L = (2000, 1000), 32
     model, P, Bf = _seeded_eval_model(jam, dims, L)
-    assert model._eval_cfg(4096, 2000, 2000) == 12
+    assert model._eval_cfg(4096, 2000, 2000) == 17
     n = 5000
     X = _synth(n, dims, seed=8)
     with torch.no_grad():

@@ -819,6 +819,37 @@ def test_full_size_config2_step_vs_oracle(jam):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+def test_fp32_weight_gradients_grouped_at_the_end_equal_one_launch_per_layer(jam):
+    """fp32, one GPU: the large layers' dW products wait for the end of the backward pass and go out as ONE launch
+    (engine.TUNING['f32_dw_group'] = 4: 2560 tiles = 5.0 rounds of the chip's 512 slots instead of 4 x 1.25).  Same tiles,
+    same k order, same per-tile sums of squares: gradients, clip norm and the updated parameters equal the
+    one-launch-per-layer order (f32_dw_group = 1) bit for bit, at config 2's layer sizes."""
+    from jamie_amd import engine
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    B, dims, L = 512, (2000, 1000), 32
+    g = torch.Generator().manual_seed(5)
+    X = [torch.randn(B, d, generator=g).cuda() for d in dims]
+    out = []
+    try:
+        for group in (1, 4, 2):
+            engine.tune(f32_dw_group=group)
+            torch.manual_seed(666)
+            model = edModelVar(dims, L)
+            eng = TrainEngine(model, B, seed=3)
+            assert eng._f32_dw_fused
+            eng.set_batch(X)
+            for _ in range(2):
+                eng.step()
+            out.append((eng.grad.clone(), eng.norm_partials.clone(), model.flat.clone()))
+            del eng, model
+    finally:
+        engine.tune(f32_dw_group=4)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('B,dims,L,p', [(64, (40, 32, 24), 8, 0.0), (256, (264, 200, 136), 16, 0.6),
                                         (96, (56, 44, 36), 10, 0.6), (64, (40, 32, 24, 20), 6, 0.0), (128, (72, 48, 40), 33, 0.6)])
 def test_three_modalities_step_vs_generalised_oracle(jam, B, dims, L, p):
