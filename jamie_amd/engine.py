@@ -981,7 +981,9 @@ class TrainEngine:
         if left:                      # (more than two modalities: the skinny layers' dW share a launch of their own)
             self._dw_gemm(*left[0], extra=left[1:])
         # the dX tiles run 2-3x as long as the dW tiles (K = features / slices vs K = batch): they go first in the
-        # grid so that the short dW tiles fill in behind them (in-kernel stamps: the launch ends 4-5 us earlier)
+        # grid so that the short dW tiles fill in behind them (in-kernel stamps: the launch ends 4-5 us earlier).
+        # (fp32's order -- dX launches alone, every dW tile in one last launch -- costs bf16 +33 us per step: here the dW tiles ARE
+        #  the filler of the dX launches, profiles/r04_ab_bf16_dw_all_in_last_launch_rejected.log)
         probs = []
         for i, d in enumerate(self.dims):
             w = self.ws[i]
