@@ -41,7 +41,7 @@ CONFIGS = {
 DEFAULT_DTYPE = {'c5': 'f32'}
 ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the exposure model (dp_model): stated, not measured
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, true, 1, true>'      # engine.F32_CFG_ROWS = 17 on the large layers
+F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, 2, 1, true>'      # engine.F32_CFG_ROWS = 17 on the large layers
 PEAK_HBM_GBS = 8000.0
 SETTLE_STEPS = 100               # plan replays inside job construction, before the W warm-up steps (clock / cache steady state)
 LEG_BUDGET_S = 240.0             # N > 1: a sub-record leg (another data-parallel arrangement, timed behind the headline) is abandoned after this long
