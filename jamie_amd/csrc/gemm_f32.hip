@@ -111,8 +111,11 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM
 void gemm_f32_kernel(GemmGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_LD = A_KC ? BK + 4 : BM + 4;
-    constexpr int B_LD = B_KC ? BK + 4 : BN + 4;
+    // (row-contiguous images need no padding: a 32-lane group of ds_read_b32 reads 32 consecutive dwords of ONE k row, an 8-lane
+    //  group of ds_write_b128 writes 128 contiguous bytes; rows a multiple of 256 bytes apart let all four k rows of a fragment
+    //  come from one base register by ds_read2st64_b32 -- with the 4-dword pad every pair needed an address add of its own)
+    constexpr int A_LD = A_KC ? BK + 4 : BM;
+    constexpr int B_LD = B_KC ? BK + 4 : BN;
     constexpr int A_SZ = A_KC ? BM * A_LD : BK * A_LD;
     constexpr int B_SZ = B_KC ? BN * B_LD : BK * B_LD;
     constexpr int LA = BM * BK / 4 / NT, LB = BN * BK / 4 / NT;
