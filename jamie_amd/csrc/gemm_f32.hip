@@ -107,7 +107,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
 // the skinny heads / latent products.
 // MID = true: the k-loop with its one barrier in the MIDDLE of a k-step's MFMA stream (see the loop).
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int FAST, int TAG, bool MID = false>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 16 ? 8 : 1)))      // (16 waves: two workgroups per CU)
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 16 && BM * BN <= 128 * 128 ? 8 : 1)))      // (16 waves of 32x32: two workgroups per CU)
 void gemm_f32_kernel(GemmGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
