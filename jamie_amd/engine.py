@@ -123,7 +123,9 @@ def plan_bf16_bwd(B, shapes):
 
 F32_CFG_ROWS = 17           # 128x128x32 tile on 16 waves of 32x32, barrier in mid k-step (gemm_f32.hip; 12: the barrier at the end,
                             # +1.3 % per step; 8 waves of 64x32, cfg 4, is 5-7 % slower)
-F32_CFG_DW = 1              # fp32 dW (TN, K = batch): 64x64x32 tile (sweep: tools/sweep_f32_dw.sh)
+F32_CFG_DW = 17             # fp32 dW (TN, K = batch) of the large layers when the launches do not carry the fused clip norm (gradient
+                            # exchange): the mid-barrier 128x128 tile (round 2's sweep had 64x64, configuration 1; with round 4's loop
+                            # config 5's dimensions run 6.86 against 6.97 ms per step, config 2 the same: r04_f32_dp_dw_tile.log)
 F32_CFG_DW_FUSED = 17       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
 
 
