@@ -31,6 +31,7 @@ extern "C" {
 
 #define JAMIE_MAX_GROUP 4      /* problems per grouped launch (modalities) */
 #define JAMIE_MAX_GEMM_GROUP 8 /* problems per grouped GEMM launch (modalities x {dX, dW} + a skinny layer's dW riding along) */
+#define JAMIE_MAX_GEMM_GROUP_F32 12 /* ... of jamie_gemm_f32 / _cfg (fp32: the four large layers' dW of two modalities + the two skinny layers' in one launch) */
 
 const char* jamie_last_error(void);
 int jamie_version(void);

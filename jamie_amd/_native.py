@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('JAMIE_HIP_LIB') or os.path.join(_HERE, 'libjamie_hip.
 
 MAX_GROUP = 4
 MAX_GEMM_GROUP = 8          # JAMIE_MAX_GEMM_GROUP: problems per grouped GEMM launch
+MAX_GEMM_GROUP_F32 = 12     # JAMIE_MAX_GEMM_GROUP_F32: ... of the fp32 entry points
 NT, NN, TN = 0, 1, 2
 EPI_STORE, EPI_MSE, EPI_BN_EVAL = 0, 1, 2
 

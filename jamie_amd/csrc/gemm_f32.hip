@@ -13,7 +13,7 @@
 //       row-contiguous operand ("RC"): LDS [BK][rows+4]; a lane reads 4 ds_read_b32 (lanes consecutive).
 //     MFMA step s of a k-group of 8 consumes logical k = kk + 4*(lane>>5) + s for BOTH operands.
 //   * double-buffered LDS, next tile's global loads issued before the MFMAs of the current tile.
-//   * grouped launch: up to JAMIE_MAX_GEMM_GROUP problems (the modalities) share one grid; block ids are
+//   * grouped launch: up to JAMIE_MAX_GEMM_GROUP_F32 problems (the modalities) share one grid; block ids are
 //     remapped so that the M-tiles that re-read one weight panel run back to back on one XCD (its L2).
 //   * split-K writes fp32 slabs (deterministic; the consumer kernel sums them).
 #include "common.h"
@@ -60,7 +60,7 @@ struct GemmDev {
 };
 
 struct GemmGroup {
-    GemmDev p[JAMIE_MAX_GEMM_GROUP];
+    GemmDev p[JAMIE_MAX_GEMM_GROUP_F32];
     int count;
 };
 
@@ -139,7 +139,7 @@ void gemm_f32_kernel(GemmGroup g) {
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
 #pragma unroll
-    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) {
         if (i < g.count) {
             const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
             const int j = (xcd - rot) & 7;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
 #pragma unroll
-    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) {
         if (i < g.count) {
             const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
             const int j = (xcd - rot) & 7;
@@ -893,7 +893,7 @@ static int pick_cfg(int layout, int max_m, int max_n, int max_k) {
 }
 
 extern "C" int jamie_gemm_f32_cfg(const jamie_gemm_problem* pr, int count, int layout, int cfg, void* stream) {
-    JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GEMM_GROUP, "1 <= count <= JAMIE_MAX_GEMM_GROUP");
+    JAMIE_ARG(pr != nullptr && count >= 1 && count <= JAMIE_MAX_GEMM_GROUP_F32, "1 <= count <= JAMIE_MAX_GEMM_GROUP_F32");
     JAMIE_ARG(layout >= JAMIE_NT && layout <= JAMIE_TN, "layout");
     int max_n = 0, max_m = 0, max_k = 0;
     for (int i = 0; i < count; ++i) {

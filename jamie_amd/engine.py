@@ -485,6 +485,7 @@ class TrainEngine:
         self.pipeline = False            # enable_pipeline(): optimiser on its own stream, overlapped with the next forward
         self._zs = None                  # enable_sharded_optimizer(): packed shard state of a data-parallel run
         self._dw_wait = None             # fp32 backward pass: the large layers' dW products waiting for _flush_dw
+        self._dw_small = []              # ... and the skinny layers' that go with them
         self.side_transposes, self._wT_pending, self._wT_stale = False, False, False
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
@@ -890,7 +891,8 @@ class TrainEngine:
         skinny layers whose dW rides in the same launch; `ranges` (bf16 large-tile launch only): the range-norm work rides too."""
         probs = self._dw_problems(dy_key, a_key, lin, only)
         for ex in (extra or []):
-            if len(probs) + self.M <= nv.MAX_GEMM_GROUP and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(ex[2])):
+            if len(probs) + self.M <= (nv.MAX_GEMM_GROUP if self.bf16 else nv.MAX_GEMM_GROUP_F32) \
+                    and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(ex[2])):
                 probs += self._dw_problems(*ex)
             else:
                 self._dw_gemm(*ex)
@@ -904,14 +906,19 @@ class TrainEngine:
         the latest gradients first.  One layer is 640 tiles of 128 x 128 at config 2 = 1.25 rounds of the chip's 512 slots (half
         the chip idles through the second round); four layers are 5.0 rounds."""
         todo = ([last] if last else []) + self._dw_wait[::-1]
-        self._dw_wait = None
-        per = max(1, min(int(TUNING['f32_dw_group']), nv.MAX_GEMM_GROUP // self.M))
+        small, self._dw_wait, self._dw_small = self._dw_small, None, []
+        per = max(1, min(int(TUNING['f32_dw_group']), nv.MAX_GEMM_GROUP_F32 // self.M))
         while todo:
             chunk, todo = todo[:per], todo[per:]
             probs = []
             for dy_key, a_key, lin in chunk:
                 probs += self._dw_problems(dy_key, a_key, lin)
             nv.gemm(probs, nv.TN, _f32_fused_cfg())
+        # the skinny layers' dW (decoder layer 0, heads: 0.3 GFLOP but 16 dependent k-steps, 19 us) keep a launch of their own: as 48
+        # more 128 x 128 tiles of the grouped launch, first or last in its grid, they cost 9-12 us more (the launch is exactly 10 tiles
+        # per CU without them; profiles/r04_ab_f32_skinny_dw_in_grouped_launch_rejected.log)
+        if small:
+            self._dw_gemm(*small[0], extra=small[1:])
 
     def _f32_dw_cfg(self, lin):
         """fp32 dW launch (TN, K = batch): tile configuration (-1: the library's 64 x 64 default)."""
@@ -965,8 +972,7 @@ class TrainEngine:
         if not self.bf16 and self._dw_wait is not None and self._f32_dw_cfg(lin) == _f32_fused_cfg():
             # fp32: the weight gradient is not on the critical chain -- it waits for the end of the pass (_flush_dw)
             self._dw_wait.append((dy_key, a_key, lin))
-            if extra:
-                self._dw_gemm(*extra[0], extra=extra[1:])
+            self._dw_small += list(extra or [])
             self._dx_gemm(dy_key, lin, out_key, sk_key)
             return
         if not self.bf16 or 2 * self.M > nv.MAX_GEMM_GROUP:
@@ -1298,7 +1304,8 @@ class TrainEngine:
             self._wT_stale = False
         self._fuse_now = self.fused_norm and allreduce is None      # a reduced gradient needs its norm taken afterwards
         self._dw_wait = [] if (not self.bf16 and allreduce is None and int(TUNING['f32_dw_group']) > 1
-                               and self.M <= nv.MAX_GEMM_GROUP) else None
+                               and self.M <= nv.MAX_GEMM_GROUP_F32) else None
+        self._dw_small = []
         self._g16_now = self.grad_bf16 and self._fuse_now and not self.accumulate
         if self.accumulate and self._g16_pending:
             raise nv.JamieHipError('gradients accumulate onto a backward pass that wrote bf16 weight gradients: call '
