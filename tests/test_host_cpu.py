@@ -53,6 +53,19 @@ def test_library_exports_every_declared_symbol(lib):
     assert handle.jamie_max_partials() >= 1024
 
 
+def test_bench_roofline_kernel_names_exist_in_the_library(lib):
+    """The kernel `bench.py` names in its fp32 `roofline` record (and `tools/collect_profiles.py` looks up in the rocprofv3 tables)
+    is an instantiation the library really contains, and it is the one the engine's default tile configuration launches."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from jamie_amd import engine
+    out = subprocess.run(['nm', '-C', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert f'void {bench.F32_ROOFLINE_KERNEL}(GemmGroup)' in out, bench.F32_ROOFLINE_KERNEL
+    assert 'clip_adam_kernel<' in out
+    # <BM, BN, BK, WM, WN, A_KC, B_KC, FAST, TAG, MID>: configuration 17 = 128x128x32 on 4 x 4 waves with the barrier in mid k-step
+    assert engine.F32_CFG_ROWS == 17 and bench.F32_ROOFLINE_KERNEL.endswith('<128, 128, 32, 4, 4, true, true, 2, 1, true>')
+
+
 def test_package_reads_no_environment_switches():
     """jamie_amd/*.py read NO JAMIE_* variable besides the library path and the two test hooks of the data-parallel launcher
     (29 switches used to select measured-and-rejected variants; those are engine.TUNING keys now, set by
