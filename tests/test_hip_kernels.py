@@ -88,6 +88,34 @@ def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
             assert torch.equal(out, ref), f'{layout} cfg {cfg} != cfg {twin} at {(M, N, K, sk)}'
 
 
+@pytest.mark.parametrize('cfg', [1, 12, 17, 18])
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+def test_gemm_f32_rows_that_end_inside_a_float4(nv, layout, cfg):
+    """Buffer-descriptor path with in-row tails (the `FAST = 1` instantiation: 16-byte aligned bases and leading dimensions that
+    are multiples of 4, but K / M / N are not): operands live in padded storage whose padding holds NaN -- a value read from
+    beyond a row's end poisons the result -- against fp64."""
+    M, N, K = 130, 70, 66
+    g = torch.Generator().manual_seed(11 * cfg + len(layout))
+    a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+
+    def padded(t, ld):            # [rows, ld] storage, NaN beyond the logical columns
+        buf = torch.full((t.shape[0], ld), float('nan'))
+        buf[:, :t.shape[1]] = t
+        return dev(buf)
+    out = torch.full((M, N), float('nan'), device='cuda')
+    if layout == 'NT':
+        A, Bm = padded(a, 68), padded(b.t().contiguous(), 68)
+        nv.gemm([nv.gemm_problem(A, Bm, out, M, N, K, 68, 68, N)], nv.NT, cfg)
+    elif layout == 'NN':
+        A, Bm = padded(a, 68), padded(b, 72)
+        nv.gemm([nv.gemm_problem(A, Bm, out, M, N, K, 68, 72, N)], nv.NN, cfg)
+    else:
+        A, Bm = padded(a.t().contiguous(), 132), padded(b, 72)
+        nv.gemm([nv.gemm_problem(A, Bm, out, M, N, K, 132, 72, N)], nv.TN, cfg)
+    torch.cuda.synchronize()
+    close(out, a.double() @ b.double(), rtol=1e-5, atol=2e-6 * float(np.sqrt(K)), msg=f'{layout} cfg {cfg}')
+
+
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES + [(512, 2000, 1000), (130, 72, 1002), (64, 64, 20)])
 @pytest.mark.parametrize('cfg', [7, 8, 9])
 def test_gemm_f32_lds_dma_nt(nv, M, N, K, cfg):
