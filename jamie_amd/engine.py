@@ -883,7 +883,7 @@ class TrainEngine:
                 probs.append(self._dw_problem(i, dy_key, a_key, lin))
             else:
                 probs.append(nv.gemm_problem(dy, a, dW, nout, nin, self.B, nout, nin, nin, accumulate=self.accumulate,
-                                             store_nt=True, partial=self._dw_partial(i, lin)))
+                                             store_nt=bool(TUNING['dw_store_nt']), partial=self._dw_partial(i, lin)))
         return probs
 
     def _dw_gemm(self, dy_key, a_key, lin, extra=None, ranges=None, only=None):
