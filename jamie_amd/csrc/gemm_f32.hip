@@ -17,6 +17,7 @@
 //     remapped so that the M-tiles that re-read one weight panel run back to back on one XCD (its L2).
 //   * split-K writes fp32 slabs (deterministic; the consumer kernel sums them).
 #include "common.h"
+#include <type_traits>
 
 // diagnostic ablations of the register-staged k-loop (tools/ablate_gemm.sh; results are wrong, timings only), a bit mask:
 // 1 = no global loads in the k-loop, 2 = no MFMAs, 4 = no LDS writes, 8 = no barrier, 16 = no fragment reads
@@ -56,6 +57,7 @@ struct GemmDev {
     int splitk, kchunk, tiles_m, tiles_n, tile_begin, n_tiles;
     int epi, accumulate, a_vec, b_vec, store_nt;
     unsigned a_bytes, b_bytes;
+    unsigned c_bytes;    // extent of one output slab in bytes (0: 4 GiB or more -- the generic epilogue)
     float scale, slope, eps, pscale;
 };
 
@@ -462,6 +464,60 @@ void gemm_f32_kernel(GemmGroup g) {
     float* Cout = P.C + (long long)ks * P.slab_stride;
     const bool add_bias = (P.bias != nullptr) && ks == 0;
     float local = 0.f;
+    // Plain stores (split-K slabs, weight gradients): one lean path.  Beside a co-resident workgroup that saturates the matrix
+    // pipe a vector or scalar instruction of this epilogue gets an issue slot about once per MFMA, and the general loop below
+    // spends ~8 vector instructions and ~10 branches per element (stamps: 12-18 us of epilogue beside a computing workgroup, 4 us
+    // alone) while the tile's slot on the CU stays taken.  Here an element is one add (bias), one FMA (sum of squares) and one
+    // buffer store whose row offset is scalar; rows beyond M only cost a select in the tiles that have any.
+    if (FAST && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.c_bytes != 0) {
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cout, 0, (int)P.c_bytes, 0x00020000);
+        const bool edge = m0 + BM > P.M || n0 + BN > P.N;
+        const unsigned ldc4 = (unsigned)P.ldc * 4u;
+        auto emit = [&](auto nt_c, auto edge_c) {            // (four straight-line instances behind two scalar branches)
+            constexpr bool NT_ST = decltype(nt_c)::value, EDGE = decltype(edge_c)::value;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 32 + r;
+                const bool nok = n < P.N;
+                const float bv = (add_bias && nok) ? P.bias[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int mrow = m0 + wm0 + i * 32 + 4 * h;                       // + (e & 3) + 8 * (e >> 2)
+                    const unsigned voff = nok ? (unsigned)mrow * ldc4 + (unsigned)n * 4u : JAMIE_OOB;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rel = (e & 3) + 8 * (e >> 2);
+                        const float v = acc[i][j][e] + bv;
+                        unsigned vo = voff;
+                        if (EDGE) vo = (mrow + rel < P.M) ? voff : JAMIE_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rs, (int)vo, (int)((unsigned)rel * ldc4), NT_ST ? 2 : 0);
+                        if (EDGE) local += (vo != JAMIE_OOB) ? v * v : 0.f;
+                        else local += v * v;                  // (interior tiles: every element counts)
+                    }
+                }
+            }
+        };
+        if (P.store_nt) {
+            asm volatile("; nt stores");
+            if (edge) { asm volatile("; edge tile"); emit(std::true_type{}, std::true_type{}); }
+            else emit(std::true_type{}, std::false_type{});
+        } else {
+            asm volatile("; plain stores");
+            if (edge) { asm volatile("; edge tile"); emit(std::false_type{}, std::true_type{}); }
+            else emit(std::false_type{}, std::false_type{});
+        }
+        if (P.partial != nullptr) {
+            const float tot = block_sum(local, red);
+            if (tid == 0) P.partial[t] = tot;
+        }
+#ifdef JAMIE_GEMMB_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        JF_STAMP(3);
+        JF_STAMPV(7, __builtin_amdgcn_s_memtime());
+#endif
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + j * 32 + r;
@@ -786,6 +842,8 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         const long long bb = ((b_rows_n - 1) * s.ldb + (b_cols + 3) / 4 * 4) * 4;
         if (!d.a_vec || !d.b_vec || s.a_rows || ab >= 0xFFFFFFF0LL || bb >= 0xFFFFFFF0LL) fast = false;
         d.a_bytes = (unsigned)ab; d.b_bytes = (unsigned)bb;
+        const long long cb = ((long long)(s.M - 1) * s.ldc + s.N) * 4;
+        d.c_bytes = cb < 0xFFFFFFF0LL ? (unsigned)cb : 0u;
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
     if (tiles == 0) return 0;
