@@ -469,17 +469,23 @@ void gemm_f32_kernel(GemmGroup g) {
     // spends ~8 vector instructions and ~10 branches per element (stamps: 12-18 us of epilogue beside a computing workgroup, 4 us
     // alone) while the tile's slot on the CU stays taken.  Here an element is one add (bias), one FMA (sum of squares) and one
     // buffer store whose row offset is scalar; rows beyond M only cost a select in the tiles that have any.
-    if (FAST && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.c_bytes != 0) {
+    if (FAST && (P.epi == JAMIE_EPI_STORE || P.epi == JAMIE_EPI_BN_EVAL) && !P.accumulate && P.c_bytes != 0) {
         const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cout, 0, (int)P.c_bytes, 0x00020000);
         const bool edge = m0 + BM > P.M || n0 + BN > P.N;
         const unsigned ldc4 = (unsigned)P.ldc * 4u;
-        auto emit = [&](auto nt_c, auto edge_c) {            // (four straight-line instances behind two scalar branches)
-            constexpr bool NT_ST = decltype(nt_c)::value, EDGE = decltype(edge_c)::value;
+        auto emit = [&](auto nt_c, auto edge_c, auto bn_c) {            // (straight-line instances behind scalar branches)
+            constexpr bool NT_ST = decltype(nt_c)::value, EDGE = decltype(edge_c)::value, EVAL_BN = decltype(bn_c)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn0 + j * 32 + r;
                 const bool nok = n < P.N;
                 const float bv = (add_bias && nok) ? P.bias[n] : 0.f;
+                float e_mean = 0.f, e_scale = 1.f, e_shift = 0.f;
+                if (EVAL_BN && nok) {       // eval BatchNorm + LeakyReLU, the general loop's operation order
+                    e_mean = P.aux0[n];
+                    e_scale = rsqrtf(P.aux1[n] + P.eps) * P.aux2[n];
+                    e_shift = P.aux3[n];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int mrow = m0 + wm0 + i * 32 + 4 * h;                       // + (e & 3) + 8 * (e >> 2)
@@ -487,24 +493,34 @@ void gemm_f32_kernel(GemmGroup g) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int rel = (e & 3) + 8 * (e >> 2);
-                        const float v = acc[i][j][e] + bv;
+                        float v = acc[i][j][e] + bv;
+                        if (EVAL_BN) {
+                            v = (v - e_mean) * e_scale + e_shift;
+                            v = v > 0.f ? v : P.slope * v;
+                        }
                         unsigned vo = voff;
                         if (EDGE) vo = (mrow + rel < P.M) ? voff : JAMIE_OOB;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rs, (int)vo, (int)((unsigned)rel * ldc4), NT_ST ? 2 : 0);
-                        if (EDGE) local += (vo != JAMIE_OOB) ? v * v : 0.f;
-                        else local += v * v;                  // (interior tiles: every element counts)
+                        if (!EVAL_BN) {
+                            if (EDGE) local += (vo != JAMIE_OOB) ? v * v : 0.f;
+                            else local += v * v;                  // (interior tiles: every element counts)
+                        }
                     }
                 }
             }
         };
-        if (P.store_nt) {
+        if (P.epi == JAMIE_EPI_BN_EVAL) {
+            asm volatile("; eval BatchNorm epilogue");
+            if (edge) { asm volatile("; edge tile"); emit(std::false_type{}, std::true_type{}, std::true_type{}); }
+            else emit(std::false_type{}, std::false_type{}, std::true_type{});
+        } else if (P.store_nt) {
             asm volatile("; nt stores");
-            if (edge) { asm volatile("; edge tile"); emit(std::true_type{}, std::true_type{}); }
-            else emit(std::true_type{}, std::false_type{});
+            if (edge) { asm volatile("; edge tile"); emit(std::true_type{}, std::true_type{}, std::false_type{}); }
+            else emit(std::true_type{}, std::false_type{}, std::false_type{});
         } else {
             asm volatile("; plain stores");
-            if (edge) { asm volatile("; edge tile"); emit(std::false_type{}, std::true_type{}); }
-            else emit(std::false_type{}, std::false_type{});
+            if (edge) { asm volatile("; edge tile"); emit(std::false_type{}, std::true_type{}, std::false_type{}); }
+            else emit(std::false_type{}, std::false_type{}, std::false_type{});
         }
         if (P.partial != nullptr) {
             const float tot = block_sum(local, red);
