@@ -62,6 +62,7 @@ struct GemmDev {
 };
 
 struct GemmGroup {
+    int ntiles[JAMIE_MAX_GEMM_GROUP_F32];        // tile count of every problem (0: unused), read first by every workgroup
     GemmDev p[JAMIE_MAX_GEMM_GROUP_F32];
     int count;
 };
@@ -140,21 +141,24 @@ void gemm_f32_kernel(GemmGroup g) {
     const int xcd = bid & 7;
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
+    // (branch-free, every problem's tile count loaded up front -- unused problems hold 0: written as a loop of guarded
+    //  iterations this was one dependent scalar-memory round trip and three branches per problem, 2-3 us of a tile's time on its CU
+    //  slot before the first load, more beside a workgroup that saturates the matrix pipe)
+    int ntl[JAMIE_MAX_GEMM_GROUP_F32];
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) ntl[i] = g.ntiles[i];
+    bool found = false;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) {
-        if (i < g.count) {
-            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
-            const int j = (xcd - rot) & 7;
-            const int cp = qp + (j < rp ? 1 : 0);
-            if (slot >= 0 && slot < cp) {
-                pi = i;
-                t = j * qp + min(j, rp) + slot;
-                slot = -1;
-            } else if (slot >= 0) {
-                slot -= cp;
-            }
-            rot = (rot + rp) & 7;
-        }
+        const int T = ntl[i], qp = T >> 3, rp = T & 7;
+        const int j = (xcd - rot) & 7;
+        const int cp = qp + (j < rp ? 1 : 0);
+        const bool hit = !found && slot < cp;
+        pi = hit ? i : pi;
+        t = hit ? j * qp + min(j, rp) + slot : t;
+        slot = (found || hit) ? slot : slot - cp;
+        found = found || hit;
+        rot = (rot + rp) & 7;
     }
     const GemmDev& P = g.p[pi];
     const int tm_i = t % P.tiles_m;
@@ -619,21 +623,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
     const int xcd = bid & 7;
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
+    // (branch-free, every problem's tile count loaded up front -- unused problems hold 0: written as a loop of guarded
+    //  iterations this was one dependent scalar-memory round trip and three branches per problem, 2-3 us of a tile's time on its CU
+    //  slot before the first load, more beside a workgroup that saturates the matrix pipe)
+    int ntl[JAMIE_MAX_GEMM_GROUP_F32];
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) ntl[i] = g.ntiles[i];
+    bool found = false;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) {
-        if (i < g.count) {
-            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
-            const int j = (xcd - rot) & 7;
-            const int cp = qp + (j < rp ? 1 : 0);
-            if (slot >= 0 && slot < cp) {
-                pi = i;
-                t = j * qp + min(j, rp) + slot;
-                slot = -1;
-            } else if (slot >= 0) {
-                slot -= cp;
-            }
-            rot = (rot + rp) & 7;
-        }
+        const int T = ntl[i], qp = T >> 3, rp = T & 7;
+        const int j = (xcd - rot) & 7;
+        const int cp = qp + (j < rp ? 1 : 0);
+        const bool hit = !found && slot < cp;
+        pi = hit ? i : pi;
+        t = hit ? j * qp + min(j, rp) + slot : t;
+        slot = (found || hit) ? slot : slot - cp;
+        found = found || hit;
+        rot = (rot + rp) & 7;
     }
     const GemmDev& P = g.p[pi];
     const int tm_i = t % P.tiles_m;
@@ -850,6 +857,7 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.b_vec = ((s.ldb % 4) == 0 && ((uintptr_t)s.B % 16) == 0) ? 1 : 0;
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        g.ntiles[i] = d.n_tiles;
         tiles += d.n_tiles;
         // operand extents in bytes, last row rounded up to a whole float4 (stays inside the ld-strided storage)
         const long long a_rows_n = A_KC ? s.M : s.K, a_cols = A_KC ? s.K : s.M;
@@ -906,6 +914,7 @@ static int launch_dma_nt(const jamie_gemm_problem* pr, int count, hipStream_t st
         d.epi = s.epi; d.accumulate = s.accumulate; d.store_nt = s.store_nt;
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        g.ntiles[i] = d.n_tiles;
         tiles += d.n_tiles;
         if ((s.lda % 4) || (s.ldb % 4) || ((uintptr_t)s.A % 16) || ((uintptr_t)s.B % 16) || s.a_rows ||
             ((long long)(s.M - 1) * s.lda + s.K) * 4 >= 0xFFFFFFF0LL || ((long long)(s.N - 1) * s.ldb + s.K) * 4 >= 0xFFFFFFF0LL)
