@@ -46,7 +46,7 @@ struct GemmBDev {
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
-struct GemmBGroup { GemmBDev p[JAMIE_MAX_GEMM_GROUP]; int count; };
+struct GemmBGroup { int ntiles[JAMIE_MAX_GEMM_GROUP]; GemmBDev p[JAMIE_MAX_GEMM_GROUP]; int count; };      // ntiles[i]: tile count of problem i (0: unused)
 
 #ifdef JAMIE_EXPERIMENTS
 // In-launch split-K reduction + BatchNorm forward (jamie_gemm_bf16_bn): per problem the BatchNorm strip descriptor whose `h` is
@@ -127,21 +127,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
     const int xcd = bid & 7;
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
+    // (branch-free, every problem's tile count loaded up front -- unused problems hold 0; as a loop of guarded iterations this was one
+    //  dependent scalar-memory round trip and three branches per problem in front of the first load: gemm_f32.hip)
+    int ntl[JAMIE_MAX_GEMM_GROUP];
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) ntl[i] = g.ntiles[i];
+    bool found = false;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
-        if (i < g.count) {
-            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
-            const int j = (xcd - rot) & 7;
-            const int cp = qp + (j < rp ? 1 : 0);
-            if (slot >= 0 && slot < cp) {
-                pi = i;
-                t = j * qp + min(j, rp) + slot;
-                slot = -1;
-            } else if (slot >= 0) {
-                slot -= cp;
-            }
-            rot = (rot + rp) & 7;
-        }
+        const int T = ntl[i], qp = T >> 3, rp = T & 7;
+        const int j = (xcd - rot) & 7;
+        const int cp = qp + (j < rp ? 1 : 0);
+        const bool hit = !found && slot < cp;
+        pi = hit ? i : pi;
+        t = hit ? j * qp + min(j, rp) + slot : t;
+        slot = (found || hit) ? slot : slot - cp;
+        found = found || hit;
+        rot = (rot + rp) & 7;
     }
     const GemmBDev& P = g.p[pi];
     const int tm_i = t % P.tiles_m;
@@ -327,21 +329,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
     const int xcd = bid & 7;
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
+    // (branch-free, every problem's tile count loaded up front -- unused problems hold 0; as a loop of guarded iterations this was one
+    //  dependent scalar-memory round trip and three branches per problem in front of the first load: gemm_f32.hip)
+    int ntl[JAMIE_MAX_GEMM_GROUP];
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) ntl[i] = g.ntiles[i];
+    bool found = false;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
-        if (i < g.count) {
-            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
-            const int j = (xcd - rot) & 7;
-            const int cp = qp + (j < rp ? 1 : 0);
-            if (slot >= 0 && slot < cp) {
-                pi = i;
-                t = j * qp + min(j, rp) + slot;
-                slot = -1;
-            } else if (slot >= 0) {
-                slot -= cp;
-            }
-            rot = (rot + rp) & 7;
-        }
+        const int T = ntl[i], qp = T >> 3, rp = T & 7;
+        const int j = (xcd - rot) & 7;
+        const int cp = qp + (j < rp ? 1 : 0);
+        const bool hit = !found && slot < cp;
+        pi = hit ? i : pi;
+        t = hit ? j * qp + min(j, rp) + slot : t;
+        slot = (found || hit) ? slot : slot - cp;
+        found = found || hit;
+        rot = (rot + rp) & 7;
     }
     const GemmBDev& P = g.p[pi];
     const int tm_i = t % P.tiles_m;
@@ -548,21 +552,23 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     const int xcd = bid & 7;
     int slot = bid >> 3;
     int pi = 0, t = 0, rot = 0;
+    // (branch-free, every problem's tile count loaded up front -- unused problems hold 0; as a loop of guarded iterations this was one
+    //  dependent scalar-memory round trip and three branches per problem in front of the first load: gemm_f32.hip)
+    int ntl[JAMIE_MAX_GEMM_GROUP];
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) ntl[i] = g.ntiles[i];
+    bool found = false;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP; ++i) {
-        if (i < g.count) {
-            const int T = g.p[i].n_tiles, qp = T >> 3, rp = T & 7;
-            const int j = (xcd - rot) & 7;
-            const int cp = qp + (j < rp ? 1 : 0);
-            if (slot >= 0 && slot < cp) {
-                pi = i;
-                t = j * qp + min(j, rp) + slot;
-                slot = -1;
-            } else if (slot >= 0) {
-                slot -= cp;
-            }
-            rot = (rot + rp) & 7;
-        }
+        const int T = ntl[i], qp = T >> 3, rp = T & 7;
+        const int j = (xcd - rot) & 7;
+        const int cp = qp + (j < rp ? 1 : 0);
+        const bool hit = !found && slot < cp;
+        pi = hit ? i : pi;
+        t = hit ? j * qp + min(j, rp) + slot : t;
+        slot = (found || hit) ? slot : slot - cp;
+        found = found || hit;
+        rot = (rot + rp) & 7;
     }
     const GemmBDev& P = g.p[pi];
     // FUSE: the tiles_m x splitk workgroups of one column strip are adjacent in the tile list (same XCD chunk, dispatched
@@ -1008,6 +1014,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.tiles_m = (s.M + BM - 1) / BM;
         d.tiles_n = (s.N + BN - 1) / BN;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        g.ntiles[i] = d.n_tiles;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
         if (s.b_tr || s.a_tr || s.c_bf16) return jamie_fail(-1, "%s: a_tr / b_tr / c_bf16 need a large-tile LDS-DMA configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
@@ -1046,6 +1053,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, c
         d.tiles_m = (s.M + BM - 1) / BM;
         d.tiles_n = (s.N + BN - 1) / BN;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        g.ntiles[i] = d.n_tiles;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
         d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt; d.c_bf16 = s.c_bf16;
@@ -1131,6 +1139,7 @@ static int launch_dma_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_pro
         d.tiles_m = (s.M + BM - 1) / BM;
         d.tiles_n = (s.N + BN - 1) / BN;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
+        g.ntiles[i] = d.n_tiles;
         tiles += d.n_tiles;
         d.epi = JAMIE_EPI_STORE; d.scale = 1.f; d.pscale = 1.f; d.vec = 1;
         JAMIE_ARG(s.epi == JAMIE_EPI_STORE && !s.accumulate && !s.a_tr && !s.b_tr && !s.c_bf16 && !s.partial,
