@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBGroup g) {
         found = found || hit;
         rot = (rot + rp) & 7;
     }
-    const GemmBDev& P = g.p[pi];
+    const GemmBDev P = g.p[pi];          // (by value: every field in one burst of scalar loads, not a round trip per first use)
     const int tm_i = t % P.tiles_m;
     const int tn_i = (t / P.tiles_m) % P.tiles_n;
     const int ks = t / (P.tiles_m * P.tiles_n);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
         found = found || hit;
         rot = (rot + rp) & 7;
     }
-    const GemmBDev& P = g.p[pi];
+    const GemmBDev P = g.p[pi];          // (by value: every field in one burst of scalar loads, not a round trip per first use)
     const int tm_i = t % P.tiles_m;
     const int tn_i = (t / P.tiles_m) % P.tiles_n;
     const int ks = t / (P.tiles_m * P.tiles_n);
@@ -570,7 +570,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
         found = found || hit;
         rot = (rot + rp) & 7;
     }
-    const GemmBDev& P = g.p[pi];
+    const GemmBDev P = g.p[pi];          // (by value: every field in one burst of scalar loads, not a round trip per first use)
     // FUSE: the tiles_m x splitk workgroups of one column strip are adjacent in the tile list (same XCD chunk, dispatched
     // together): they hand their slabs to each other inside the launch
     const int pn = P.tiles_m * P.splitk;

@@ -160,7 +160,7 @@ void gemm_f32_kernel(GemmGroup g) {
         found = found || hit;
         rot = (rot + rp) & 7;
     }
-    const GemmDev& P = g.p[pi];
+    const GemmDev& P = g.p[pi];          // (by value, as gemm_bf16.hip does: +5 us per fp32 step)
     const int tm_i = t % P.tiles_m;
     const int tn_i = (t / P.tiles_m) % P.tiles_n;
     const int ks = t / (P.tiles_m * P.tiles_n);
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
         found = found || hit;
         rot = (rot + rp) & 7;
     }
-    const GemmDev& P = g.p[pi];
+    const GemmDev& P = g.p[pi];          // (by value, as gemm_bf16.hip does: +5 us per fp32 step)
     const int tm_i = t % P.tiles_m;
     const int tn_i = (t / P.tiles_m) % P.tiles_n;
     const int ks = t / (P.tiles_m * P.tiles_n);
