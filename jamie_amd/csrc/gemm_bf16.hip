@@ -820,6 +820,55 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
             if (nc + 3 < P.N) b4.w = P.bias[nc + 3];
         }
     }
+    // Plain stores of whole interior tiles (split-K slabs, bf16 weight gradients: every large launch of the step) take a lean
+    // path: the general loop below decides epilogue kind, accumulation, output type, cache policy and bounds per 16-byte piece
+    // (~30 instructions and 6 branches each, 64-bit address arithmetic); here a piece is its bias add, (sum of squares,) pack and ONE
+    // buffer store whose row offset is scalar -- the tile's CU slot is free again that much earlier (gemm_f32.hip, round 4).
+    const unsigned c_elem = P.c_bf16 ? 2u : 4u;
+    const unsigned long long c_ext = ((unsigned long long)(P.M - 1) * (unsigned long long)P.ldc + (unsigned long long)P.N) * c_elem;
+    if (!FUSE && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.vec && (P.N & 3) == 0 && m0 + BM <= P.M && n0 + BN <= P.N &&
+        c_ext < 0xFFFFFFF0ull) {
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cout, 0, (int)(unsigned)c_ext, 0x00020000);
+        const unsigned ldcb = (unsigned)P.ldc * c_elem;
+        const unsigned voff = (unsigned)(m0 + wm0 + rsub) * ldcb + (unsigned)nc * c_elem;
+        auto emit = [&](auto bf_c, auto nt_c) {
+            constexpr bool C16 = decltype(bf_c)::value, NT_ST = decltype(nt_c)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(scr + r * SROW + j * 32 + 8 * q + 4 * h) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+#pragma unroll
+                for (int rr = 0; rr < 32 / RPI; ++rr) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(scr + (rr * RPI + rsub) * SROW + cch * 4);
+                    const float v0 = a4.x + b4.x, v1 = a4.y + b4.y, v2 = a4.z + b4.z, v3 = a4.w + b4.w;
+                    local += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                    const unsigned so = (unsigned)(i * 32 + rr * RPI) * ldcb;
+                    if (C16) {
+                        auto bfr = [](float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); };
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        u32x2 pk; pk.x = bfr(v0) | (bfr(v1) << 16); pk.y = bfr(v2) | (bfr(v3) << 16);
+                        __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, (int)voff, (int)so, NT_ST ? 2 : 0);
+                    } else {
+                        u32x4 pk; pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3);
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, c_rs, (int)voff, (int)so, NT_ST ? 2 : 0);
+                    }
+                }
+            }
+        };
+        if (P.c_bf16) {
+            asm volatile("; bf16 output");
+            if (P.store_nt) { asm volatile("; nt"); emit(std::true_type{}, std::true_type{}); }
+            else emit(std::true_type{}, std::false_type{});
+        } else {
+            asm volatile("; fp32 output");
+            if (P.store_nt) { asm volatile("; nt"); emit(std::false_type{}, std::true_type{}); }
+            else emit(std::false_type{}, std::false_type{});
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
