@@ -12,11 +12,11 @@ dst = os.path.join(root, 'profiles')
 bench = json.load(open(os.path.join(src, 'bench.json')))
 KERNEL = bench['roofline']['kernel'].split(' (')[0] if bench['dtype'] == 'f32' else 'clip_adam_kernel'
 def avg_counter(d, counter):
-    f = glob.glob(os.path.join(src, d, '*', '*_counter_collection.csv'))[0]
+    f = max(glob.glob(os.path.join(src, d, '*', '*_counter_collection.csv')), key=os.path.getmtime)      # (the newest: gpurun_out/ keeps earlier runs)
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
             if r['Counter_Name'] == counter and KERNEL in r['Kernel_Name']]
     return sum(vals) / len(vals), len(vals)
-st = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
+st = max(glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv')), key=os.path.getmtime)
 rows = list(csv.DictReader(open(st)))
 with open(os.path.join(dst, name + '_kernel_stats.csv'), 'w') as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)

@@ -7,7 +7,7 @@ tag = sys.argv[1]
 
 
 def load(d, counter):
-    f = glob.glob(os.path.join(root, 'gpurun_out', tag, d, '*', '*_counter_collection.csv'))[0]
+    f = max(glob.glob(os.path.join(root, 'gpurun_out', tag, d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
     tot, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == counter:
