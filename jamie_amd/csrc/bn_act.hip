@@ -435,11 +435,17 @@ __global__ __launch_bounds__(128 * CQ, (R <= 4 ? JAMIE_BN_FWD_WAVES : 1)) void b
     __shared__ float shraw[2 * CQ * 4 * CQ];                     // [waves = 2 CQ][columns = 4 CQ]
     float (*sh)[4 * CQ] = reinterpret_cast<float (*)[4 * CQ]>(shraw);
     __shared__ __attribute__((aligned(16))) unsigned short tl[CQ == 4 ? BN_CW * (128 * R + 2) : 8];
+    // (every problem's first workgroup loaded up front and the chosen problem's descriptor by value: as guarded iterations and
+    //  fields fetched at their first use these were eight dependent scalar-memory round trips in front of the first slab load of a
+    //  launch that lasts 11-17 us)
+    int bb[JAMIE_MAX_GROUP];
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) bb[i] = g.p[i].blk_begin;
+    const int cnt = g.count;
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
-        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
-    const BnFwdDev& P = g.p[pi];
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i) pi = (i < cnt && (int)blockIdx.x >= bb[i]) ? i : pi;
+    const BnFwdDev P = g.p[pi];
     const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N, 4 * CQ) * (4 * CQ);
     bn_fwd4_strip<R, JAMIE_BN_LD_AUX, CQ>(P, col0, (int)threadIdx.x, true, sh, tl, p_drop, momentum, eps, slope, rng);      // (bn_fwd_strip.h)
 }
@@ -467,11 +473,14 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, flo
     float (*sh)[4 * CQ] = reinterpret_cast<float (*)[4 * CQ]>(shraw);
     float (*sh2)[8 * CQ] = reinterpret_cast<float (*)[8 * CQ]>(sh2raw);
     __shared__ __attribute__((aligned(16))) unsigned short tl[CQ == 4 ? BN_CW * (128 * R + 2) : 8];
+    int bb[JAMIE_MAX_GROUP];                    // (up front and by value: see the forward kernel)
+#pragma unroll
+    for (int i = 0; i < JAMIE_MAX_GROUP; ++i) bb[i] = g.p[i].blk_begin;
+    const int cnt = g.count;
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
-        if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
-    const BnBwdDev& P = g.p[pi];
+    for (int i = 1; i < JAMIE_MAX_GROUP; ++i) pi = (i < cnt && (int)blockIdx.x >= bb[i]) ? i : pi;
+    const BnBwdDev P = g.p[pi];
     const int tid = threadIdx.x, cq = tid & (CQ - 1), rp = tid / CQ;
     const int col0 = bn_strip((int)blockIdx.x - P.blk_begin, P.N, 4 * CQ) * (4 * CQ), col = col0 + 4 * cq;
     const bool cok = col < P.N;
