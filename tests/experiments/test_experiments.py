@@ -200,7 +200,10 @@ def test_persistent_ring_equals_one_workgroup_per_tile(nv, ex, case):
     torch.cuda.synchronize()
     assert int(err[0].item()) == 0
     for a, b in zip(o0, o1):
-        assert torch.equal(a, b), (case, float((a.float() - b.float()).abs().max()))
+        if a.dim() == 1:      # (per-tile sums of squares: the product kernel's lean epilogue adds the same squares in another association)
+            assert torch.allclose(a, b, rtol=1e-6), (case, float((a - b).abs().max()))
+        else:
+            assert torch.equal(a, b), (case, float((a.float() - b.float()).abs().max()))
     if ranges0 is not None:
         # (the riders run on 768 instead of 512 threads here: the same sums of squares in another order)
         assert torch.allclose(pa0, pa1, rtol=1e-5) and torch.equal(g16a, g16b) and int(st1[1]) == 6 == int(st0[1])
