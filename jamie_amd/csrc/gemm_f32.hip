@@ -58,6 +58,7 @@ struct GemmDev {
     int epi, accumulate, a_vec, b_vec, store_nt;
     unsigned a_bytes, b_bytes;
     unsigned c_bytes;    // extent of one output slab in bytes (0: 4 GiB or more -- the generic epilogue)
+    unsigned inv_tm, inv_tn;     // floor(2^32 / tiles_m) + 1, ... / tiles_n) + 1 (0: 65536 tiles or more)
     float scale, slope, eps, pscale;
 };
 
@@ -148,8 +149,10 @@ void gemm_f32_kernel(GemmGroup g) {
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) ntl[i] = g.ntiles[i];
     bool found = false;
+    const int n_prob = g.count;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) {
+        if (i >= n_prob) break;                    // (one scalar branch: the forward / dX launches hold 2 of 12 problems)
         const int T = ntl[i], qp = T >> 3, rp = T & 7;
         const int j = (xcd - rot) & 7;
         const int cp = qp + (j < rp ? 1 : 0);
@@ -161,9 +164,20 @@ void gemm_f32_kernel(GemmGroup g) {
         rot = (rot + rp) & 7;
     }
     const GemmDev& P = g.p[pi];          // (by value, as gemm_bf16.hip does: +5 us per fp32 step)
-    const int tm_i = t % P.tiles_m;
-    const int tn_i = (t / P.tiles_m) % P.tiles_n;
-    const int ks = t / (P.tiles_m * P.tiles_n);
+    // t -> (M tile, N tile, K slice) by multiply-high with reciprocals from the host (exact below 65536 tiles; 0: divide -- a
+    // scalar integer division is ~30 instructions through the vector unit's reciprocal and back)
+    int tm_i, tn_i, ks;
+    if (P.inv_tm != 0) {
+        const unsigned q1 = P.tiles_m == 1 ? (unsigned)t : __umulhi((unsigned)t, P.inv_tm);      // (2^32 / 1 + 1 does not fit)
+        const unsigned q2 = P.tiles_n == 1 ? q1 : __umulhi(q1, P.inv_tn);
+        tm_i = t - (int)q1 * P.tiles_m;
+        tn_i = (int)q1 - (int)q2 * P.tiles_n;
+        ks = (int)q2;
+    } else {
+        tm_i = t % P.tiles_m;
+        tn_i = (t / P.tiles_m) % P.tiles_n;
+        ks = t / (P.tiles_m * P.tiles_n);
+    }
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int kbeg = ks * P.kchunk;
     const int kend = min(P.K, kbeg + P.kchunk);
@@ -630,8 +644,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) ntl[i] = g.ntiles[i];
     bool found = false;
+    const int n_prob = g.count;
 #pragma unroll
     for (int i = 0; i < JAMIE_MAX_GEMM_GROUP_F32; ++i) {
+        if (i >= n_prob) break;                    // (one scalar branch: the forward / dX launches hold 2 of 12 problems)
         const int T = ntl[i], qp = T >> 3, rp = T & 7;
         const int j = (xcd - rot) & 7;
         const int cp = qp + (j < rp ? 1 : 0);
@@ -643,9 +659,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
         rot = (rot + rp) & 7;
     }
     const GemmDev& P = g.p[pi];          // (by value, as gemm_bf16.hip does: +5 us per fp32 step)
-    const int tm_i = t % P.tiles_m;
-    const int tn_i = (t / P.tiles_m) % P.tiles_n;
-    const int ks = t / (P.tiles_m * P.tiles_n);
+    // t -> (M tile, N tile, K slice) by multiply-high with reciprocals from the host (exact below 65536 tiles; 0: divide -- a
+    // scalar integer division is ~30 instructions through the vector unit's reciprocal and back)
+    int tm_i, tn_i, ks;
+    if (P.inv_tm != 0) {
+        const unsigned q1 = P.tiles_m == 1 ? (unsigned)t : __umulhi((unsigned)t, P.inv_tm);      // (2^32 / 1 + 1 does not fit)
+        const unsigned q2 = P.tiles_n == 1 ? q1 : __umulhi(q1, P.inv_tn);
+        tm_i = t - (int)q1 * P.tiles_m;
+        tn_i = (int)q1 - (int)q2 * P.tiles_n;
+        ks = (int)q2;
+    } else {
+        tm_i = t % P.tiles_m;
+        tn_i = (t / P.tiles_m) % P.tiles_n;
+        ks = t / (P.tiles_m * P.tiles_n);
+    }
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int kbeg = ks * P.kchunk;
     const int kend = min(P.K, kbeg + P.kchunk);
@@ -858,6 +885,9 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         g.ntiles[i] = d.n_tiles;
+        const bool small = (long long)d.tiles_m * d.tiles_n * d.splitk < 65536;
+        d.inv_tm = small ? (unsigned)(0x100000000ull / (unsigned)d.tiles_m) + 1u : 0u;
+        d.inv_tn = small ? (unsigned)(0x100000000ull / (unsigned)d.tiles_n) + 1u : 0u;
         tiles += d.n_tiles;
         // operand extents in bytes, last row rounded up to a whole float4 (stays inside the ld-strided storage)
         const long long a_rows_n = A_KC ? s.M : s.K, a_cols = A_KC ? s.K : s.M;
@@ -915,6 +945,9 @@ static int launch_dma_nt(const jamie_gemm_problem* pr, int count, hipStream_t st
         d.scale = s.scale; d.slope = s.slope; d.eps = s.eps; d.pscale = s.pscale;
         d.n_tiles = d.tiles_m * d.tiles_n * d.splitk;
         g.ntiles[i] = d.n_tiles;
+        const bool small = (long long)d.tiles_m * d.tiles_n * d.splitk < 65536;
+        d.inv_tm = small ? (unsigned)(0x100000000ull / (unsigned)d.tiles_m) + 1u : 0u;
+        d.inv_tn = small ? (unsigned)(0x100000000ull / (unsigned)d.tiles_n) + 1u : 0u;
         tiles += d.n_tiles;
         if ((s.lda % 4) || (s.ldb % 4) || ((uintptr_t)s.A % 16) || ((uintptr_t)s.B % 16) || s.a_rows ||
             ((long long)(s.M - 1) * s.lda + s.K) * 4 >= 0xFFFFFFF0LL || ((long long)(s.N - 1) * s.ldb + s.K) * 4 >= 0xFFFFFFF0LL)
