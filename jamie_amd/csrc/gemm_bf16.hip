@@ -826,13 +826,15 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     // buffer store whose row offset is scalar -- the tile's CU slot is free again that much earlier (gemm_f32.hip, round 4).
     const unsigned c_elem = P.c_bf16 ? 2u : 4u;
     const unsigned long long c_ext = ((unsigned long long)(P.M - 1) * (unsigned long long)P.ldc + (unsigned long long)P.N) * c_elem;
-    if (!FUSE && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.vec && (P.N & 3) == 0 && m0 + BM <= P.M && n0 + BN <= P.N &&
-        c_ext < 0xFFFFFFF0ull) {
+    if (!FUSE && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.vec && (P.N & 3) == 0 && c_ext < 0xFFFFFFF0ull) {
         const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cout, 0, (int)(unsigned)c_ext, 0x00020000);
         const unsigned ldcb = (unsigned)P.ldc * c_elem;
-        const unsigned voff = (unsigned)(m0 + wm0 + rsub) * ldcb + (unsigned)nc * c_elem;
-        auto emit = [&](auto bf_c, auto nt_c) {
-            constexpr bool C16 = decltype(bf_c)::value, NT_ST = decltype(nt_c)::value;
+        // (columns beyond N: an out-of-range offset from the start -- N % 4 == 0, a 16-byte piece is in or out whole; rows beyond M:
+        //  a select per piece, in the edge tiles' instance only.  The edge tiles matter: in a one-round launch the slowest tile ends it.)
+        const unsigned voff = nc < P.N ? (unsigned)(m0 + wm0 + rsub) * ldcb + (unsigned)nc * c_elem : 0xFFFFFFF0u;
+        const bool edge_m = m0 + BM > P.M || n0 + BN > P.N;       // (an edge tile of either kind)
+        auto emit = [&](auto bf_c, auto nt_c, auto edge_c) {
+            constexpr bool C16 = decltype(bf_c)::value, NT_ST = decltype(nt_c)::value, EDGE = decltype(edge_c)::value;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -845,28 +847,39 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                 for (int rr = 0; rr < 32 / RPI; ++rr) {
                     const float4 a4 = *reinterpret_cast<const float4*>(scr + (rr * RPI + rsub) * SROW + cch * 4);
                     const float v0 = a4.x + b4.x, v1 = a4.y + b4.y, v2 = a4.z + b4.z, v3 = a4.w + b4.w;
-                    local += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                    unsigned vo = voff;
+                    if (EDGE) vo = (m0 + wm0 + i * 32 + rr * RPI + rsub < P.M) ? voff : 0xFFFFFFF0u;
+                    const float sq = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                    if (EDGE) local += (vo != 0xFFFFFFF0u) ? sq : 0.f;          // (rows beyond M repeat row M - 1, columns beyond N hold other data)
+                    else local += sq;
                     const unsigned so = (unsigned)(i * 32 + rr * RPI) * ldcb;
                     if (C16) {
                         auto bfr = [](float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); };
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         u32x2 pk; pk.x = bfr(v0) | (bfr(v1) << 16); pk.y = bfr(v2) | (bfr(v3) << 16);
-                        __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, (int)voff, (int)so, NT_ST ? 2 : 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, (int)vo, (int)so, NT_ST ? 2 : 0);
                     } else {
+                        // (the row offset in the VECTOR offset here: a 16-byte buffer store with a scalar-register offset had its data
+                        //  registers overwritten under it -- wrong .y elements in fixed lanes, tools/debug_bf16_epilogue.py; hipcc's
+                        //  hazard model holds that form free of the store-data hazard, gfx950 does not)
                         u32x4 pk; pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3);
-                        __builtin_amdgcn_raw_buffer_store_b128(pk, c_rs, (int)voff, (int)so, NT_ST ? 2 : 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, c_rs, (int)(vo == 0xFFFFFFF0u ? vo : vo + so), 0, NT_ST ? 2 : 0);
                     }
                 }
             }
         };
+        auto emit2 = [&](auto bf_c, auto nt_c) {
+            if (edge_m) { asm volatile("; rows beyond M"); emit(bf_c, nt_c, std::true_type{}); }
+            else emit(bf_c, nt_c, std::false_type{});
+        };
         if (P.c_bf16) {
             asm volatile("; bf16 output");
-            if (P.store_nt) { asm volatile("; nt"); emit(std::true_type{}, std::true_type{}); }
-            else emit(std::true_type{}, std::false_type{});
+            if (P.store_nt) { asm volatile("; nt"); emit2(std::true_type{}, std::true_type{}); }
+            else emit2(std::true_type{}, std::false_type{});
         } else {
             asm volatile("; fp32 output");
-            if (P.store_nt) { asm volatile("; nt"); emit(std::false_type{}, std::true_type{}); }
-            else emit(std::false_type{}, std::false_type{});
+            if (P.store_nt) { asm volatile("; nt"); emit2(std::false_type{}, std::true_type{}); }
+            else emit2(std::false_type{}, std::false_type{});
         }
     } else
 #pragma unroll
