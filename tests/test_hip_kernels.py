@@ -937,6 +937,23 @@ def test_gemm_bf16(nv, M, N, K, cfg):
     close(out, ref, rtol=1e-5, atol=3e-6 * float(np.sqrt(K)) * 4)     # exact bf16 products, fp32 accumulation
 
 
+@pytest.mark.parametrize('cfg', [23, 24, 26, 29, 31, 32])
+def test_gemm_bf16_stores_survive_the_instructions_behind_them(nv, cfg):
+    """Regression (round 4): a 16-byte buffer store with a scalar-register offset had its data registers overwritten by the packed
+    multiplies a few instructions behind it (gfx950; hipcc's hazard model exempts that form) -- fixed lanes of fixed rows stored a
+    wrong second element.  Integer-valued operands: the product is exact, every element is compared, five launches per shape."""
+    for (M, N, K) in ((128, 128, 64), (512, 256, 128), (256, 1000, 512)):
+        g = torch.Generator().manual_seed(M + N + K + cfg)
+        a = _bf16(torch.randint(-4, 5, (M, K), generator=g).float())
+        w = _bf16(torch.randint(-4, 5, (N, K), generator=g).float())
+        ref = a.float() @ w.float().t()
+        A, W = dev(a), dev(w)
+        for rep in range(5):
+            out = torch.full((M, N), float('nan'), device='cuda')
+            nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N)], cfg)
+            assert torch.equal(out.cpu(), ref), (cfg, M, N, K, rep, int((out.cpu() != ref).sum()))
+
+
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (512, 256, 128), (130, 264, 200), (512, 1000, 2000), (40, 136, 24),
                                    (256, 72, 520)])
 @pytest.mark.parametrize('cfg', [23, 24, 25])
