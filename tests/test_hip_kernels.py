@@ -88,6 +88,24 @@ def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
             assert torch.equal(out, ref), f'{layout} cfg {cfg} != cfg {twin} at {(M, N, K, sk)}'
 
 
+@pytest.mark.parametrize('cfg', [1, 12, 17])
+def test_gemm_f32_lean_epilogue_is_exact_on_integers(nv, cfg):
+    """The fp32 kernel's lean store path (4-byte buffer stores with a scalar-register row offset, the value's register reused two
+    instructions later): integer-valued operands, exact products, every element, interior and edge tiles, slabs and a plain
+    result with per-tile sums of squares; five launches."""
+    for (M, N, K, sk) in ((512, 384, 96, 1), (300, 200, 64, 1), (512, 520, 256, 2)):
+        g = torch.Generator().manual_seed(M + N + K + cfg)
+        a = torch.randint(-4, 5, (M, K), generator=g).float()
+        w = torch.randint(-4, 5, (N, K), generator=g).float()
+        ref = a @ w.t()
+        A, W = dev(a), dev(w)
+        for rep in range(5):
+            out = torch.full((sk, M, N), float('nan'), device='cuda')
+            kw = dict(splitk=sk, slab_stride=M * N) if sk > 1 else {}
+            nv.gemm([nv.gemm_problem(A, W, out, M, N, K, K, K, N, **kw)], nv.NT, cfg)
+            assert torch.equal(out.sum(0).cpu(), ref), (cfg, M, N, K, sk, rep)
+
+
 @pytest.mark.parametrize('cfg', [1, 12, 17, 18])
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
 def test_gemm_f32_rows_that_end_inside_a_float4(nv, layout, cfg):
@@ -951,6 +969,19 @@ def test_gemm_bf16_stores_survive_the_instructions_behind_them(nv, cfg):
         for rep in range(5):
             out = torch.full((M, N), float('nan'), device='cuda')
             nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N)], cfg)
+            assert torch.equal(out.cpu(), ref), (cfg, M, N, K, rep, int((out.cpu() != ref).sum()))
+    if cfg not in (24, 29):
+        return
+    # the weight-gradient form: operands stored k-major, bf16 result (8-byte stores with a scalar-register row offset), exact in bf16
+    for (M, N, K) in ((256, 384, 64), (2000, 1000, 64)):
+        g = torch.Generator().manual_seed(M + N + cfg)
+        a = _bf16(torch.randint(-1, 2, (K, M), generator=g).float())
+        b = _bf16(torch.randint(-1, 2, (K, N), generator=g).float())
+        ref = (a.float().t() @ b.float()).to(torch.bfloat16)
+        A, Bm = dev(a), dev(b)
+        for rep in range(5):
+            out = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+            nv.gemm_bf16([nv.gemm_problem(A, Bm, out, M, N, K, M, N, N, a_tr=True, b_tr=True, store_nt=True, c_bf16=True)], cfg)
             assert torch.equal(out.cpu(), ref), (cfg, M, N, K, rep, int((out.cpu() != ref).sum()))
 
 
