@@ -28,6 +28,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.perf_counter()
 
 CONFIGS = {
     # name: (cells, dims, latent)
@@ -43,11 +44,15 @@ ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the expos
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, 2, 1, true>'      # engine.F32_CFG_ROWS = 17 on the large layers
 PEAK_HBM_GBS = 8000.0
-SETTLE_STEPS = 100               # plan replays inside job construction, before the W warm-up steps (clock / cache steady state)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (never the 2:1-sparsity figure)
+INGEST_TBPS = 17.0               # L2 -> LDS ingest of the whole chip: 256 CUs x 66 GB/s (MI355X_MICROARCH.md 'Indexed rows: gather into LDS';
+                                 # DESIGN.md §4): what the M = 512 GEMM launches are bound by in bf16
+STEADY_STEPS = 200               # the `steady_state` sub-record: more steps timed BEHIND the contract's K steps
+OTHER_BUDGET_S = 150.0           # `other_configs` sub-records (C4 bf16, C5's dimensions fp32): skipped, and said so, beyond this
 LEG_BUDGET_S = 240.0             # N > 1: a sub-record leg (another data-parallel arrangement, timed behind the headline) is abandoned after this long
 
 
-def synth_shard(n_cells, lo, hi, dims, rank, world, device):
+def synth_shard(n_cells, lo, hi, dims, rank, world, device, device_noise=False):
     """SURVEY.md §8(d) generator: rng = np.random.default_rng(0); Z ~ N(0,1) [N, 16]; X_i = Z A_i + 0.1 E_i with
     A_i ~ N(0,1) [16, d_i], E_i ~ N(0,1); fp32; then standardised per feature (what `preclass(axis=0)` does in the
     reference, jamie.py:462-465).  Draw order: Z, every A_i, then every E_i, so that Z and the A_i are the same for every
@@ -61,7 +66,7 @@ def synth_shard(n_cells, lo, hi, dims, rank, world, device):
     # beyond 1e9 noise values per rank (config 5: 7e9 at one rank) the E_i are drawn ON THE DEVICE (torch Philox generator
     # seeded per rank, 100 000 rows at a time into the output) -- numpy would spend minutes and 28 GB of host memory on
     # them; Z and the A_i still come from default_rng(0), so the factor structure is the same for every world size
-    on_device = (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1'
+    on_device = device_noise or (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1'
     gen = torch.Generator(device=device).manual_seed(1000 + rank) if on_device else None
     out = []
     for a in A:
@@ -261,7 +266,58 @@ def cpu_baseline(dims, L, B, budget_s=24.0):
     return out
 
 
-def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20):
+def _static_traffic(key):
+    """profiles/traffic.json[key] -> (record or None, note): HBM bytes per launch from separate rocprofv3 --pmc passes of this
+    command (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section), committed with the profile they came from."""
+    tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        rec = json.load(open(tf)).get(key)
+    except Exception:       # noqa: BLE001
+        rec = None
+    if not rec or rec.get('hbm_bytes_per_launch') is None:
+        return None, None
+    return rec, (f"profiles/traffic.json[{key}] (static: FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
+                 f"command, profile {rec.get('source')}; NOT measured in this run)")
+
+
+def encoder_gemm_record(eng, ms, config, dtype):
+    """Roofline of the kernel north_star names -- the encoder's first Linear (reference model.py:151: [B, d] x [2d, d]^T, both
+    modalities in one grouped launch) -- from its HIP-event launch time `ms` (median over the timed steps): against the dense MFMA
+    peak of the dtype, against HBM on its algorithmic bytes (operands once + ONE fp32 output; the split-K slabs the launch
+    really writes are in `hbm_bytes`, from the counters) and against the resource that binds it at M = 512, the L2 -> LDS
+    ingest of the CUs (INGEST_TBPS): every workgroup pulls its (BM + BN) x K operand panels in, so the launch moves
+    sum(tiles x K x (BM + BN)) x element bytes through the CUs whatever the caches hold."""
+    from jamie_amd import _native as nv
+    from jamie_amd import engine as je
+    B, dims = eng.B, eng.dims
+    es = 2 if dtype == 'bf16' else 4
+    flop = 4.0 * B * sum(d * d for d in dims)
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+    alg = sum(B * d * es + 2 * d * d * es + B * 2 * d * 4 for d in dims)
+    ingest, tiles, slices = 0.0, [], []
+    for i, d in enumerate(dims):
+        if dtype == 'bf16':
+            cfg = eng.gcfg.get('enc0', -1)
+            bm, bn = je.BF16_TILE.get(cfg, nv.gemm_bf16_tile(B, 2 * d))
+        else:
+            bm, bn = nv.gemm_tile(nv.NT, B, 2 * d, d, eng.fcfg.get('enc0', -1))
+        ingest += -(-B // bm) * -(-2 * d // bn) * d * (bm + bn) * es
+        tiles.append([int(bm), int(bn)])
+        slices.append(int(eng.ws[i]['sk']['enc0']))
+    rec, note = _static_traffic(f'{config}_{dtype}_encoder_gemm')
+    hbm = rec['hbm_bytes_per_launch'] if rec else None
+    t = ms * 1e-3
+    out = {'kernel': 'forward d -> 2d Linear of the encoder (reference model.py:151), both modalities in one launch',
+           'avg_launch_ms': ms, 'flop': flop, 'tflops': flop / t / 1e12, 'peak_tflops': peak, 'frac_mfma': flop / t / 1e12 / peak,
+           'algorithmic_bytes': alg, 'frac_hbm_algorithmic': alg / t / 1e9 / PEAK_HBM_GBS,
+           'hbm_bytes': hbm, 'hbm_bytes_source': note, 'frac_hbm': (hbm / t / 1e9 / PEAK_HBM_GBS) if hbm else None,
+           'tile': tiles, 'k_slices': slices, 'ingest_model_bytes': ingest, 'ingest_peak_TBps': INGEST_TBPS,
+           'frac_ingest': ingest / t / 1e12 / INGEST_TBPS,
+           'binding': 'L2 -> LDS ingest of the CUs' if dtype == 'bf16' else 'MFMA (fp32 matrix pipe)'}
+    return out
+
+
+def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20, config='c2'):
     """The parity configuration (exact-fp32 MFMA) on the same workload: cells/s, ms/step and the roofline of ITS dominant
     kernel, the forward d <-> 2d Linear GEMM launch (north_star: >= 60 % of the binding roofline on the encoder matmul)."""
     from jamie_amd.engine import TrainEngine
@@ -275,13 +331,14 @@ def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20):
     for _ in range(warmup):
         eng.run_plan(plan)
     torch.cuda.synchronize()
-    eng.enable_kernel_timing('enc_gemm', every=4)
+    eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', every=4)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.run_plan(plan)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = eng.kernel_timing_ms('enc_gemm', 'all')
+    tm0 = eng.kernel_timing_ms('enc0_gemm', 'all')
     gemm_flop = 4.0 * B * sum(d * d for d in model_dims)
     achieved = gemm_flop / (tm['median'] * 1e-3) / 1e12
     cells_s = B * steps / dt
@@ -292,7 +349,85 @@ def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20):
                                                      'GEMM, both modalities in one launch; 4 launches/step)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': tm['median'], 'flop_per_launch': gemm_flop,
-                         'whole_step_frac': cells_s * flops_per_cell(model_dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)}}
+                         'whole_step_frac': cells_s * flops_per_cell(model_dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                         'encoder_gemm': encoder_gemm_record(eng, tm0['median'], config, 'f32')}}
+
+
+def other_config_record(name, dtype, dev, B=512, steps=20, warmup=5):
+    """One more single-GPU configuration of BASELINE.json timed by the same process (driver-timed figures for
+    C4 and for C5's dimensions): the workload at its own size (synthetic cells as in the headline, the noise term drawn on the
+    device to keep the leg short), plan construction, `warmup` untimed and `steps` timed steps, the encoder-GEMM roofline."""
+    from jamie_amd.engine import TrainEngine, kl_anneal
+    from jamie_amd.model import edModelVar
+    t_leg = time.perf_counter()
+    n_cells, dims, L = CONFIGS[name]
+    pad = 8 if (dtype == 'bf16' and any(d % 8 for d in dims)) else 1
+    data = synth_shard(n_cells, 0, n_cells, dims, 0, 1, dev, device_noise=True)
+    torch.manual_seed(666)
+    model = edModelVar(dims, L, device=dev, pad_features=pad)
+    eng = TrainEngine(model, B, lr=1e-3, seed=666, compute_dtype=dtype)
+    data = eng.pad_cells(data)
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    eng.set_kl_anneal(kl_anneal(0, 2500, 10000))
+    eng.enable_kernel_timing('enc0_gemm')
+    rep = min(dims) < B and len(dims) == 2
+    plan = eng.make_plan(data, idx, n_cells, rep, None)
+    for _ in range(warmup):
+        eng.run_plan(plan)
+    torch.cuda.synchronize()
+    eng.enable_kernel_timing('enc0_gemm', every=2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.run_plan(plan)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm0 = eng.kernel_timing_ms('enc0_gemm', 'all')
+    total = eng.read_losses()[1]
+    if not np.isfinite(total):
+        raise RuntimeError('non-finite loss')
+    rec = {'value': B * steps / dt, 'unit': 'cells/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup, 'dtype': dtype,
+           'workload': f'{name}: {len(dims)}-modality synthetic {n_cells} cells x {tuple(dims)} features, latent={L}, B={B}, one GPU '
+                       f'(noise term of the generator drawn on the device)',
+           'parameters': model.num_parameters(), 'flop_per_cell': flops_per_cell(dims, L), 'final_loss': total,
+           'encoder_gemm': encoder_gemm_record(eng, tm0['median'], name, dtype) if tm0 else None}
+    if dtype == 'f32':
+        rec['whole_step_frac_mfma'] = rec['value'] * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    rec['leg_seconds'] = round(time.perf_counter() - t_leg, 1)
+    del plan, eng, model, data
+    torch.cuda.empty_cache()
+    return rec
+
+
+def allreduce_probe(element_counts, dev, world, iters=10):
+    """Measured all-reduce bandwidth of THIS job's communicator at the step's own message sizes (every rank calls this): per
+    distinct message (element count) and per message dtype, 3 untimed + `iters` timed all-reduces, each bracketed by HIP events
+    on the issuing stream; algbw = bytes / time, busbw = algbw x 2 (n - 1) / n (what one link direction carries in a ring).
+    Read it against SURVEY.md 5's estimates for config 3's 161 MB (fp32) gradient: a single ring at ~90 GB/s algbw is 1.8 ms,
+    direct reduce-scatter + all-gather over all 7 xGMI links ~0.26 ms."""
+    dist = torch.distributed
+    out = []
+    for n in sorted(set(int(c) for c in element_counts if c > 0)):
+        for dt, es, nm in ((torch.bfloat16, 2, 'bf16'), (torch.float32, 4, 'f32')):
+            buf = torch.zeros(n, dtype=dt, device=dev)
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ts = []
+            for _ in range(iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(buf)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+                buf.zero_()
+            med = float(np.median(ts))
+            alg = n * es / (med * 1e-3) / 1e9 if med > 0 else None
+            out.append({'elements': n, 'dtype': nm, 'bytes': n * es, 'median_us': 1e3 * med, 'min_us': 1e3 * float(min(ts)),
+                        'algbw_GBps': alg, 'busbw_GBps': alg * 2.0 * (world - 1) / world if alg else None, 'iters': iters})
+            del buf
+    return out
 
 
 def rccl_record(world, log_dir):
@@ -328,17 +463,43 @@ def rccl_record(world, log_dir):
     return rec
 
 
+def visible_gpus(root='/sys/class/kfd/kfd/topology/nodes'):
+    """GPUs visible to this process, counted WITHOUT a HIP call (the launcher parent must never initialise the runtime: it
+    fork+execs the ranks): KFD's topology nodes with SIMDs, cut down by HIP_/ROCR_/CUDA_VISIBLE_DEVICES when those hold plain
+    index lists.  None if sysfs has nothing to say: every rank checks for itself in main() anyway (and exits non-zero)."""
+    import glob
+    n = 0
+    try:
+        for f in glob.glob(os.path.join(root, '*', 'properties')):
+            props = dict(ln.split(None, 1) for ln in open(f).read().splitlines() if ' ' in ln)
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    if n == 0:
+        return None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is None:
+            continue
+        ids = [x for x in v.split(',') if x.strip() != '']
+        if all(x.strip().lstrip('-').isdigit() for x in ids):
+            n = min(n, len([x for x in ids if int(x) >= 0]))
+        # (UUID-style lists: leave the count to the ranks' own check)
+    return n
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): be the launcher.  Called BEFORE anything
-    touches the GPU (counting devices does not initialise HIP); the children are fresh processes of this script, never an
+    touches the GPU (devices are counted from sysfs, `visible_gpus`: no HIP call in this parent); the children are fresh processes of this script, never an
     exec of a process that holds the device.  Rank 0's stdout is relayed (the ONE JSON line), every rank's stderr goes to
     ours.  Returns the exit code: 0 only if every rank exited 0."""
     import signal
     import socket
     import subprocess
     share = os.environ.get('JAMIE_SHARE_GPU') == '1'           # test hook: the ranks share cuda:0 (jamie_amd/distributed.py)
-    have = torch.cuda.device_count()
-    if have < (1 if share else n):
+    have = visible_gpus()
+    if have is not None and have < (1 if share else n):
         print(f'bench.py: --gpus {n} but {have} GPU(s) visible to this process; refusing to print a line for fewer GPUs '
               f'than requested', file=sys.stderr)
         return 2
@@ -423,6 +584,10 @@ def main():
                     help='bf16: transposed weight copies on a side stream under the next forward pass')
     ap.add_argument('--opt-priority', type=int, default=0, help='HIP stream priority of the optimiser stream')
     ap.add_argument('--cpu-budget', type=float, default=24.0)
+    ap.add_argument('--settle', type=int, default=0,
+                    help='extra untimed plan replays in front of the W warm-up steps (default 0: --warmup is the only warm-up the '
+                         'headline gets; the steady-state figure is the `steady_state` sub-record, timed behind the K steps)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` sub-records (C4 bf16, C5 dims fp32)')
     ap.add_argument('--tune', default=os.environ.get('JAMIE_TUNE', ''),
                     help='A/B measurements (tools/ab.sh): "key=value+key=value" for jamie_amd.engine.tune() -- tile / split-K plans and the '
                          'older variant of every adopted change (engine.TUNING); also read from JAMIE_TUNE')
@@ -443,11 +608,13 @@ def main():
         os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,GRAPH',
                           NCCL_DEBUG_FILE=os.path.join(log_dir, 'rccl_%h_%p.log'))
     from jamie_amd import distributed as jd
+    w_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if w_env > 1 and os.environ.get('JAMIE_SHARE_GPU') != '1' and torch.cuda.device_count() < w_env:
+        # (a rank process may ask the runtime; checked BEFORE the process group exists so that every rank ends at once)
+        raise SystemExit(f'--gpus {w_env} but {torch.cuda.device_count()} GPU(s) visible')
     rank, world, local = jd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if world > 1 and os.environ.get('JAMIE_SHARE_GPU') != '1' and torch.cuda.device_count() < world:
-        raise SystemExit(f'--gpus {world} but {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     from jamie_amd import _native as nv
@@ -520,15 +687,13 @@ def main():
             eng_.enable_pipeline(args.opt_priority)
         if args.side_transposes:
             eng_.enable_side_transposes()
-        eng_.enable_kernel_timing('enc_gemm', 'adam')
+        eng_.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam')
         # the step is a fixed launch sequence on static buffers: record it once, replay it (one foreign call per launch)
         plan_ = eng_.make_plan(data_, idx_, hi - lo, rep, ar_, prefetch=args.prefetch)
-        # part of building the job, like the recording step: the plan is replayed SETTLE_STEPS times so that the GPU clock, the
-        # caches and the allocator are in their steady state BEFORE the W warm-up steps (the metric is the
-        # steady-state loop; with W = 5 and K = 20 -- the driver's line -- the first steps after a cold start read 2-3 % slow:
-        # 586-595 against 574-578 us per step for W = 20, K = 200 on one box).  Untimed; the W warm-up steps and EXACTLY K timed
-        # steps follow as the contract says.
-        for _ in range(SETTLE_STEPS):
+        # --settle N (default 0): N more untimed replays.  Round 4 ran 100 of them by default in front of the driver's W = 5; the
+        # contract's warm-up is --warmup and nothing else, so the default is gone and the steady-state figure is
+        # reported beside the headline instead (`steady_state`: STEADY_STEPS more steps timed behind the K steps).
+        for _ in range(max(0, args.settle)):
             eng_.run_plan(plan_)
         torch.cuda.synchronize()
         return model_, eng_, data_, ar_, opt_, idx_, plan_
@@ -549,7 +714,7 @@ def main():
             state['epoch'] = ep
             eng.set_kl_anneal(kl_anneal(ep, 2500, 10000))
     state['epoch'] = 0
-    state['step'] = 2 + SETTLE_STEPS
+    state['step'] = 2 + max(0, args.settle)
 
     def step():
         set_anneal()
@@ -564,9 +729,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if world > 1 and allreduce is not None and hasattr(allreduce, 'enable_exposure'):
+        allreduce.enable_exposure(True, every=4)      # HIP events around finish()'s device-side waits (the exposed part of the exchange)
     events = os.environ.get('JAMIE_BENCH_NO_EVENTS') != '1'
     if events:
-        eng.enable_kernel_timing('enc_gemm', 'adam', every=8)   # drop the warm-up samples; sample every 8th step
+        # drop the warm-up samples; sample every 8th step (every 2nd of a short run: the driver's K = 20 would leave 2-3 samples)
+        eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam', every=8 if args.steps > 64 else 2)
     else:
         eng._timing = None
     t0 = time.perf_counter()
@@ -578,8 +746,35 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    exposure, msg_elems = None, []
+    if world > 1 and allreduce is not None and hasattr(allreduce, 'exposed_us'):
+        exposure = allreduce.exposed_us()
+        msg_elems = allreduce.message_elements()
+        allreduce.enable_exposure(False)
+    # `steady_state`: STEADY_STEPS more steps timed the same way right BEHIND the contract's region (the driver's W = 5 / K = 20 is
+    # 14 ms after a cold start; the GPU's clock and caches settle over the first ~100 steps: 2-3 % on one box).  A sub-record,
+    # never `value`.
+    steady = None
+    timing_head = {k: eng.kernel_timing_ms(k, 'all') for k in ('enc_gemm', 'enc0_gemm', 'adam')} if events else None
+    if args.dry_run_world <= 1:
+        if events:
+            eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam', every=8)      # (this leg's own samples)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(STEADY_STEPS):
+            step()
+        barrier()
+        ds = time.perf_counter() - ts
+        if world > 1:
+            t = torch.tensor([ds], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ds = float(t.item())
+        steady = {'value': world * B * STEADY_STEPS / ds, 'unit': 'cells/s', 'ms_per_step': 1e3 * ds / STEADY_STEPS, 'steps': STEADY_STEPS,
+                  'note': f'{STEADY_STEPS} more steps timed behind the K timed steps of the headline (same barriers, max over ranks)'}
+        if events:
+            steady['kernel_event_timing_ms'] = {k: eng.kernel_timing_ms(k, 'all') for k in ('enc_gemm', 'enc0_gemm', 'adam')}
     if not events:          # kernel timings from extra steps AFTER the timed region -- on every rank (a step is a collective)
-        eng.enable_kernel_timing('enc_gemm', 'adam')
+        eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam')
         for _ in range(20):
             step()
         barrier()
@@ -630,23 +825,17 @@ def main():
         #         4*B*sum(d^2) FLOP) against the exact-fp32 MFMA peak;
         #   bf16: the step is HBM-bound on optimiser traffic; the dominant kernel is clip+Adam:
         #         28 bytes per parameter (read p, g, m, v; write p, m, v) against the HBM peak.
-        timing_detail = {'enc_gemm': eng.kernel_timing_ms('enc_gemm', 'all'), 'adam': eng.kernel_timing_ms('adam', 'all')}
+        timing_detail = timing_head if timing_head is not None else {
+            'enc_gemm': eng.kernel_timing_ms('enc_gemm', 'all'), 'enc0_gemm': eng.kernel_timing_ms('enc0_gemm', 'all'),
+            'adam': eng.kernel_timing_ms('adam', 'all')}
         # event pairs bracket one launch each; a host hiccup between the two records (GC, scheduler) shows up as a
         # multi-millisecond outlier in a handful of the samples, so the per-launch duration is the MEDIAN
         gemm_ms, adam_ms = timing_detail['enc_gemm']['median'], timing_detail['adam']['median']
         kdims = eng.dims                                   # what the kernels multiply (padded feature counts, if any)
         gemm_flop = 4.0 * B * sum(d * d for d in kdims)
-        traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tf):
-            try:
-                rec = json.load(open(tf)).get(f'{args.config}_{args.dtype}', {})
-                traffic = rec.get('hbm_bytes_per_launch')
-                if traffic is not None:
-                    traffic_source = (f"profiles/traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc "
-                                      f"passes of this command, profile {rec.get('source')}; NOT measured in this run)")
-            except Exception:       # noqa: BLE001
-                traffic = None
+        rec, traffic_source = _static_traffic(f'{args.config}_{args.dtype}')
+        traffic = rec['hbm_bytes_per_launch'] if rec else None
+        enc0 = encoder_gemm_record(eng, timing_detail['enc0_gemm']['median'], args.config, args.dtype) if timing_detail['enc0_gemm'] else None
         if args.dtype == 'f32':
             achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': F32_ROOFLINE_KERNEL + ' (Linear d<->2d forward '
@@ -654,7 +843,8 @@ def main():
                     'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop,
                     'traffic': traffic, 'traffic_source': traffic_source,
-                    'whole_step_frac': cells_s / world * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)}
+                    'whole_step_frac': cells_s / world * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                    'encoder_gemm': enc0}
         else:
             n_par = model.layout.total
             adam_launches = len(eng.PIPE_GROUPS) if eng.pipeline else 1
@@ -662,7 +852,13 @@ def main():
                 n_par = eng._zs['S']
             adam_bytes = eng.adam_bytes_per_param() * n_par / adam_launches
             achieved = adam_bytes / (adam_ms * 1e-3) / 1e9
-            step_bytes = 44.0 * model.layout.total
+            # the step's algorithmic weight-side bytes in THIS dtype: forward + backward read the bf16 weight copy (2 + 2 B per
+            # parameter), the dW epilogues write bf16 gradients (2), clip + Adam moves 26 (p, m, v in and out, g in) and writes
+            # the bf16 copy (2): 34 B per parameter (fp32 gradients: 38).  SURVEY.md 8(d)'s 44 P is the fp32 byte model; the
+            # fraction on it is kept beside this one, named.
+            own_bpp = 8.0 + eng.adam_bytes_per_param() if eng.grad_bf16 else 10.0 + eng.adam_bytes_per_param()
+            step_bytes = own_bpp * model.layout.total
+            step_bytes_f32_model = 44.0 * model.layout.total
             roof = {'bound': 'hbm', 'kernel': f'clip_adam_kernel (global-norm clip + Adam on the flat fp32 buffers; {adam_launches} launch(es)/step'
                                        + (', on the optimiser stream under the next forward pass)' if eng.pipeline else
                                           (f'; sharded optimiser: this launch covers 1/{n_dp} of the large weight regions)' if dp_opt == 'sharded' else ')')),
@@ -670,7 +866,10 @@ def main():
                     'avg_launch_ms': adam_ms, 'bytes_per_launch': adam_bytes,
                     'bytes_per_parameter': eng.adam_bytes_per_param(), 'traffic': traffic, 'traffic_source': traffic_source,
                     'whole_step_frac': (step_bytes * cells_s / world / B) / (PEAK_HBM_GBS * 1e9),
-                    'gemm_bf16_tflops': gemm_flop / (gemm_ms * 1e-3) / 1e12, 'gemm_avg_launch_ms': gemm_ms}
+                    'whole_step_bytes_per_parameter': own_bpp,
+                    'whole_step_frac_on_fp32_byte_model_44P': (step_bytes_f32_model * cells_s / world / B) / (PEAK_HBM_GBS * 1e9),
+                    'gemm_bf16_tflops': gemm_flop / (gemm_ms * 1e-3) / 1e12, 'gemm_avg_launch_ms': gemm_ms,
+                    'encoder_gemm': enc0}
         out = {
             'metric': 'training cells/sec (two-modality coupled VAE)', 'value': cells_s, 'unit': 'cells/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -681,7 +880,7 @@ def main():
                                    + 'identity P (diag sampling), F=0, KL anneal per epoch',
                        'generator': 'SURVEY.md 8(d): numpy default_rng(0), 16-dim latent factor model + 0.1 noise, standardised per feature'
                                     + ('; the noise term drawn on the device (torch generator per rank)' if (hi - lo) * sum(dims) > 1_000_000_000 or os.environ.get('JAMIE_BENCH_DEVICE_NOISE') == '1' else ''),
-                       'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B, 'settle_steps_before_warmup': SETTLE_STEPS,
+                       'cells': n_cells, 'features': list(dims), 'latent': L, 'batch_per_gpu': B, 'settle_steps_before_warmup': max(0, args.settle),
                        'parallelism': f'dp{world}', 'grad_allreduce': ('none' if world == 1 else ('bf16' if comm is not None else 'f32')),
                        'dp_optimizer': dp_opt, **({'dp_optimizer_fallback': dp_fallback} if dp_fallback else {}),
                        'parameters': model.num_parameters(),
@@ -690,6 +889,8 @@ def main():
             'kernel_event_timing_ms': timing_detail,
             'final_loss': total,
         }
+        if steady is not None:
+            out['steady_state'] = steady
         if args.dry_run_world > 1:
             out['dry_run_world'] = args.dry_run_world
             out['dp_model'] = dp
@@ -697,6 +898,19 @@ def main():
         if world > 1:
             out['rccl'] = rccl_record(world, log_dir) if log_dir else {'backend': torch.distributed.get_backend(),
                                                                         'world': torch.distributed.get_world_size(), 'algo': None}
+            # measured, not modelled: the time the step's stream stood still in finish() waiting for messages on the wire
+            out['exchange'] = {'exposed_us_per_step': exposure,
+                               'messages_per_step': [{'elements': int(n), 'bytes': int(n) * (2 if comm is not None else 4)} for n in msg_elems],
+                               'note': 'HIP events on the launch stream around the device-side waits of finish(), every 4th timed step '
+                                       '(median / mean / max in us); messages in issue order'}
+    if world > 1:
+        # every rank: all-reduce bandwidth of this communicator at the step's message sizes (the headline is already measured)
+        try:
+            probe = allreduce_probe(msg_elems, dev, world)
+        except Exception as err:         # noqa: BLE001
+            probe = {'error': f'{type(err).__name__}: {err}'[:300]}
+        if rank == 0:
+            out['rccl']['allreduce_probe'] = probe
     if world > 1 and not args.no_f32_record:
         # N > 1: the same job in its other data-parallel arrangements, timed right behind the headline on every rank (a step is
         # a collective), so that one invocation reports them all:
@@ -770,7 +984,25 @@ def main():
         if args.dtype == 'bf16' and not args.no_f32_record and len(dims) == 2 and not any(d % 8 for d in dims):
             del eng, model
             torch.cuda.empty_cache()
-            out['f32'] = f32_record(dims, L, B, data_real, hi - lo, rep, dev)
+            out['f32'] = f32_record(dims, L, B, data_real, hi - lo, rep, dev, config=args.config)
+        if args.config == 'c2' and args.dtype == 'bf16' and not args.no_other_configs and B == 512 and args.dry_run_world <= 1:
+            # driver-timed sub-records of the other single-GPU configurations, inside a stated budget: each leg is skipped (and says
+            # so) when the process has already spent OTHER_BUDGET_S since it started
+            try:
+                del data_real, data
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            out['other_configs'] = {'budget_s': OTHER_BUDGET_S}
+            for key, cname, cdt in (('c4_bf16', 'c4', 'bf16'), ('c5dims_f32', 'c5dims', 'f32')):
+                spent = time.perf_counter() - T_START
+                if spent > OTHER_BUDGET_S:
+                    out['other_configs'][key] = {'value': None, 'skipped': f'{spent:.0f} s spent before this leg: over the {OTHER_BUDGET_S:.0f} s budget'}
+                    continue
+                try:
+                    out['other_configs'][key] = other_config_record(cname, cdt, dev, B)
+                except Exception as err:         # noqa: BLE001  (a sub-record must never lose the headline)
+                    out['other_configs'][key] = {'value': None, 'error': f'{type(err).__name__}: {err}'[:300]}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dims, L, B, args.cpu_budget)
             out['gpu_over_cpu'] = cells_s / out['cpu_baseline']['value']

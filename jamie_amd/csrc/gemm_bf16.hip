@@ -741,9 +741,24 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     };
 
     // prologue: every buffer in flight, then tile 0 published and its first fragments read
+    if constexpr (!FUSE) JB_STAMP(6);
+#ifdef JB_PRO_BARRIER
+    // A/B (round 5): tile 0's pieces of EVERY wave go out before any wave's tile 1 / 2 pieces -- the waves reach this point up to
+    // ~0.5 us apart, and an early wave's later tiles otherwise queue in front of a late wave's tile-0 pieces (tile 0 is
+    // published when its LAST piece lands)
+    if (nk > 0) stage(0, 0);
+    if (NB > 1 && nk > 1) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 1; u < NB; ++u)
+            if (u < nk) stage(u, u);
+    }
+#else
 #pragma unroll
     for (int u = 0; u < NB; ++u)
         if (u < nk) stage(u, u);
+#endif
+    if constexpr (!FUSE) JB_STAMP(7);
     wait_tile(0, min(NB, nk) - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

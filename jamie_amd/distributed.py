@@ -169,13 +169,35 @@ class OverlappedGradAllReduce:
         self.works = []
         self.stream = None           # side stream of the cast + collective (low-precision messages on the GPU)
         self.pending = None          # (flat, lo, hi, precast) not yet issued
+        self._msgs, self._last_msgs = [], []      # element counts of the messages of the current / the last finished step
         self._casts = {}             # (flat ptr, message-buffer ptr, lo, hi) -> prepared fp32 -> bf16 cast launch of that region
         self.trace = None            # enable_trace(): [(kind, bytes, HIP event)] of one step (bench.py's exposure model)
+        self.exposure = None         # enable_exposure(): [(event, event)] around finish()'s device-side waits
+        self._exp_every, self._exp_count = 1, 0
 
     def enable_trace(self, on=True):
         """Record a HIP event on the launch stream wherever a message is issued and where `finish()` starts waiting: the
         timeline bench.py's `dp_model` block prices the exchange against (dry runs and real ones alike)."""
         self.trace = [] if on else None
+
+    def enable_exposure(self, on=True, every=1):
+        """Bracket the device-side waits of `finish()` with HIP events on the launch stream (every `every`-th step): the time the
+        step's stream stands still waiting for gradient messages that are still on the wire -- the EXPOSED part of the exchange,
+        measured, where bench.py's `dp_model` only models it.  `exposed_us()` reads them back."""
+        self.exposure = [] if on else None
+        self._exp_every, self._exp_count = max(1, int(every)), 0
+
+    def exposed_us(self):
+        """{'median', 'mean', 'max', 'n'} of the bracketed waits in microseconds (device sync), or None."""
+        if not self.exposure:
+            return None
+        torch.cuda.synchronize()
+        t = sorted(1e3 * a.elapsed_time(b) for a, b in self.exposure)
+        return {'median': t[len(t) // 2], 'mean': sum(t) / len(t), 'max': t[-1], 'n': len(t)}
+
+    def message_elements(self):
+        """Element counts of the messages the last step issued, in issue order (bench.py's all-reduce probe)."""
+        return list(self._last_msgs)
 
     def message_buffer(self, flat):
         """The persistent low-precision exchange buffer (same offsets as the flat gradient): a producer that writes its
@@ -217,6 +239,7 @@ class OverlappedGradAllReduce:
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _issue(self, flat, lo, hi, precast=False):
+        self._msgs.append(int(hi - lo))
         if self.trace is not None and flat.is_cuda:
             from . import _native as nv
             ev = torch.cuda.Event(enable_timing=True)
@@ -267,6 +290,13 @@ class OverlappedGradAllReduce:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(nv.current_stream())
             self.trace.append(('finish', 0, ev))
+        e0 = None
+        if self.exposure is not None and self.works and torch.cuda.is_available():
+            self._exp_count += 1
+            if self._exp_count % self._exp_every == 0:
+                from . import _native as nv
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(nv.current_stream())
         for w, flat, lo, hi in self.works:
             if w is not None:
                 w.wait()
@@ -274,7 +304,13 @@ class OverlappedGradAllReduce:
                 torch.cuda.current_stream().wait_stream(self.stream)
             if flat is not None and copy_back and self._copies_back(lo, hi):
                 flat[lo:hi].copy_(self.comm[lo:hi])
+        if e0 is not None:
+            from . import _native as nv
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(nv.current_stream())
+            self.exposure.append((e0, e1))
         self.works = []
+        self._last_msgs, self._msgs = self._msgs, []
 
     def __call__(self, flat):          # non-overlapped use
         self.region_done(flat, 0, flat.numel())

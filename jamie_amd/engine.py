@@ -38,7 +38,10 @@ TUNING = {
     'fused_da2': True, 'fused_latent': True, 'direct_comm': True, 'cs_ride': True, 'late_dec0_dw': True, 'range_ride': True,
     'defer_final': True, 'fused_sampler': True, 'gather_ride': True,
     'dw_store_nt': True,          # weight gradients stored non-temporally (next read by the optimiser, a backward pass later)
-    'split_last_dw': True,        # data parallel (replicated): the last layer's dW in two launches, its first part on the wire early
+    'split_last_dw': False,       # data parallel (replicated): the last layer's dW in two launches, its first part on the wire early.
+                                  # OFF until an N > 1 A/B shows a gain: it adds a launch to the tail of the backward pass and turns
+                                  # the merged rep + enc0 message into three all-reduces (~28 us of host enqueue each); bench.py
+                                  # --tune split_last_dw=True is the A/B for the first multi-GPU box
     'f32_dw_group': 4,            # fp32, no gradient exchange: the large layers' dW products wait and go out `n` layers per launch
                                   # (4 layers = 2560 tiles of 128 x 128 = 5.0 rounds of 512 slots; one layer = 1.25 rounds); 1: off
 }
@@ -686,9 +689,12 @@ class TrainEngine:
             rec()
 
     def _launch(self, label, fn):
-        self._ev(label, 0)
+        labels = label if isinstance(label, tuple) else (label,)
+        for lb in labels:
+            self._ev(lb, 0)
         fn()
-        self._ev(label, 1)
+        for lb in labels:
+            self._ev(lb, 1)
 
     def kernel_timing_ms(self, label, stat='mean'):
         if self._timing is None or not self._timing.get(label):
@@ -844,7 +850,10 @@ class TrainEngine:
         cfg = self.gcfg.get(sk_key, -1)
         fcfg = self.fcfg.get(sk_key, -1)
         self._wait_params(lin)
-        self._launch('enc_gemm' if lin in ('enc0', 'enc1', 'dec1') or (lin == 'dec2' and fcfg >= 0) else lin,
+        # 'enc_gemm': every large forward launch; 'enc0_gemm': the encoder's first Linear alone (model.py:151, d -> 2d, both
+        # modalities: the matmul north_star's roofline target names; bench.py's roofline.encoder_gemm)
+        label = 'enc_gemm' if lin in ('enc0', 'enc1', 'dec1') or (lin == 'dec2' and fcfg >= 0) else lin
+        self._launch((label, 'enc0_gemm') if lin == 'enc0' else label,
                      (lambda: nv.gemm_bf16(probs, cfg)) if self.bf16 else (lambda: nv.gemm(probs, nv.NT, fcfg)))
 
     def _dx_gemm(self, dy_key, lin, out_key, sk_key):
@@ -927,7 +936,7 @@ class TrainEngine:
         if big and self._f32_dw_fused:
             return _f32_fused_cfg()           # (the partial sums are laid out for this tile)
         small = TUNING['f32_dw_small_cfg']
-        return (int(env) if env else F32_CFG_DW) if big else (int(small) if small not in (None, '') else -1)
+        return (int(env) if env not in (None, '') else F32_CFG_DW) if big else (int(small) if small not in (None, '') else -1)
 
     def _dw_cfg(self, lin):
         """Tile configuration of the dW launch of layer `lin` (-1: the library default for small / skinny problems)."""
@@ -1373,7 +1382,8 @@ class TrainEngine:
         # Data parallel with the replicated optimiser: this is the LAST gradient of the pass, and whatever of it is still on the wire
         # when the pass ends is exposed in full.  The first M - 1 modalities' weight gradients (config 2: 16 of the layer's 20 MB
         # as bf16) go out in a launch of their own and their message is issued at once; the last modality's launch carries the
-        # riders, and only its part (+ `rep`) is announced at the end.  (Reasoned, not measured: no multi-GPU box.)
+        # riders, and only its part (+ `rep`) is announced at the end.  (Reasoned, not measured: no multi-GPU box -- so it is an
+        # opt-in knob, TUNING['split_last_dw'], not the default.)
         split = (allreduce is not None and hasattr(allreduce, 'region_done') and self._zs is None and self.M >= 2
                  and TUNING['split_last_dw'] and not self.accumulate
                  and (getattr(allreduce, 'world', 1) > 1 or getattr(allreduce, 'single', False)))

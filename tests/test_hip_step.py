@@ -372,6 +372,16 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['value'] > 0
     assert out['rccl']['world'] == 2 and out['rccl']['backend'] == 'gloo'
     assert out['config']['dp_optimizer'] == 'replicated' and np.isfinite(out['final_loss'])
+    # the line explains its own exchange: measured all-reduce bandwidth at the step's message sizes (both message dtypes) and the
+    # time the step's stream stood still waiting for messages (HIP events around finish()'s waits)
+    msgs = out['exchange']['messages_per_step']
+    assert msgs and sum(m['elements'] for m in msgs) >= out['config']['parameters']
+    exp = out['exchange']['exposed_us_per_step']
+    assert exp is not None and exp['n'] >= 1 and exp['median'] >= 0.0
+    probe = out['rccl']['allreduce_probe']
+    assert {(p['elements'], p['dtype']) for p in probe} == {(m['elements'], dt) for m in msgs for dt in ('bf16', 'f32')}
+    assert all(p['median_us'] > 0 and p['algbw_GBps'] > 0 and p['busbw_GBps'] == pytest.approx(p['algbw_GBps'], rel=1e-6) for p in probe)
+    assert out['steady_state']['ms_per_step'] > 0 and out['config']['settle_steps_before_warmup'] == 0
     # more GPUs than the box has (one): refused, no JSON line
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
                         '--config', 'c1'], capture_output=True, text=True, env=clean, timeout=300)

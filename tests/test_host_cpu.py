@@ -253,6 +253,15 @@ for comm, tol in ((None, 0.0), (torch.bfloat16, 2e-2)):
     dist.all_gather(both, g)
     assert torch.equal(both[0], both[1]), comm
     assert not ov.works and ov.pending is None
+    # what the step put on the wire, in issue order (bench.py probes the all-reduce bandwidth at exactly these sizes): with
+    # min_bytes = 1024 the merged backward-adjacent regions [600, 1003), [100, 600) and the tail [0, 100) as fp32, and
+    # [100, 1003) + the tail as bf16 (half the bytes per element: the bucket fills later)
+    msgs = ov.message_elements()
+    assert msgs == ([403, 500, 100] if comm is None else [903, 100]), msgs
+    ov.enable_exposure(True)                   # (no GPU here: nothing to bracket, nothing recorded)
+    ov.region_done(g, 0, 1003); ov.finish()
+    assert ov.exposed_us() is None and ov.message_elements() == [1003]
+    dist.all_reduce(g)                         # (keep the ranks' buffers in step for what follows)
 # producers that write the bf16 message buffer themselves (the engine's dW epilogues): precast regions are reduced where they
 # stand, the fp32 buffer is neither read nor written, and the dry run (one process pretending to be N ranks) issues nothing
 ov = jd.OverlappedGradAllReduce(min_bytes=1024, comm_dtype=torch.bfloat16)
@@ -318,6 +327,28 @@ for comm in (None, torch.bfloat16):
 dist.destroy_process_group()
 print('OK', rank)
 '''
+
+
+def test_bench_counts_gpus_from_sysfs_without_hip(tmp_path, monkeypatch):
+    """bench.visible_gpus (the launcher parent of `bench.py --gpus N` must not initialise HIP before it starts the ranks,
+    ADVICE r4): KFD topology nodes with SIMDs, cut down by plain index lists in *_VISIBLE_DEVICES; None when sysfs is silent."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.visible_gpus(str(tmp_path / 'absent')) is None
+    for i, simd in enumerate((0, 1024, 1024, 1024)):          # node 0: the CPU
+        d = tmp_path / 'nodes' / str(i)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text(f'cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n')
+    assert bench.visible_gpus(str(tmp_path / 'nodes')) == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2')
+    assert bench.visible_gpus(str(tmp_path / 'nodes')) == 2
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', 'GPU-abcdef')   # UUID form: left to the ranks' own check
+    assert bench.visible_gpus(str(tmp_path / 'nodes')) == 3
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    body = src[src.index('def spawn_ranks'):src.index('def main')]
+    assert 'device_count' not in body and 'is_available' not in body      # the parent asks sysfs, never the runtime
 
 
 def test_dry_run_exchange_issues_no_collective():

@@ -18,7 +18,7 @@ for i in $(seq 1 $R); do
   for E in "${V[@]}"; do
     n=$((n + 1))
     EE="$E"; if [ "$E" = "-" ]; then EE=""; fi
-    out=$(env $EE python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-f32-record "$@" 2>/dev/null | tail -1)
+    out=$(env $EE python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-f32-record --no-other-configs "$@" 2>/dev/null | tail -1)
     echo "v$n [$E] $(echo "$out" | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d.get('kernel_event_timing_ms',{}); print(round(d['value']), round(1e3*d['ms_per_step'],1), 'us/step  adam', round(1e3*d['roofline']['avg_launch_ms'],1), ' enc_gemm', round(1e3*k.get('enc_gemm',{}).get('median',0),1))")"
   done
 done

@@ -38,6 +38,11 @@ def run(name, shapes, cfg, sks, iters=13):
     print(f'== {name} cfg {cfg} sk {sks}: {len(a)} workgroups, event {e0.elapsed_time(e1)*1e3:.1f} us, last end {end.max():.1f} us')
     q = lambda v: f'min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}'
     print('  start    ', q(st)); print('  prologue ', q(pro)); print('  k-loop   ', q(loop)); print('  epilogue ', q(epi)); print('  end      ', q(end))
+    if (a[:, 6] > a[:, 0]).all() and (a[:, 7] >= a[:, 6]).all() and (a[:, 1] >= a[:, 7]).all():
+        # round 5: entry -> descriptor + addresses ready (6) -> every prologue DMA issued (7) -> tile 0 published (1)
+        print('  prologue: entry -> first DMA issue', q(us(a[:, 6] - a[:, 0])))
+        print('            issue of the NB tiles   ', q(us(a[:, 7] - a[:, 6])))
+        print('            issued -> tile 0 visible', q(us(a[:, 1] - a[:, 7])))
     for pi in sorted(set(a[:, 4] // 1000)):
         m = a[:, 4] // 1000 == pi
         nk = a[m, 4] % 1000
