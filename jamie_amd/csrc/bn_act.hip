@@ -503,6 +503,9 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, flo
     for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
+#ifdef JAMIE_BN_STRIPMAJOR_TIMING      // TIMING EXPERIMENT ONLY (wrong results): see bn_fwd_strip.h
+        if (row < B && cok) roff[j] = ((unsigned)(col0 / (4 * CQ)) * (unsigned)B + (unsigned)row) * (16u * CQ) + (unsigned)cq * 16u;
+#endif
     }
     float4 dyv[R], xnv[R];
 #pragma unroll

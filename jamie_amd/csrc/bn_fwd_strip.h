@@ -145,6 +145,12 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
         roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
+#ifdef JAMIE_BN_STRIPMAJOR_TIMING
+        // TIMING EXPERIMENT ONLY (wrong results): the strip's rows as ONE contiguous block (what a strip-major slab layout
+        // [strip][row][4 CQ columns] would give this workgroup: 512 x 64 / 128 contiguous bytes per slab instead of 512 segments
+        // 4 N bytes apart) -- same bytes, each read once
+        if (row < B && cok) roff[j] = ((unsigned)(col0 / (4 * CQ)) * (unsigned)B + (unsigned)row) * (16u * CQ) + (unsigned)cq * 16u;
+#endif
     }
     // latency order: parameter loads and the first slabs are issued first; the Philox keep words (pure VALU,
     // ~100 instructions per call) are computed while those loads are in flight (they cost 3.7 us per launch when they
@@ -247,7 +253,11 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
         const int row = rp + j * BN4_RP;
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < B && cok) {
+#ifdef JAMIE_BN_STRIPMAJOR_TIMING
+            const long long o = (long long)(roff[j] >> 2);
+#else
             const long long o = (long long)row * N + col;
+#endif
             if (nslab > 1) {      // (the summed pre-activation: next read by the backward pass, stored non-temporally)
                 __builtin_nontemporal_store(v[j].x, P.h + o); __builtin_nontemporal_store(v[j].y, P.h + o + 1);
                 __builtin_nontemporal_store(v[j].z, P.h + o + 2); __builtin_nontemporal_store(v[j].w, P.h + o + 3);

@@ -98,9 +98,21 @@ extern "C" int jamie_comm_create(const void* id128 /*host*/, int rank, int world
     memcpy(&id, id128, sizeof(id));
     const jc_result_t r = g_api.CommInitRank(&c->comm, world, id, rank);
     if (r != 0) { delete c; return jc_fail("jamie_comm_create", r); }
-    JC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    JC_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-    for (int i = 0; i < JC_SLOTS; ++i) JC_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+    // a failure from here on must not leak the communicator (RCCL holds device buffers and proxy threads for it), the stream or
+    // the events made so far: everything is torn down again before the error goes back
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+    for (int i = 0; i < JC_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        snprintf(g_jamie_err, sizeof(g_jamie_err), "jamie_comm_create: %s", hipGetErrorString(e));
+        if (g_api.CommDestroy) g_api.CommDestroy(c->comm);
+        for (int i = 0; i < JC_SLOTS; ++i)
+            if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+        if (c->ready) (void)hipEventDestroy(c->ready);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return (int)e;
+    }
     *comm_out = c;
     return 0;
 }
@@ -108,11 +120,11 @@ extern "C" int jamie_comm_create(const void* id128 /*host*/, int rank, int world
 extern "C" int jamie_comm_destroy(void* comm) {
     JamieComm* c = (JamieComm*)comm;
     if (!c) return 0;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     if (g_api.CommDestroy) g_api.CommDestroy(c->comm);
-    for (int i = 0; i < JC_SLOTS; ++i) hipEventDestroy(c->done[i]);
-    hipEventDestroy(c->ready);
-    hipStreamDestroy(c->stream);
+    for (int i = 0; i < JC_SLOTS; ++i) (void)hipEventDestroy(c->done[i]);
+    (void)hipEventDestroy(c->ready);
+    (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }

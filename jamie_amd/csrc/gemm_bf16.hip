@@ -76,6 +76,14 @@ __device__ __attribute__((aligned(16))) unsigned int jb_zero16[4];      // what 
 // (profiles/r04_stamps_probe*.log; the .s of round 3's kernel shows the wait right behind the four global_load_lds).  The asm is
 // invisible to that pass; the reads are ordered by the hand-written `s_waitcnt lgkmcnt(0)` in front of the MFMAs that use them
 // (jb_lds_wait, followed by a sched_barrier: cdna_hip_programming.md 5.4 rule 18).
+// What the asm form owes the compiler in return (cdna_hip_programming.md 5.7 item 1, form (ii)): hipcc holds an asm
+// read's destination to be written when the statement ends, so NOTHING may touch a destination between the read and the wait
+// -- not the 64 -> 128-bit concatenation into an MFMA operand either (a v_mov the register allocator might emit for it would copy
+// stale registers: no hardware interlock).  The two 64-bit halves of a fragment therefore stay separate values until the wait:
+// jb_lds_wait_for() is the `s_waitcnt lgkmcnt(0)` and names every half it retires as a read-write operand ("+v"), so each
+// consumer -- the concatenation, then the MFMA -- is data-dependent on the wait statement.  tests/test_isa_hazards.py
+// disassembles the product object and fails if any instruction reads or writes a destination of a transposed read before
+// the wait that follows it.
 typedef short jb_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ jb_s16x4 jb_ds_read_tr16(const unsigned char* p) {
     typedef const unsigned char __attribute__((address_space(3)))* lp_t;
@@ -85,6 +93,9 @@ __device__ __forceinline__ jb_s16x4 jb_ds_read_tr16(const unsigned char* p) {
     return v;
 }
 __device__ __forceinline__ void jb_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the wait + "these registers are only valid from here on" (asm volatile statements keep their order among themselves)
+__device__ __forceinline__ void jb_lds_wait_for(jb_s16x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
+__device__ __forceinline__ void jb_after_wait(jb_s16x4& a) { asm volatile("" : "+v"(a)); }
 // Measured and rejected in round 3 (the A/B builds are gone; logs in profiles/): non-temporal LDS-DMA of the weights operand
 // (r03_ab_nt_weights_rejected.log: forward launches 7 % faster, the step 18-45 us slower: the backward pass finds the weights in
 // the Infinity Cache), issue priority for the long tiles of a grouped launch (r03_ab_long_tile_priority_rejected.log), write-through
@@ -693,6 +704,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
 
     const int swz = (r >> 1) & 7;
     bf16x8 af[2][TM], bf[2][TN];
+    s16x4 afl[2][TM], afh[2][TM], bfl[2][TN], bfh[2][TN];      // k-row-major operands: the halves of a fragment as the asm reads wrote them
     // transposed read of the [k][n] image: in a 16-lane group lane 4q+p supplies row q, columns 4p..4p+3 of a 4 x 16
     // block and lane i receives column i of the 4 rows; lane (n = lane & 31, kh = lane >> 5) of the MFMA operand needs
     // k = 16 s + 8 kh + 0..7 of column n: two reads (k-rows +0..3, +4..7).  Row 16 s + 8 kh + 4 t + q has row & 3 = q
@@ -710,9 +722,8 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                 const unsigned char* base = As + s * (16 * BM * 2) + 8 * (tp & 1);
                 const int o0 = (8 * h + tq) * (BM * 2) + ((ch ^ ((tq << 2) | ((2 * h) & 3))) << 4);
                 const int o1 = (8 * h + 4 + tq) * (BM * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
-                const s16x4 lo = jb_ds_read_tr16(base + o0);
-                const s16x4 hi = jb_ds_read_tr16(base + o1);
-                af[fb][i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                afl[fb][i] = jb_ds_read_tr16(base + o0);          // (concatenated behind the wait: take_frags)
+                afh[fb][i] = jb_ds_read_tr16(base + o1);
             }
         } else {
 #pragma unroll
@@ -728,10 +739,8 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                 const unsigned char* base = Bs + s * (16 * BN * 2) + 8 * (tp & 1);
                 const int o0 = (8 * h + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h) & 3))) << 4);
                 const int o1 = (8 * h + 4 + tq) * (BN * 2) + ((ch ^ ((tq << 2) | ((2 * h + 1) & 3))) << 4);
-                const s16x4 lo = jb_ds_read_tr16(base + o0);
-                const s16x4 hi = jb_ds_read_tr16(base + o1);
-                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                bf[fb][j] = __builtin_bit_cast(bf16x8, both);
+                bfl[fb][j] = jb_ds_read_tr16(base + o0);
+                bfh[fb][j] = jb_ds_read_tr16(base + o1);
             }
         } else {
 #pragma unroll
@@ -740,6 +749,28 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
         }
     };
 
+    // the hand-written wait for the asm reads of fragment set `fb`, naming every half it retires, then their concatenation into
+    // the MFMA operands (see jb_ds_read_tr16)
+    auto take_frags = [&](int fb, auto tr, auto tra) {
+        if constexpr (decltype(tr)::value) {
+            jb_lds_wait_for(bfl[fb][0]);
+            jb_after_wait(bfh[fb][0]);
+#pragma unroll
+            for (int j = 1; j < TN; ++j) { jb_after_wait(bfl[fb][j]); jb_after_wait(bfh[fb][j]); }
+            if constexpr (decltype(tra)::value) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { jb_after_wait(afl[fb][i]); jb_after_wait(afh[fb][i]); }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[fb][j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bfl[fb][j], bfh[fb][j], 0, 1, 2, 3, 4, 5, 6, 7));
+            if constexpr (decltype(tra)::value) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[fb][i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(afl[fb][i], afh[fb][i], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+    };
     // prologue: every buffer in flight, then tile 0 published and its first fragments read
     if constexpr (!FUSE) JB_STAMP(6);
 #ifdef JB_PRO_BARRIER
@@ -764,6 +795,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     __builtin_amdgcn_s_barrier();
     JB_STAMP(1);
     auto k_loop = [&](auto tr, auto tra) {
+    if (nk <= 0) return;        // (an empty K slice stores zeros; no asm read may be left pending into the epilogue: tools/isa_check.py)
     read_frags(smem, 0, 0, tr, tra);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -774,7 +806,7 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
             // hipcc waits lgkmcnt(0) (not a counted wait) before the first MFMA of a sub-step while LDS-DMA is
             // pending, so the prefetch of the next fragments is issued AFTER that MFMA: the wait then only covers
             // reads that have had a whole sub-step to land
-            if constexpr (decltype(tr)::value) jb_lds_wait();        // (the asm transposed reads: no compiler-side tracking)
+            take_frags(s & 1, tr, tra);        // (the asm transposed reads: no compiler-side tracking -- wait + concatenate)
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s & 1][0], af[s & 1][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -805,6 +837,10 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     if (a_tr) k_loop(std::true_type{}, std::true_type{});            // dW on the row-major activations / gradients
     else if (b_tr) k_loop(std::true_type{}, std::false_type{});      // dX on the weights as stored
     else k_loop(std::false_type{}, std::false_type{});
+    // every asm read retired before the epilogue reuses a register (the loop's exit branch sits BEHIND the next tile's first reads
+    // in program order: on that -- infeasible -- path hipcc knows of nothing pending; tools/isa_check.py walks it)
+    jb_lds_wait();
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     JB_STAMP(2);
 
@@ -872,7 +908,14 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
                         auto bfr = [](float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); };
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         u32x2 pk; pk.x = bfr(v0) | (bfr(v1) << 16); pk.y = bfr(v2) | (bfr(v3) << 16);
+#ifdef JAMIE_STORE_SOFF       // (A/B: round 4's form, the row offset as the store's SCALAR offset)
                         __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, (int)vo, (int)so, NT_ST ? 2 : 0);
+#else
+                        // the row offset in the VECTOR offset for the 8-byte stores too (round 5): the ISA holds stores of <= 64 bits
+                        // free of the store-data hazard, but the product now contains NO buffer store with an SGPR offset at all --
+                        // what tests/test_isa_hazards.py asserts on the code objects, whatever a later toolchain schedules
+                        __builtin_amdgcn_raw_buffer_store_b64(pk, c_rs, (int)((EDGE && vo == 0xFFFFFFF0u) ? vo : vo + so), 0, NT_ST ? 2 : 0);
+#endif
                     } else {
                         // (the row offset in the VECTOR offset here: a 16-byte buffer store with a scalar-register offset had its data
                         //  registers overwritten under it -- wrong .y elements in fixed lanes, tools/debug_bf16_epilogue.py; hipcc's

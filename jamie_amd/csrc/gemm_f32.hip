@@ -518,7 +518,12 @@ void gemm_f32_kernel(GemmGroup g) {
                         }
                         unsigned vo = voff;
                         if (EDGE) vo = (mrow + rel < P.M) ? voff : JAMIE_OOB;
+#ifdef JAMIE_STORE_SOFF       // (A/B: round 4's form, the row offset as the store's SCALAR offset)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rs, (int)vo, (int)((unsigned)rel * ldc4), NT_ST ? 2 : 0);
+#else
+                        // (row offset in the VECTOR offset: no buffer store with an SGPR offset anywhere in the product, see gemm_bf16.hip)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rs, (int)((EDGE && vo == JAMIE_OOB) ? vo : vo + (unsigned)rel * ldc4), 0, NT_ST ? 2 : 0);
+#endif
                         if (!EVAL_BN) {
                             if (EDGE) local += (vo != JAMIE_OOB) ? v * v : 0.f;
                             else local += v * v;                  // (interior tiles: every element counts)
@@ -855,8 +860,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_dma_kernel(GemmGroup g)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// `solo_lds` > 0: that many bytes of dynamic LDS on top of the kernel's own, so that only ONE workgroup fits a CU (configuration
+// 19: the forward launches that run beside the optimiser stream leave half of each CU's wave slots to clip + Adam -- one workgroup
+// alone on a CU keeps 0.86 of the pair's MFMA rate, profiles/r04_stamps_f32_launches_after.log)
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool MID = false>
-static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
+static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st, int solo_lds = 0) {
     GemmGroup g;
     memset(&g, 0, sizeof(g));
     g.count = count;
@@ -901,10 +909,18 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st) {
         if (s.M <= 64 || s.N <= 64 || s.K <= 64) big = false;
     }
     if (tiles == 0) return 0;
-    if (fast && big && !tails)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 1, MID>), dim3(tiles),
-                           dim3(WM * WN * 64), 0, st, g);
-    else if (fast && !tails)
+    if (fast && big && !tails) {
+        auto kern = gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 1, MID>;
+        if (solo_lds > 0) {
+            static bool raised = false;          // (once per process: the dynamic-LDS ceiling of this instantiation)
+            if (!raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, solo_lds);
+                if (e != hipSuccess) return jamie_fail((int)e, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed [%lld %lld]", "jamie_gemm_f32", solo_lds, 0);
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), solo_lds > 0 ? solo_lds : 0, st, g);
+    } else if (fast && !tails)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 0, MID>), dim3(tiles),
                            dim3(WM * WN * 64), 0, st, g);
     else if (fast)
@@ -995,6 +1011,8 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
         case 16: return launch_cfg<128, 256, 32, 4, 4, A_KC, B_KC>(pr, count, st);    // 16 waves of 32x64
         case 17: return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC, true>(pr, count, st);   // 12 with the barrier in mid k-step
         case 18: return launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC, true>(pr, count, st);      // 1 likewise
+        // 17 with 56 KB of unused dynamic LDS: one workgroup per CU (64 + 56 KB each of 160), for launches beside the optimiser stream
+        case 19: return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC, true>(pr, count, st, 56 * 1024);
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
 }
@@ -1046,10 +1064,10 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[19][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
-                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 256}, {128, 128}, {64, 64}};
+    static const int T[20][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
+                                 {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 256}, {128, 128}, {64, 64}, {128, 128}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 18 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 19 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

@@ -42,6 +42,9 @@ TUNING = {
                                   # OFF until an N > 1 A/B shows a gain: it adds a launch to the tail of the backward pass and turns
                                   # the merged rep + enc0 message into three all-reduces (~28 us of host enqueue each); bench.py
                                   # --tune split_last_dw=True is the A/B for the first multi-GPU box
+    'f32_pipe_solo': 'enc0,enc1',  # fp32, pipelined optimiser: the forward launches of these layers run beside clip + Adam on the optimiser
+                                  # stream and take tile configuration 19 (= 17 at ONE workgroup per CU: half of each CU's wave slots
+                                  # stay free for the streaming kernel); '' = off
     'f32_dw_group': 4,            # fp32, no gradient exchange: the large layers' dW products wait and go out `n` layers per launch
                                   # (4 layers = 2560 tiles of 128 x 128 = 5.0 rounds of 512 slots; one layer = 1.25 rounds); 1: off
 }
@@ -130,6 +133,7 @@ F32_CFG_DW = 17             # fp32 dW (TN, K = batch) of the large layers when t
                             # exchange): the mid-barrier 128x128 tile (round 2's sweep had 64x64, configuration 1; with round 4's loop
                             # config 5's dimensions run 6.86 against 6.97 ms per step, config 2 the same: r04_f32_dp_dw_tile.log)
 F32_CFG_DW_FUSED = 17       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
+F32_CFG_SOLO = 19           # 17 with 56 KB of unused dynamic LDS: one workgroup per CU (forward launches beside the optimiser stream)
 
 
 def _f32_fused_cfg():
@@ -849,6 +853,8 @@ class TrainEngine:
                                          splitk=w['sk'][sk_key], slab_stride=self.B * nout))
         cfg = self.gcfg.get(sk_key, -1)
         fcfg = self.fcfg.get(sk_key, -1)
+        if (not self.bf16 and self.pipeline and fcfg == F32_CFG_ROWS and lin in str(TUNING['f32_pipe_solo']).split(',')):
+            fcfg = F32_CFG_SOLO           # (same tile, same K slices, same sums: one workgroup per CU while clip + Adam streams beside it)
         self._wait_params(lin)
         # 'enc_gemm': every large forward launch; 'enc0_gemm': the encoder's first Linear alone (model.py:151, d -> 2d, both
         # modalities: the matmul north_star's roofline target names; bench.py's roofline.encoder_gemm)
