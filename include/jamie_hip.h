@@ -85,7 +85,14 @@ typedef struct {
                                  * bf16 [M, ldc] and the fp32 accumulators are rounded once on the way out (`partial` still sums
                                  * the squares of the fp32 values).  The weight gradients of the bf16 compute mode: 2 instead of 4
                                  * bytes per parameter written here and read again by jamie_clip_adam_g16 */
+    int c_panel;                /* jamie_gemm_bf16, large-tile configurations, fp32 EPI_STORE without accumulate: every slab of C is
+                                 * written in PANELS of JAMIE_PANEL (16) columns -- element (m, n) at ((n / 16) * M + m) * 16 + n % 16
+                                 * of its slab, slab_stride >= ceil(N / 16) * 16 * M, ldc ignored -- the layout the BatchNorm launches
+                                 * read (`panel` below): the 16-column strip a BatchNorm workgroup owns is then ONE contiguous block of
+                                 * M x 64 bytes per slab instead of M segments 4 N bytes apart (round 5: the pre-activations of
+                                 * model.py:151-154 etc. go GEMM -> BatchNorm -> BatchNorm backward in this layout) */
 } jamie_gemm_problem;
+#define JAMIE_PANEL 16
 
 /* One launch computing up to JAMIE_MAX_GEMM_GROUP independent problems (the modalities of one layer; dX and dW together). */
 int jamie_gemm_f32(const jamie_gemm_problem* problems /*host*/, int count, int layout, void* stream);
@@ -150,6 +157,9 @@ typedef struct {
     int B, N; int rng_stream;
     void* out_bf16;                                  /* optional bf16 [B,N] copy of `out` (out may be NULL) */
     void* outT_bf16;                                 /* optional bf16 transposed [N,B] copy (B <= 512, B % 8 == 0) */
+    int panel;                                       /* 1: `h` (every slab, and the sum written back to slab 0) is in panels of
+                                                      * JAMIE_PANEL columns (jamie_gemm_problem.c_panel); float4 kernels only
+                                                      * (B <= 1024, N % 4 == 0); `out` / the bf16 copies / `mask` stay row-major */
 } jamie_bnact_fwd_problem;
 
 int jamie_bn_act_fwd(const jamie_bnact_fwd_problem* problems /*host*/, int count, float p_drop,
@@ -172,6 +182,8 @@ typedef struct {
     int B, N; int rng_stream; int accumulate;        /* accumulate: d{gamma,beta,bias} += */
     void* dh_bf16; void* dhT_bf16;                   /* optional bf16 [B,N] / transposed [N,B] copies of dh */
     int skip_f32;                                    /* 1: do not write the fp32 dh (bf16 copies only)     */
+    int panel;                                       /* 1: `da` (every slab) and `h` are in panels of JAMIE_PANEL columns; needs
+                                                      * skip_f32 (dh leaves as bf16 row-major only); float4 kernels only */
 } jamie_bnact_bwd_problem;
 
 int jamie_bn_act_bwd(const jamie_bnact_bwd_problem* problems /*host*/, int count, float p_drop,
@@ -269,6 +281,8 @@ typedef struct {
      * W_dec0 [d[i], L], written by the workgroups that stage the weight chunks anyway; what jamie_gemm_bf16_skinny multiplies
      * d g1 by for the decoder-layer-0 input gradient (d[i] a multiple of 8).  NULL: not written. */
     void* dec0_WT_bf16[4];
+    int g1_panel, da2_panel;    /* 1: g1[i] / da2[i] are written in panels of JAMIE_PANEL columns (see jamie_gemm_problem.c_panel):
+                                 * what the BatchNorm launches that consume them read when their `panel` is set */
 } jamie_latent_m;
 /* What a riding sampler draws: idx[B] = jamie_sample_indices(B, N, offset, replace, {seed, step + step_add}, rng_stream)
  * (np.random.choice of jamie/jamie.py:556).  step_add = 1 in a launch that runs before the norm kernel has advanced the step. */

@@ -30,7 +30,7 @@ class GemmProblem(C.Structure):
                 ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('aux_ld', C.c_int),
                 ('splitk', C.c_int), ('slab_stride', C.c_longlong),
                 ('epi', C.c_int), ('accumulate', C.c_int),
-                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float), ('b_tr', C.c_int), ('a_tr', C.c_int), ('store_nt', C.c_int), ('c_bf16', C.c_int)]
+                ('scale', C.c_float), ('slope', C.c_float), ('eps', C.c_float), ('pscale', C.c_float), ('b_tr', C.c_int), ('a_tr', C.c_int), ('store_nt', C.c_int), ('c_bf16', C.c_int), ('c_panel', C.c_int)]
 
 
 class CastProblem(C.Structure):
@@ -58,7 +58,7 @@ class BnFwdProblem(C.Structure):
                 ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p),
                 ('out', C.c_void_p), ('mask', C.c_void_p),
                 ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int),
-                ('out_bf16', C.c_void_p), ('outT_bf16', C.c_void_p)]
+                ('out_bf16', C.c_void_p), ('outT_bf16', C.c_void_p), ('panel', C.c_int)]
 
 
 class BnBwdProblem(C.Structure):
@@ -68,7 +68,7 @@ class BnBwdProblem(C.Structure):
                 ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dbias_lin', C.c_void_p),
                 ('mask', C.c_void_p),
                 ('B', C.c_int), ('N', C.c_int), ('rng_stream', C.c_int), ('accumulate', C.c_int),
-                ('dh_bf16', C.c_void_p), ('dhT_bf16', C.c_void_p), ('skip_f32', C.c_int)]
+                ('dh_bf16', C.c_void_p), ('dhT_bf16', C.c_void_p), ('skip_f32', C.c_int), ('panel', C.c_int)]
 
 
 class Latent(C.Structure):
@@ -104,7 +104,8 @@ class LatentM(C.Structure):
                 ('comb_alias', C.c_void_p * 4), ('comb_bf16', C.c_void_p * 4), ('combT_bf16', C.c_void_p * 4),
                 ('dml_bf16', C.c_void_p * 4), ('dmlT_bf16', C.c_void_p * 4),
                 ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p),
-                ('defer_final', C.c_int), ('head_W', C.c_void_p * 4), ('da2', C.c_void_p * 4), ('dec0_WT_bf16', C.c_void_p * 4)]
+                ('defer_final', C.c_int), ('head_W', C.c_void_p * 4), ('da2', C.c_void_p * 4), ('dec0_WT_bf16', C.c_void_p * 4),
+                ('g1_panel', C.c_int), ('da2_panel', C.c_int)]
 
 
 class SampleArgs(C.Structure):
@@ -342,9 +343,9 @@ def require_gpu():
 # ---------------------------------------------------------------------------------------------------
 def gemm_problem(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, splitk=1, slab_stride=0, epi=EPI_STORE,
                  accumulate=False, aux=(None, None, None, None), aux_ld=0, partial=None, a_rows=None,
-                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0, b_tr=False, a_tr=False, store_nt=False, c_bf16=False):
+                 scale=1.0, slope=0.01, eps=1e-5, pscale=1.0, b_tr=False, a_tr=False, store_nt=False, c_bf16=False, c_panel=False):
     p = GemmProblem()
-    p.b_tr, p.a_tr, p.store_nt, p.c_bf16 = int(b_tr), int(a_tr), int(store_nt), int(c_bf16)
+    p.b_tr, p.a_tr, p.store_nt, p.c_bf16, p.c_panel = int(b_tr), int(a_tr), int(store_nt), int(c_bf16), int(c_panel)
     p.A, p.B, p.C, p.bias = ptr(A), ptr(B), ptr(Cout), ptr(bias)
     p.aux0, p.aux1, p.aux2, p.aux3 = (ptr(a) for a in aux)
     p.partial, p.a_rows = ptr(partial), ptr(a_rows)

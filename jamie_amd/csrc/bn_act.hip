@@ -49,6 +49,7 @@ struct BnBwdDev {
     unsigned short* dh_bf; unsigned short* dhT_bf;
     long long slab_stride;
     int nslab, B, N, rng_stream, accumulate, blk_begin, skip_f32;
+    int panel;           // da (every slab) and h in panels of 16 columns (bn_fwd_strip.h); dh leaves as bf16 row-major only
 };
 struct BnBwdGroup { BnBwdDev p[JAMIE_MAX_GROUP]; int count; };
 
@@ -493,19 +494,20 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, flo
     const bool drop = p_drop > 0.f;
     const float keep_scale = drop ? 1.f / (1.f - p_drop) : 1.f;
     const uint32_t thr = drop_threshold16(p_drop);
-    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    // panel layout of the two fp32 inputs (bn_fwd_strip.h): this strip's rows are one contiguous block of each
+    const bool pan = P.panel != 0;
+    const unsigned row_bytes = pan ? 64u : (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const unsigned one_slab = pan ? (unsigned)((N + 15) >> 4) * (unsigned)B * 64u : (unsigned)B * (unsigned)N * 4u;
     const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)P.da, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)((unsigned)B * row_bytes), 0x00020000);
+        (void*)P.da, 0, (int)((unsigned)(nslab - 1) * slab_bytes + one_slab), 0x00020000);
+    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)one_slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
+    const unsigned coff = pan ? (unsigned)(col >> 4) * ((unsigned)B * 64u) + (unsigned)(col & 15) * 4u : (unsigned)col * 4u;
     unsigned roff[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
-        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
-#ifdef JAMIE_BN_STRIPMAJOR_TIMING      // TIMING EXPERIMENT ONLY (wrong results): see bn_fwd_strip.h
-        if (row < B && cok) roff[j] = ((unsigned)(col0 / (4 * CQ)) * (unsigned)B + (unsigned)row) * (16u * CQ) + (unsigned)cq * 16u;
-#endif
+        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + coff : BN_OOB;
     }
     float4 dyv[R], xnv[R];
 #pragma unroll
@@ -515,7 +517,8 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, flo
     unsigned mk[R];
     if (drop && P.mask) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+        for (int j = 0; j < R; ++j)       // (explicit masks: row-major [B, N] bytes)
+            mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : (unsigned)(rp + j * BN4_RP) * (unsigned)N + (unsigned)col);
     }
     unsigned keepbits = 0xFFFFFFFFu;              // Philox keep words under the loads in flight (see the forward kernel)
     if (drop) {
@@ -662,7 +665,7 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     memset(&g, 0, sizeof(g));
     g.count = count;
     int blocks = 0, maxB = 0;
-    bool need_rng = false, wide = true, any_bf = false;
+    bool need_rng = false, wide = true, any_bf = false, any_panel = false;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_fwd_problem& s = pr[i];
         JAMIE_ARG(s.h && s.gamma && s.beta && s.running_mean && s.running_var && s.save_mean && s.save_invstd,
@@ -680,6 +683,13 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
         if (s.out_bf16 || s.outT_bf16) any_bf = true;
         JAMIE_ARG(s.out || s.out_bf16 || s.outT_bf16, "no output requested");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
+        d.panel = s.panel ? 1 : 0;
+        if (s.panel) {
+            any_panel = true;
+            const long long one = (long long)((s.N + 15) / 16) * 16 * s.B;          // floats of one slab in panels
+            JAMIE_ARG(s.nslab == 1 || s.slab_stride >= one, "panel layout: slab_stride >= ceil(N / 16) * 16 * B");
+            JAMIE_ARG(((long long)(s.nslab - 1) * s.slab_stride + one) * 4 < 0xFFFFFFF0LL, "activation slabs must stay below 4 GiB");
+        }
         d.blk_begin = blocks;
         blocks += 8 * (((s.N + BN_CW - 1) / BN_CW + 7) / 8);
         if (s.B > maxB) maxB = s.B;
@@ -691,6 +701,7 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
+    JAMIE_ARG(!any_panel || (wide && maxB <= 8 * BN4_RP), "panel layout: float4 kernels only (N % 4 == 0, aligned, B <= 1024)");
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].outT_bf16 != nullptr;
@@ -754,7 +765,7 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     memset(&g, 0, sizeof(g));
     g.count = count;
     int blocks = 0, maxB = 0;
-    bool need_rng = false, wide = true, any_bf = false;
+    bool need_rng = false, wide = true, any_bf = false, any_panel = false;
     for (int i = 0; i < count; ++i) {
         const jamie_bnact_bwd_problem& s = pr[i];
         JAMIE_ARG(s.da && s.h && s.gamma && s.beta && s.save_mean && s.save_invstd && s.dgamma && s.dbeta,
@@ -773,6 +784,14 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
         JAMIE_ARG(!s.skip_f32 || s.dh_bf16 || s.dhT_bf16, "skip_f32 without a bf16 output");
         d.slab_stride = s.slab_stride; d.nslab = s.nslab; d.B = s.B; d.N = s.N; d.rng_stream = s.rng_stream;
         d.accumulate = s.accumulate; d.blk_begin = blocks;
+        d.panel = s.panel ? 1 : 0;
+        if (s.panel) {
+            any_panel = true;
+            const long long one = (long long)((s.N + 15) / 16) * 16 * s.B;
+            JAMIE_ARG(s.skip_f32, "panel layout: dh leaves as bf16 only (skip_f32)");
+            JAMIE_ARG(s.nslab == 1 || s.slab_stride >= one, "panel layout: slab_stride >= ceil(N / 16) * 16 * B");
+            JAMIE_ARG(((long long)(s.nslab - 1) * s.slab_stride + one) * 4 < 0xFFFFFFF0LL, "activation slabs must stay below 4 GiB");
+        }
         blocks += 8 * (((s.N + BN_CW - 1) / BN_CW + 7) / 8);
         if (s.B > maxB) maxB = s.B;
         if (!s.mask && p_drop > 0.f) need_rng = true;
@@ -783,6 +802,7 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     JAMIE_ARG(!need_rng || rng != nullptr, "rng state required when no explicit mask is given");
     hipStream_t st = (hipStream_t)stream;
     JAMIE_ARG(!any_bf || maxB <= BN_MAXR * BN_RP || wide, "fused bf16 outputs with 512 < B <= 1024 need the float4 path (N % 4 == 0, aligned)");
+    JAMIE_ARG(!any_panel || (wide && maxB <= 8 * BN4_RP), "panel layout: float4 kernels only (N % 4 == 0, aligned, B <= 1024)");
     ColsumGroup cs;
     memset(&cs, 0, sizeof(cs));
     int cs_blocks = 0;

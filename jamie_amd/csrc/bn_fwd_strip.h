@@ -23,6 +23,7 @@ struct BnFwdDev {
     unsigned short* out_bf; unsigned short* outT_bf;
     long long slab_stride;
     int nslab, B, N, rng_stream, blk_begin;
+    int panel;           // h (every slab, and the sum written back) in panels of 16 columns: (row, col) at ((col / 16) * B + row) * 16 + col % 16
 };
 
 // Keep decision of element (row, col): 16 random bits against a 16-bit threshold.  One Philox call serves the 4
@@ -136,21 +137,22 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     BN_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));
     BN_STAMPV(6, P.N * 10 + P.nslab);
     const int B = P.B, N = P.N, nslab = P.nslab;
-    const unsigned row_bytes = (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    // panel layout (round 5; jamie_hip.h: JAMIE_PANEL): the 16 columns of a panel are contiguous for every row, the panels of a
+    // slab follow one another -- this strip's rows are ONE block of B x 64 bytes per slab (two for a 32-column strip) instead of
+    // B segments 4 N bytes apart: the slab loads, the statistics' only input, arrive 1.5-2 us earlier per launch
+    // (profiles/r05_ab_bn_panel_timing.log)
+    const bool pan = P.panel != 0;
+    const unsigned row_bytes = pan ? 64u : (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const unsigned one_slab = pan ? (unsigned)((N + 15) >> 4) * (unsigned)B * 64u : (unsigned)B * (unsigned)N * 4u;
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)P.h, 0, (int)((unsigned)(nslab - 1) * slab_bytes + (unsigned)B * row_bytes), 0x00020000);
+        (void*)P.h, 0, (int)((unsigned)(nslab - 1) * slab_bytes + one_slab), 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
+    const unsigned coff = pan ? (unsigned)(col >> 4) * ((unsigned)B * 64u) + (unsigned)(col & 15) * 4u : (unsigned)col * 4u;
     unsigned roff[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int row = rp + j * BN4_RP;
-        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + (unsigned)col * 4u : BN_OOB;
-#ifdef JAMIE_BN_STRIPMAJOR_TIMING
-        // TIMING EXPERIMENT ONLY (wrong results): the strip's rows as ONE contiguous block (what a strip-major slab layout
-        // [strip][row][4 CQ columns] would give this workgroup: 512 x 64 / 128 contiguous bytes per slab instead of 512 segments
-        // 4 N bytes apart) -- same bytes, each read once
-        if (row < B && cok) roff[j] = ((unsigned)(col0 / (4 * CQ)) * (unsigned)B + (unsigned)row) * (16u * CQ) + (unsigned)cq * 16u;
-#endif
+        roff[j] = (row < B && cok) ? (unsigned)row * row_bytes + coff : BN_OOB;
     }
     // latency order: parameter loads and the first slabs are issued first; the Philox keep words (pure VALU,
     // ~100 instructions per call) are computed while those loads are in flight (they cost 3.7 us per launch when they
@@ -170,7 +172,8 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     unsigned mk[R];
     if (drop && P.mask) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : roff[j] >> 2);
+        for (int j = 0; j < R; ++j)       // (the explicit masks of the parity tests are row-major [B, N] bytes)
+            mk[j] = buf_u32(m_rs, roff[j] == BN_OOB ? BN_OOB : (unsigned)(rp + j * BN4_RP) * (unsigned)N + (unsigned)col);
     }
     float4 v[R];
 #pragma unroll
@@ -253,14 +256,11 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
         const int row = rp + j * BN4_RP;
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < B && cok) {
-#ifdef JAMIE_BN_STRIPMAJOR_TIMING
-            const long long o = (long long)(roff[j] >> 2);
-#else
             const long long o = (long long)row * N + col;
-#endif
             if (nslab > 1) {      // (the summed pre-activation: next read by the backward pass, stored non-temporally)
-                __builtin_nontemporal_store(v[j].x, P.h + o); __builtin_nontemporal_store(v[j].y, P.h + o + 1);
-                __builtin_nontemporal_store(v[j].z, P.h + o + 2); __builtin_nontemporal_store(v[j].w, P.h + o + 3);
+                float* hp = P.h + (pan ? (long long)(roff[j] >> 2) : o);
+                __builtin_nontemporal_store(v[j].x, hp); __builtin_nontemporal_store(v[j].y, hp + 1);
+                __builtin_nontemporal_store(v[j].z, hp + 2); __builtin_nontemporal_store(v[j].w, hp + 3);
             }
             const float hv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
             const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};

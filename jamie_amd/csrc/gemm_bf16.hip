@@ -43,6 +43,7 @@ struct GemmBDev {
     int a_tr;            // A is [K, M] row-major (M contiguous), likewise (dW = dy^T a reads dy [B, out] and a [B, in])
     int store_nt;        // non-temporal output stores (weight gradients: next read by the optimiser, a whole backward pass later)
     int c_bf16;          // C is bf16 [M, ldc]: the fp32 accumulators are rounded once on the way out (weight gradients)
+    int c_panel;         // fp32 C in panels of 16 columns: (m, n) at ((n / 16) * M + m) * 16 + n % 16 (what the BatchNorm launches read)
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -876,13 +877,18 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     // (~30 instructions and 6 branches each, 64-bit address arithmetic); here a piece is its bias add, (sum of squares,) pack and ONE
     // buffer store whose row offset is scalar -- the tile's CU slot is free again that much earlier (gemm_f32.hip, round 4).
     const unsigned c_elem = P.c_bf16 ? 2u : 4u;
-    const unsigned long long c_ext = ((unsigned long long)(P.M - 1) * (unsigned long long)P.ldc + (unsigned long long)P.N) * c_elem;
+    // panel layout (c_panel; fp32 only, host-checked): a row of a 16-column panel is 64 bytes and the panels of a slab follow one
+    // another M x 64 bytes apart -- the row pitch and the column term of the offset change, nothing else does
+    const bool pan = !FUSE && P.c_panel != 0;
+    const unsigned long long c_ext = pan ? (unsigned long long)((P.N + 15) >> 4) * (unsigned long long)P.M * 64ull
+                                         : ((unsigned long long)(P.M - 1) * (unsigned long long)P.ldc + (unsigned long long)P.N) * c_elem;
     if (!FUSE && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.vec && (P.N & 3) == 0 && c_ext < 0xFFFFFFF0ull) {
         const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cout, 0, (int)(unsigned)c_ext, 0x00020000);
-        const unsigned ldcb = (unsigned)P.ldc * c_elem;
+        const unsigned ldcb = pan ? 64u : (unsigned)P.ldc * c_elem;
+        const unsigned coff = pan ? (unsigned)(nc >> 4) * ((unsigned)P.M * 64u) + (unsigned)(nc & 15) * 4u : (unsigned)nc * c_elem;
         // (columns beyond N: an out-of-range offset from the start -- N % 4 == 0, a 16-byte piece is in or out whole; rows beyond M:
         //  a select per piece, in the edge tiles' instance only.  The edge tiles matter: in a one-round launch the slowest tile ends it.)
-        const unsigned voff = nc < P.N ? (unsigned)(m0 + wm0 + rsub) * ldcb + (unsigned)nc * c_elem : 0xFFFFFFF0u;
+        const unsigned voff = nc < P.N ? (unsigned)(m0 + wm0 + rsub) * ldcb + coff : 0xFFFFFFF0u;
         const bool edge_m = m0 + BM > P.M || n0 + BN > P.N;       // (an edge tile of either kind)
         auto emit = [&](auto bf_c, auto nt_c, auto edge_c) {
             constexpr bool C16 = decltype(bf_c)::value, NT_ST = decltype(nt_c)::value, EDGE = decltype(edge_c)::value;
@@ -1123,6 +1129,7 @@ static int launch_b(const jamie_gemm_problem* pr, int count, hipStream_t st) {
     bool big = true;
     for (int i = 0; i < count; ++i) {
         const jamie_gemm_problem& s = pr[i];
+        if (s.c_panel) return jamie_fail(-1, "%s: c_panel needs a large-tile configuration [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         GemmBDev& d = g.p[i];
         d.A = (const unsigned short*)s.A; d.B = (const unsigned short*)s.B; d.C = s.C; d.bias = s.bias;
         d.aux0 = s.aux0; d.partial = s.partial; d.slab_stride = s.slab_stride;
@@ -1176,7 +1183,13 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, c
         g.ntiles[i] = d.n_tiles;
         tiles += d.n_tiles;
         d.epi = s.epi; d.accumulate = s.accumulate; d.scale = s.scale; d.pscale = s.pscale;
-        d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt; d.c_bf16 = s.c_bf16;
+        d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt; d.c_bf16 = s.c_bf16; d.c_panel = s.c_panel;
+        if (s.c_panel && !(V2 && s.epi == JAMIE_EPI_STORE && !s.accumulate && !s.c_bf16 && s.N % 4 == 0 && (uintptr_t)s.C % 16 == 0 &&
+                           s.slab_stride % 4 == 0 && (!s.bias || (uintptr_t)s.bias % 16 == 0) &&
+                           (d.splitk == 1 || s.slab_stride >= (long long)((s.N + 15) / 16) * 16 * s.M) &&
+                           (long long)((s.N + 15) / 16) * s.M * 64 < 0xFFFFFFF0LL))
+            return jamie_fail(-1, "%s: c_panel needs a large-tile configuration, a plain fp32 store, N %% 4 == 0, 16-byte aligned C / bias, "
+                                  "slab_stride >= ceil(N / 16) * 16 * M [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         if (s.c_bf16 && !(V2 && s.epi == JAMIE_EPI_STORE && !s.accumulate && d.splitk == 1 && s.bias == nullptr))
             return jamie_fail(-1, "%s: c_bf16 needs a large-tile configuration, a plain store, no bias, no accumulate, splitk == 1 [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);
@@ -1195,7 +1208,7 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, c
     if constexpr (V2) {
         for (int i = 0; i < count; ++i) {
             const jamie_gemm_problem& s = pr[i];
-            g.p[i].vec = (s.ldc % 4 == 0) && ((uintptr_t)s.C % (s.c_bf16 ? 8 : 16) == 0) && (s.slab_stride % 4 == 0) &&
+            g.p[i].vec = (s.c_panel || s.ldc % 4 == 0) && ((uintptr_t)s.C % (s.c_bf16 ? 8 : 16) == 0) && (s.slab_stride % 4 == 0) &&
                          (!s.bias || (uintptr_t)s.bias % 16 == 0) &&
                          (s.epi != JAMIE_EPI_MSE || (s.aux_ld % 4 == 0 && (uintptr_t)s.aux0 % 16 == 0));
         }
@@ -1282,6 +1295,7 @@ static int launch_dma_bn(const jamie_gemm_problem* pr, const jamie_bnact_fwd_pro
         q.smean = b.save_mean; q.sinvstd = b.save_invstd; q.out = b.out; q.mask = b.mask;
         q.out_bf = (unsigned short*)b.out_bf16; q.outT_bf = nullptr;
         q.slab_stride = b.slab_stride; q.nslab = b.nslab; q.B = b.B; q.N = b.N; q.rng_stream = b.rng_stream;
+        q.panel = 0;
         f.ticket_base[i] = strips;
         strips += d.tiles_n;
         if (!b.mask && p_drop > 0.f) need_rng = true;

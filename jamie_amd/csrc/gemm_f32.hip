@@ -1034,6 +1034,7 @@ extern "C" int jamie_gemm_f32_cfg(const jamie_gemm_problem* pr, int count, int l
         const jamie_gemm_problem& s = pr[i];
         JAMIE_ARG(s.A && s.B && s.C, "null operand");
         JAMIE_ARG(s.M > 0 && s.N > 0 && s.K > 0, "empty problem");
+        JAMIE_ARG(!s.c_panel, "c_panel: jamie_gemm_bf16's large-tile configurations only");
         JAMIE_ARG(s.ldc >= s.N, "ldc < N");
         if (layout == JAMIE_NT) JAMIE_ARG(s.lda >= s.K && s.ldb >= s.K, "NT: lda/ldb < K");
         if (layout == JAMIE_NN) JAMIE_ARG(s.lda >= s.K && s.ldb >= s.N, "NN: lda < K or ldb < N");

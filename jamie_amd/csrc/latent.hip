@@ -532,6 +532,7 @@ struct LatMDev {
     const float* head_W[LM]; float* da2[LM];
     unsigned short* dec0_WT[LM];  // optional: bf16 [L, d] transposed copy of W_dec0 (written by the forward launch's row-block-0 chunks)
     int bchunk_begin[LM + 1];     // column chunks of that product (chunk 0: the owner workgroups), prefix sums
+    int g1_panel, da2_panel;      // g1 / da2 in panels of 16 columns ((b, c) at ((c / 16) * B + b) * 16 + c % 16): what BatchNorm reads
 };
 
 // ---- forward: ONE launch from the heads' split-K slabs to the decoder's first pre-activation ----
@@ -746,11 +747,13 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         }
         LSTAMP(a, 4);
         if (ocol < a.d[mi]) {
-            float* out = a.g1[mi] + ocol;
+            // (panel layout: a row of a 16-column panel is 16 floats, the panels follow one another B rows apart)
+            float* out = a.g1[mi] + (a.g1_panel ? (long long)(ocol >> 4) * B * 16 + (ocol & 15) : (long long)ocol);
+            const long long pitch = a.g1_panel ? 16 : a.d[mi];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int b = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (b < B) out[(long long)b * a.d[mi]] = acc[e] + bias;
+                if (b < B) out[(long long)b * pitch] = acc[e] + bias;
             }
         }
     }
@@ -930,11 +933,12 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
         LSTAMP(a, 13);
         const int col = c0 + wv * 32 + r;
         if (col < a.d[mi]) {
-            float* out = a.da2[mi] + col;
+            float* out = a.da2[mi] + (a.da2_panel ? (long long)(col >> 4) * B * 16 + (col & 15) : (long long)col);
+            const long long pitch = a.da2_panel ? 16 : a.d[mi];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int b = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (b < B) out[(long long)b * a.d[mi]] = acc[e];
+                if (b < B) out[(long long)b * pitch] = acc[e];
             }
         }
         LSTAMP(a, 14);
@@ -1054,6 +1058,7 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
     d.dsigma = a->dsigma; d.rec_partials = a->rec_partials; d.n_rec_partials = a->n_rec_partials;
     d.losses = a->losses; d.rng_stream = a->rng_stream;
     d.defer_final = a->defer_final;
+    d.g1_panel = a->g1_panel ? 1 : 0; d.da2_panel = a->da2_panel ? 1 : 0;
     jamie_latent_m_fill_final(a, &d.fin);
     return 0;
 }

@@ -42,6 +42,8 @@ TUNING = {
                                   # OFF until an N > 1 A/B shows a gain: it adds a launch to the tail of the backward pass and turns
                                   # the merged rep + enc0 message into three all-reduces (~28 us of host enqueue each); bench.py
                                   # --tune split_last_dw=True is the A/B for the first multi-GPU box
+    'bn_panel': True,             # bf16 mode: the fp32 pre-activations / upstream gradients travel GEMM -> BatchNorm (-> BatchNorm backward)
+                                  # in panels of 16 columns (jamie_hip.h: JAMIE_PANEL): a BatchNorm strip is one contiguous block per slab
     'f32_pipe_solo': 'enc0,enc1',  # fp32, pipelined optimiser: the forward launches of these layers run beside clip + Adam on the optimiser
                                   # stream and take tile configuration 19 (= 17 at ONE workgroup per CU: half of each CU's wave slots
                                   # stay free for the streaming kernel); '' = off
@@ -93,6 +95,8 @@ def choose_splitk(M, N, K, bm=64, bn=64):
 BF16_CFG_ROWS_WIDE, BF16_CFG_ROWS, BF16_CFG_DW = 31, 32, 29
 BF16_TILE = {23: (256, 128), 24: (128, 128), 25: (128, 128), 29: (128, 128), 30: (128, 128), 31: (256, 128), 32: (128, 128)}
 N_CU = 256
+PANEL = 16                  # jamie_hip.h: JAMIE_PANEL
+PANEL_KEYS = ('h1', 'h2', 'g1', 'g2', 'de2', 'de1', 'da2', 'da1')      # what a BatchNorm launch reads as fp32: GEMM slabs and their sums
 
 
 def _big_enough(B, shapes):
@@ -344,6 +348,17 @@ class TrainEngine:
                 if cfg >= 0:
                     self.fcfg[key] = cfg
                     plan_sk[key] = sks
+        # ---- panel layout of the BatchNorm launches' fp32 inputs (bf16 mode, float4 BatchNorm kernels, large-tile GEMMs) ----
+        # A BatchNorm workgroup owns a strip of 16 / 32 columns for all B rows: of a row-major [B, N] slab that is B segments of 64 /
+        # 128 bytes, 4 N bytes apart, per slab.  In PANELS of 16 columns ([N / 16][B][16]) the same strip is one contiguous block of
+        # B x 64 bytes per slab: the launches' load phases -- all they are bound by -- shorten by 1.5-2 us each
+        # (profiles/r05_ab_bn_panel*.log).  The producers write that layout themselves (GEMM epilogue: c_panel; fused latent launches:
+        # g1_panel / da2_panel), BatchNorm forward writes the summed pre-activation back in it and BatchNorm backward reads it; the
+        # activations / gradients that leave a BatchNorm launch are bf16 row-major as before.  Which layers take it is decided per
+        # step (_set_panels): a layer's buffers are in panels only when BOTH its forward and its backward producer can write them.
+        self.panel = bool(self.bf16 and self.fuse_bf16 and TUNING['bn_panel'] and all(d % 4 == 0 for d in self.dims)
+                          and all(self.gcfg.get(k, -1) in BF16_TILE for k in ('enc0', 'enc1', 'dec1', 'd_e2', 'd_e1', 'd_a1')))
+        self._pan = {'bn0': False, 'bn1': False, 'bn2': False, 'bn3': False}
         self.need_T = set()
         if self.bf16:
             for dy_key, a_key, lin in (('dxhat', 'e2', 'dec2'), ('de2', 'e1', 'dec1'), ('de1', 'comb', 'dec0'),
@@ -363,23 +378,23 @@ class TrainEngine:
                 sk[key] = v[i]
             w['sk'] = sk
             w['x'] = torch.empty(B, d, **f32)
-            w['h1'] = torch.empty(sk['enc0'], B, 2 * d, **f32); w['a1'] = torch.empty(B, 2 * d, **f32)
-            w['h2'] = torch.empty(sk['enc1'], B, d, **f32); w['a2'] = torch.empty(B, d, **f32)
+            w['h1'] = self._slabs(sk['enc0'], 2 * d); w['a1'] = torch.empty(B, 2 * d, **f32)
+            w['h2'] = self._slabs(sk['enc1'], d); w['a2'] = torch.empty(B, d, **f32)
             w['ml'] = torch.empty(sk['head'], B, 2 * L, **f32)
             for k in ('mu', 'lv', 'z', 'eps', 'comb', 'cz', 'H', 'ch'):
                 w[k] = torch.empty(B, L, **f32)
-            w['g1'] = torch.empty(1, B, d, **f32); w['e1'] = torch.empty(B, d, **f32)
-            w['g2'] = torch.empty(sk['dec1'], B, 2 * d, **f32); w['e2'] = torch.empty(B, 2 * d, **f32)
+            w['g1'] = self._slabs(1, d); w['e1'] = torch.empty(B, d, **f32)
+            w['g2'] = self._slabs(sk['dec1'], 2 * d); w['e2'] = torch.empty(B, 2 * d, **f32)
             w['dxhat'] = torch.empty(B, d, **f32)
             if self.gcfg.get('dec2', -1) >= 0 or self.fcfg.get('dec2', -1) >= 0:   # split-K x_hat slabs, MSE in jamie_mse_cast
                 w['xh'] = torch.empty(sk['dec2'], B, d, **f32)
-            w['de2'] = torch.empty(sk['d_e2'], B, 2 * d, **f32)
-            w['de1'] = torch.empty(sk['d_e1'], B, d, **f32)
+            w['de2'] = self._slabs(sk['d_e2'], 2 * d)
+            w['de1'] = self._slabs(sk['d_e1'], d)
             w['dcomb'] = torch.empty(sk['d_comb'] + 1, B, L, **f32)   # +1 slab: external d(combined) (autograd seam)
             w['xhat'] = None                                           # allocated on first forward_only()
             w['dml'] = torch.empty(B, 2 * L, **f32)
-            w['da2'] = torch.empty(1, B, d, **f32)
-            w['da1'] = torch.empty(sk['d_a1'], B, 2 * d, **f32)
+            w['da2'] = self._slabs(1, d)
+            w['da1'] = self._slabs(sk['d_a1'], 2 * d)
             for k, nn in (('bn0', 2 * d), ('bn1', d), ('bn2', d), ('bn3', 2 * d)):
                 w[k + '.mean'] = torch.empty(nn, **f32); w[k + '.invstd'] = torch.empty(nn, **f32)
             w['idx'] = torch.zeros(B, dtype=torch.int32, device=self.dev)
@@ -716,6 +731,46 @@ class TrainEngine:
         off = slot * self._stagger // es
         return torch.zeros(n + off, device=self.dev, dtype=dtype)[off:]
 
+    def _slabs(self, S, N):
+        """[S, B, N] fp32 slab buffer of a BatchNorm input.  With the panel layout available the slabs are ceil(N / 16) * 16 * B
+        floats apart (room for N rounded up to whole panels); the tensor is the row-major [S, B, N] view of that storage, which is
+        what the buffer holds whenever its layer does NOT take the panel layout in a step (rows(): either layout as [S, B, N])."""
+        if not self.panel:
+            return torch.empty(S, self.B, N, device=self.dev, dtype=torch.float32)
+        npad = (N + PANEL - 1) // PANEL * PANEL
+        flat = torch.zeros(S * self.B * npad, device=self.dev, dtype=torch.float32)
+        return torch.as_strided(flat, (S, self.B, N), (self.B * npad, N, 1))
+
+    BN_OF = {'h1': 'bn0', 'da1': 'bn0', 'h2': 'bn1', 'da2': 'bn1', 'g1': 'bn2', 'de1': 'bn2', 'g2': 'bn3', 'de2': 'bn3'}
+
+    def _paneled(self, key, cfg=None):
+        """Is workspace `key` in the panel layout in the current step?  `cfg`: the tile configuration of the GEMM launch about to
+        write it -- only the large-tile kernel can (an inconsistency here would hand BatchNorm a layout it does not expect)."""
+        on = bool(self.panel and self._pan.get(self.BN_OF.get(key), False))
+        if on and cfg is not None and cfg not in BF16_TILE:
+            raise nv.JamieHipError(f'internal: {key} is to be written in panels by tile configuration {cfg}')
+        return on
+
+    def rows(self, i, key):
+        """Workspace `key` of modality `i` as a row-major [S, B, N] tensor, whichever layout the last step kept it in (tests /
+        diagnostics: a copy when the buffer is in panels)."""
+        t = self.ws[i][key]
+        if not self._paneled(key):
+            return t
+        S, B, N = t.shape
+        npad = (N + PANEL - 1) // PANEL * PANEL
+        flat = torch.as_strided(t, (S, npad // PANEL, B, PANEL), (B * npad, B * PANEL, PANEL, 1))
+        return flat.permute(0, 2, 1, 3).reshape(S, B, npad)[:, :, :N]
+
+    def _set_panels(self, fused_latent):
+        """Which BatchNorm layers keep their fp32 inputs in panels this step: bn0 / bn3 always (both producers are large-tile GEMM
+        launches); bn2 when decoder layer 0 comes out of the fused latent launch; bn1 when the heads' input gradient comes out of
+        the fused latent backward launch or a large-tile GEMM."""
+        on = self.panel
+        fused_tail = fused_latent and self._fuse_da2()
+        self._pan = {'bn0': on, 'bn3': on, 'bn2': on and fused_latent,
+                     'bn1': on and (fused_tail or self.gcfg.get('d_a2', -1) in BF16_TILE)}
+
     # ---- bf16 compute mode: bf16 / bf16-transposed copies of GEMM operands ----
     def refresh_weights_bf16(self, transposes_only=False, lins=('enc0', 'enc1', 'head', 'dec0', 'dec1', 'dec2')):
         """bf16 copy of every weight matrix (written by the Adam kernel itself during training) and the
@@ -797,7 +852,8 @@ class TrainEngine:
             w, P, bn = self.ws[i], self.m.p, self.m.bn
             h = w[h_key]
             pr = nv.BnFwdProblem()
-            pr.h, pr.nslab, pr.slab_stride = nv.ptr(h), h.shape[0], h.shape[1] * h.shape[2]
+            pr.h, pr.nslab, pr.slab_stride = nv.ptr(h), h.shape[0], h.stride(0)
+            pr.panel = int(self._paneled(h_key))
             pr.gamma, pr.beta = nv.ptr(P[f'm{i}.{layer}.g']), nv.ptr(P[f'm{i}.{layer}.b'])
             pr.running_mean, pr.running_var = nv.ptr(bn[f'm{i}.{layer}.mean']), nv.ptr(bn[f'm{i}.{layer}.var'])
             pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
@@ -817,7 +873,8 @@ class TrainEngine:
             w, P = self.ws[i], self.m.p
             da, h = w[da_key], w[h_key]
             pr = nv.BnBwdProblem()
-            pr.da, pr.nslab, pr.slab_stride = nv.ptr(da), da.shape[0], da.shape[1] * da.shape[2]
+            pr.da, pr.nslab, pr.slab_stride = nv.ptr(da), da.shape[0], da.stride(0)
+            pr.panel = int(self._paneled(da_key))             # (da and h of one layer share the layout: BN_OF)
             pr.h, pr.gamma, pr.beta = nv.ptr(h), nv.ptr(P[f'm{i}.{layer}.g']), nv.ptr(P[f'm{i}.{layer}.b'])
             pr.save_mean, pr.save_invstd = nv.ptr(w[layer + '.mean']), nv.ptr(w[layer + '.invstd'])
             pr.dgamma, pr.dbeta = nv.ptr(self.g[f'm{i}.{layer}.g']), nv.ptr(self.g[f'm{i}.{layer}.b'])
@@ -850,7 +907,8 @@ class TrainEngine:
                 a, W = w[a_key + '_bf'], self.wbf[f'm{i}.{lin}.W']
             probs.append(nv.gemm_problem(a, W, out, self.B, nout, nin, nin, nin, nout,
                                          bias=P[f'm{i}.{lin}.b'] if with_bias else None,
-                                         splitk=w['sk'][sk_key], slab_stride=self.B * nout))
+                                         splitk=w['sk'][sk_key], slab_stride=out.stride(0),
+                                         c_panel=self._paneled(out_key, self.gcfg.get(sk_key, -1))))
         cfg = self.gcfg.get(sk_key, -1)
         fcfg = self.fcfg.get(sk_key, -1)
         if (not self.bf16 and self.pipeline and fcfg == F32_CFG_ROWS and lin in str(TUNING['f32_pipe_solo']).split(',')):
@@ -871,13 +929,15 @@ class TrainEngine:
             nout, nin = W.shape
             if self.bf16 and f'm{i}.{lin}' not in self.wT:      # dx = dy W on W [out, in] as stored (b_tr)
                 probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wbf[f'm{i}.{lin}.W'], out, self.B, nin, nout,
-                                             nout, nin, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin, b_tr=True))
+                                             nout, nin, nin, splitk=w['sk'][sk_key], slab_stride=out.stride(0), b_tr=True,
+                                             c_panel=self._paneled(out_key, self.gcfg.get(sk_key, -1))))
             elif self.bf16:   # dx = dy W  ==  dy (W^T)^T with the K-contiguous transposed copy (skinny layers)
                 probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], out, self.B, nin, nout,
-                                             nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+                                             nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=out.stride(0),
+                                             c_panel=self._paneled(out_key, self.gcfg.get(sk_key, -1))))
             else:
                 probs.append(nv.gemm_problem(dy, W, out, self.B, nin, nout, nout, nin, nin,
-                                             splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+                                             splitk=w['sk'][sk_key], slab_stride=out.stride(0)))
         if self.bf16:
             nv.gemm_bf16(probs, self.gcfg.get(sk_key, -1))
         else:
@@ -1013,10 +1073,12 @@ class TrainEngine:
             nout, nin = self.g[f'm{i}.{lin}.W'].shape
             if f'm{i}.{lin}' not in self.wT:                    # W [out, in] as stored (b_tr): no transposed copy
                 probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wbf[f'm{i}.{lin}.W'], w[out_key], self.B, nin, nout,
-                                             nout, nin, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin, b_tr=True))
+                                             nout, nin, nin, splitk=w['sk'][sk_key], slab_stride=w[out_key].stride(0), b_tr=True,
+                                             c_panel=self._paneled(out_key, self.gcfg.get(sk_key, -1))))
             else:
                 probs.append(nv.gemm_problem(w[dy_key + '_bf'], self.wT[f'm{i}.{lin}'], w[out_key], self.B, nin, nout,
-                                             nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=self.B * nin))
+                                             nout, nout, nin, splitk=w['sk'][sk_key], slab_stride=w[out_key].stride(0),
+                                             c_panel=self._paneled(out_key, self.gcfg.get(sk_key, -1))))
         for i, d in enumerate(self.dims):
             probs.append(self._dw_problem(i, dy_key, a_key, lin))
         for ex in riding:
@@ -1046,11 +1108,13 @@ class TrainEngine:
             d.dbias_head[i] = nv.ptr(self.g[f'm{i}.head.b'])
             if self._fuse_da2():
                 d.head_W[i], d.da2[i] = nv.ptr(self.m.p[f'm{i}.head.W']), nv.ptr(w['da2'])
+                d.da2_panel = int(self._paneled('da2'))
             if self.bf16:
                 d.dml_bf16[i] = nv.ptr(w['dml_bf'])
                 d.dmlT_bf16[i] = nv.ptr(w['dml_T']) if 'dml' in self.need_T else None
                 d.comb_bf16[i] = nv.ptr(w['comb_bf'])
                 d.combT_bf16[i] = nv.ptr(w['comb_T']) if 'comb' in self.need_T else None
+        d.g1_panel = int(self._paneled('g1'))
         d.comb = nv.ptr(self.ws[0]['comb'])
         d.colpart, d.accumulate, d.ticket = nv.ptr(self.lat_colpart), int(self.accumulate), nv.ptr(self.lat_ticket)
         d.ml_nslab, d.ml_slab_stride = self.ws[0]['ml'].shape[0], B * 2 * L
@@ -1210,6 +1274,7 @@ class TrainEngine:
 
     def _forward(self, corr, Fblk, noise, fused_losses):
         B, L = self.B, self.L
+        self._set_panels(fused_losses and self._fused_latent(corr, Fblk))
         # ---------------- forward ----------------
         self._fwd_block('x', 'enc0', 'h1', 'enc0', 'bn0', 'a1', 10, noise, 'enc_masks', 0)
         self._fwd_block('a1', 'enc1', 'h2', 'enc1', 'bn1', 'a2', 11, noise, 'enc_masks', 1)

@@ -95,17 +95,18 @@ def _check_products_against_stored_operands(eng, model, noise, p):
         w, wb, P_ = eng.ws[i], eng.wbf, model.p
         for a, lin, h in (('x', 'enc0', 'h1'), ('a1', 'enc1', 'h2'), ('e1', 'dec1', 'g2')):
             want = bfl(w[a + '_bf']) @ bfl(wb[f'm{i}.{lin}.W']).t() + P_[f'm{i}.{lin}.b']
-            assert _rel(w[h][0], want) < 5e-5, (i, lin, 'forward', _rel(w[h][0], want))
+            assert _rel(eng.rows(i, h)[0], want) < 5e-5, (i, lin, 'forward', _rel(eng.rows(i, h)[0], want))
         assert _rel(w['ml'].sum(0), bfl(w['a2_bf']) @ bfl(wb[f'm{i}.head.W']).t()) < 5e-5, (i, 'head forward')
         if 'xh' in w:
             want = bfl(w['e2_bf']) @ bfl(wb[f'm{i}.dec2.W']).t() + P_[f'm{i}.dec2.b']
             assert _rel(w['xh'].sum(0), want) < 5e-5, (i, 'dec2 forward')
         # the two products inside the fused latent launches are exact fp32: decoder layer 0 forward, the heads' input gradient
-        assert _rel(w['g1'][0], w['comb'] @ P_[f'm{i}.dec0.W'].t() + P_[f'm{i}.dec0.b']) < 1e-5, (i, 'dec0 forward (fp32)')
-        assert _rel(w['da2'][0], w['dml'] @ P_[f'm{i}.head.W']) < 1e-5, (i, 'heads input gradient (fp32)')
+        # (eng.rows: the BatchNorm launches' fp32 inputs are kept in panels of 16 columns; row-major copies for the checks)
+        assert _rel(eng.rows(i, 'g1')[0], w['comb'] @ P_[f'm{i}.dec0.W'].t() + P_[f'm{i}.dec0.b']) < 1e-5, (i, 'dec0 forward (fp32)')
+        assert _rel(eng.rows(i, 'da2')[0], w['dml'] @ P_[f'm{i}.head.W']) < 1e-5, (i, 'heads input gradient (fp32)')
         nd = w['sk']['d_comb']
-        for dy, lin, out in (('dxhat', 'dec2', w['de2'].sum(0)), ('de2', 'dec1', w['de1'].sum(0)),
-                             ('de1', 'dec0', w['dcomb'][:nd].sum(0)), ('da2', 'enc1', w['da1'].sum(0))):
+        for dy, lin, out in (('dxhat', 'dec2', eng.rows(i, 'de2').sum(0)), ('de2', 'dec1', eng.rows(i, 'de1').sum(0)),
+                             ('de1', 'dec0', w['dcomb'][:nd].sum(0)), ('da2', 'enc1', eng.rows(i, 'da1').sum(0))):
             want = bfl(w[dy + '_bf']) @ bfl(wb[f'm{i}.{lin}.W'])
             assert _rel(out, want) < 5e-5, (i, lin, 'input gradient', _rel(out, want))
         for dy, a, lin in (('dxhat', 'e2', 'dec2'), ('de2', 'e1', 'dec1'), ('de1', 'comb', 'dec0'), ('dml', 'a2', 'head'),
@@ -119,7 +120,7 @@ def _check_products_against_stored_operands(eng, model, noise, p):
         # BatchNorm + LeakyReLU + dropout outputs from the summed pre-activations (slab 0 after the forward launch)
         for bn, h, a, kind, j in (('bn0', 'h1', 'a1', 'enc_masks', 0), ('bn1', 'h2', 'a2', 'enc_masks', 1),
                                   ('bn2', 'g1', 'e1', 'dec_masks', 0), ('bn3', 'g2', 'e2', 'dec_masks', 1)):
-            hv = w[h][0]
+            hv = eng.rows(i, h)[0]
             mean, var = hv.mean(0), hv.var(0, unbiased=False)
             y = (hv - mean) * torch.rsqrt(var + BN_EPS) * P_[f'm{i}.{bn}.g'] + P_[f'm{i}.{bn}.b']
             y = torch.where(y > 0, y, LRELU_SLOPE * y)

@@ -1191,3 +1191,88 @@ def test_bn_prefetch_rider_changes_nothing(nv):
         assert torch.equal(a, b)
     with pytest.raises(nv.JamieHipError):
         nv.bn_act_fwd([pr], p, state, prefetch=[weights[1:]])        # 2-byte aligned only
+
+
+# ---- panel layout of the BatchNorm launches' fp32 inputs (round 5; include/jamie_hip.h: JAMIE_PANEL) ----
+def _to_panels(t, npad=None):
+    """[S, B, N] row-major -> the same values in panels of 16 columns: flat [S, ceil(N / 16) * 16 * B]."""
+    S, B, N = t.shape
+    npad = (N + 15) // 16 * 16
+    p = torch.zeros(S, B, npad, dtype=t.dtype, device=t.device)
+    p[:, :, :N] = t
+    return p.reshape(S, B, npad // 16, 16).permute(0, 2, 1, 3).contiguous().reshape(S, -1)
+
+
+def _from_panels(flat, B, N):
+    S = flat.shape[0]
+    npad = (N + 15) // 16 * 16
+    return flat.reshape(S, npad // 16, B, 16).permute(0, 2, 1, 3).reshape(S, B, npad)[:, :, :N]
+
+
+@pytest.mark.parametrize('M,N,K,sk,cfg', [(512, 2000, 1000, 2, 31), (512, 1000, 2000, 3, 32), (512, 264, 512, 1, 29),
+                                           (300, 520, 256, 2, 23), (512, 504, 512, 1, 24)])
+def test_gemm_bf16_panel_store_equals_row_major_store(nv, M, N, K, sk, cfg):
+    """c_panel: every slab of C in panels of 16 columns -- element (m, n) at ((n / 16) * M + m) * 16 + n % 16 -- holds bit for bit
+    what the row-major store of the same launch holds (edge tiles in M and N, ragged last panel, bias on slab 0 only)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias = _bf16(torch.randn(M, K, generator=g)), _bf16(torch.randn(N, K, generator=g)), torch.randn(N, generator=g)
+    A, W, bd = dev(a), dev(w), dev(bias)
+    ref = torch.full((sk, M, N), float('nan'), device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(A, W, ref, M, N, K, K, K, N, bias=bd, splitk=sk, slab_stride=M * N)], cfg)
+    npad = (N + 15) // 16 * 16
+    out = torch.full((sk, M * npad), float('nan'), device='cuda')
+    nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N, bias=bd, splitk=sk, slab_stride=M * npad, c_panel=True)], cfg)
+    assert torch.equal(_from_panels(out, M, N), ref)
+    # the padding columns of a ragged last panel are never written
+    if npad != N:
+        pad = out.reshape(sk, npad // 16, M, 16)[:, -1, :, N % 16:]
+        assert torch.isnan(pad).all()
+    with pytest.raises(nv.JamieHipError):          # small-tile configurations cannot write panels
+        nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N, bias=bd, splitk=sk, slab_stride=M * npad, c_panel=True)], 7)
+
+
+@pytest.mark.parametrize('B,N,p,nslab', [(512, 2000, 0.6, 3), (512, 1000, 0.6, 2), (512, 504, 0.0, 1), (256, 72, 0.25, 2), (1024, 136, 0.6, 2)])
+def test_bn_act_panel_inputs_equal_row_major_inputs(nv, B, N, p, nslab):
+    """BatchNorm forward / backward with `panel` set read their fp32 inputs (split-K slabs, summed pre-activation, upstream
+    gradient slabs) from panels of 16 columns and produce bit for bit what the row-major launches produce: bf16 activations,
+    statistics, running statistics, the summed pre-activation (written back in panels), bf16 dh, d gamma / d beta / d bias."""
+    g = torch.Generator().manual_seed(B + N)
+    hs = torch.randn(nslab, B, N, generator=g) * 2 + 0.5
+    da_s = torch.randn(nslab, B, N, generator=g)
+    gamma, beta = dev(torch.rand(N, generator=g) + .5), dev(torch.randn(N, generator=g))
+    state = torch.tensor([77, 5, 0, 0], dtype=torch.int64, device='cuda')
+
+    def run(panel):
+        hd = dev(_to_panels(hs)) if panel else dev(hs)
+        dad = dev(_to_panels(da_s)) if panel else dev(da_s)
+        stride = hd.shape[1] if panel else B * N
+        out_bf = torch.zeros(B, N, dtype=torch.bfloat16, device='cuda')
+        rm, rv, sm, si = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda'), torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+        pr = nv.BnFwdProblem()
+        pr.h, pr.nslab, pr.slab_stride, pr.gamma, pr.beta = nv.ptr(hd), nslab, stride, nv.ptr(gamma), nv.ptr(beta)
+        pr.running_mean, pr.running_var, pr.save_mean, pr.save_invstd = nv.ptr(rm), nv.ptr(rv), nv.ptr(sm), nv.ptr(si)
+        pr.out, pr.out_bf16, pr.mask, pr.B, pr.N, pr.rng_stream, pr.panel = None, nv.ptr(out_bf), None, B, N, 3, int(panel)
+        nv.bn_act_fwd([pr], p, state)
+        dh_bf = torch.zeros(B, N, dtype=torch.bfloat16, device='cuda')
+        dg, db, dl = (torch.zeros(N, device='cuda') for _ in range(3))
+        pb = nv.BnBwdProblem()
+        pb.da, pb.nslab, pb.slab_stride = nv.ptr(dad), nslab, stride
+        pb.h, pb.gamma, pb.beta, pb.save_mean, pb.save_invstd = nv.ptr(hd), nv.ptr(gamma), nv.ptr(beta), nv.ptr(sm), nv.ptr(si)
+        pb.dgamma, pb.dbeta, pb.dbias_lin, pb.mask = nv.ptr(dg), nv.ptr(db), nv.ptr(dl), None
+        pb.B, pb.N, pb.rng_stream, pb.accumulate, pb.dh_bf16, pb.skip_f32, pb.panel = B, N, 3, 0, nv.ptr(dh_bf), 1, int(panel)
+        nv.bn_act_bwd([pb], p, state)
+        torch.cuda.synchronize()
+        h0 = _from_panels(hd[:1], B, N)[0] if panel else hd[0]
+        return out_bf, rm, rv, sm, si, h0.clone(), dh_bf, dg, db, dl
+    a, b = run(False), run(True)
+    for x, y, name in zip(a, b, ('out', 'running_mean', 'running_var', 'save_mean', 'save_invstd', 'h sum', 'dh', 'dgamma', 'dbeta', 'dbias')):
+        assert torch.equal(x, y), name
+    close(a[5], hs.sum(0), rtol=1e-6, atol=1e-6)
+    # a panel-layout backward launch cannot write the fp32 dh in place (its input is in another layout)
+    pb = nv.BnBwdProblem()
+    t = torch.zeros(1, B * ((N + 15) // 16 * 16), device='cuda')
+    pb.da, pb.nslab, pb.slab_stride, pb.h = nv.ptr(t), 1, t.shape[1], nv.ptr(t)
+    pb.gamma, pb.beta, pb.save_mean, pb.save_invstd = nv.ptr(gamma), nv.ptr(beta), nv.ptr(gamma), nv.ptr(gamma)
+    pb.dgamma, pb.dbeta, pb.B, pb.N, pb.panel = nv.ptr(torch.zeros(N, device='cuda')), nv.ptr(torch.zeros(N, device='cuda')), B, N, 1
+    with pytest.raises(nv.JamieHipError):
+        nv.bn_act_bwd([pb], 0.0, state)

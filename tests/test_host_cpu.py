@@ -102,13 +102,13 @@ def test_ctypes_struct_sizes_match_header(lib, tmp_path):
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include "jamie_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
                    'sizeof(jamie_gemm_problem),sizeof(jamie_bnact_fwd_problem),sizeof(jamie_bnact_bwd_problem),'
-                   'sizeof(jamie_latent));printf("%zu\\n",sizeof(jamie_pd_state));return 0;}\n')
+                   'sizeof(jamie_latent));printf("%zu %zu\\n",sizeof(jamie_pd_state),sizeof(jamie_latent_m));return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     import ctypes
     assert sizes == [ctypes.sizeof(lib.GemmProblem), ctypes.sizeof(lib.BnFwdProblem),
-                     ctypes.sizeof(lib.BnBwdProblem), ctypes.sizeof(lib.Latent), ctypes.sizeof(lib.PdState)]
+                     ctypes.sizeof(lib.BnBwdProblem), ctypes.sizeof(lib.Latent), ctypes.sizeof(lib.PdState), ctypes.sizeof(lib.LatentM)]
 
 
 def test_no_gpu_fails_loudly(lib):
