@@ -306,9 +306,14 @@ def encoder_gemm_record(eng, ms, config, dtype):
         slices.append(int(eng.ws[i]['sk']['enc0']))
     rec, note = _static_traffic(f'{config}_{dtype}_encoder_gemm')
     hbm = rec['hbm_bytes_per_launch'] if rec else None
+    prof_us = rec.get('rocprofv3_avg_launch_us') if rec else None
     t = ms * 1e-3
     out = {'kernel': 'forward d -> 2d Linear of the encoder (reference model.py:151), both modalities in one launch',
            'avg_launch_ms': ms, 'flop': flop, 'tflops': flop / t / 1e12, 'peak_tflops': peak, 'frac_mfma': flop / t / 1e12 / peak,
+           'avg_launch_note': 'HIP events around the launch, median over the timed steps.  It is the first launch behind clip + Adam: an '
+                              'event between the two makes the optimiser\'s write-back drain visible inside this bracket (~+8 us over the '
+                              'kernel\'s own duration: rocprofv3_avg_launch_us, static, from the committed profile)',
+           'rocprofv3_avg_launch_us': prof_us, 'frac_mfma_rocprofv3': (flop / (prof_us * 1e-6) / 1e12 / peak) if prof_us else None,
            'algorithmic_bytes': alg, 'frac_hbm_algorithmic': alg / t / 1e9 / PEAK_HBM_GBS,
            'hbm_bytes': hbm, 'hbm_bytes_source': note, 'frac_hbm': (hbm / t / 1e9 / PEAK_HBM_GBS) if hbm else None,
            'tile': tiles, 'k_slices': slices, 'ingest_model_bytes': ingest, 'ingest_peak_TBps': INGEST_TBPS,

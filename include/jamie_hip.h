@@ -86,13 +86,20 @@ typedef struct {
                                  * the squares of the fp32 values).  The weight gradients of the bf16 compute mode: 2 instead of 4
                                  * bytes per parameter written here and read again by jamie_clip_adam_g16 */
     int c_panel;                /* jamie_gemm_bf16, large-tile configurations, fp32 EPI_STORE without accumulate: every slab of C is
-                                 * written in PANELS of JAMIE_PANEL (16) columns -- element (m, n) at ((n / 16) * M + m) * 16 + n % 16
-                                 * of its slab, slab_stride >= ceil(N / 16) * 16 * M, ldc ignored -- the layout the BatchNorm launches
-                                 * read (`panel` below): the 16-column strip a BatchNorm workgroup owns is then ONE contiguous block of
-                                 * M x 64 bytes per slab instead of M segments 4 N bytes apart (round 5: the pre-activations of
+                                 * written in PANELS of P = JAMIE_PANEL columns -- element (m, n) at ((n / P) * M + m) * P + n % P
+                                 * of its slab, slab_stride >= ceil(N / P) * P * M, ldc ignored -- the layout the BatchNorm launches
+                                 * read (`panel` below): the column strip a BatchNorm workgroup owns is then whole contiguous blocks of
+                                 * M x 4 P bytes per slab instead of M segments 4 N bytes apart (round 5: the pre-activations of
                                  * model.py:151-154 etc. go GEMM -> BatchNorm -> BatchNorm backward in this layout) */
 } jamie_gemm_problem;
-#define JAMIE_PANEL 16
+#ifndef JAMIE_PANEL
+#define JAMIE_PANEL 16           /* columns per panel (16 fp32 = 64 bytes per row): a power of two >= 4.  8-column panels with 8-column BatchNorm
+                                  * strips (three 256-thread workgroups per CU: 24 instead of 32 columns on the busiest CU) were built and
+                                  * measured in round 5: +28 us per step, and +3 us with 8-column panels under the 16 / 32-column strips
+                                  * (profiles/r05_ab_panel8_cq2_rejected.log) */
+#endif
+/* the panel width this library was built with (the host side lays its buffers out for it) */
+int jamie_panel_width(void);
 
 /* One launch computing up to JAMIE_MAX_GEMM_GROUP independent problems (the modalities of one layer; dX and dW together). */
 int jamie_gemm_f32(const jamie_gemm_problem* problems /*host*/, int count, int layout, void* stream);
@@ -131,11 +138,14 @@ int jamie_cast_transpose(const jamie_cast_problem* problems /*host*/, int count 
  * partial[t] = pscale * sum (y - x)^2 over 64x64 tile t (tile index = m_tile + tiles_m * n_tile, the order of the
  * 64x64 GEMM's fused MSE epilogue), ceil(R/64) * ceil(C/64) partials per problem. */
 typedef struct {
-    const float* y; const float* x; float* d;
+    const float* y; const float* x; float* d;   /* d: optional (NULL: only the bf16 copies / column sums leave the launch) */
     void* d_bf16; void* dT_bf16;        /* optional */
     float* partial;                     /* optional */
     int R, C, nslab; long long slab_stride;
     float scale, pscale;
+    float* colpart;                     /* optional [ceil(R / 64), C]: column sums of d over each 64-row tile (rows added in order): the
+                                         * decoder's output-bias gradient = column sums of d x_hat (jamie.py:734) is then a sum of
+                                         * ceil(R / 64) rows instead of a second pass over the [R, C] matrix */
 } jamie_mse_problem;
 int jamie_mse_cast(const jamie_mse_problem* problems /*host*/, int count /* <= JAMIE_MAX_GROUP */, void* stream);
 
@@ -283,6 +293,11 @@ typedef struct {
     void* dec0_WT_bf16[4];
     int g1_panel, da2_panel;    /* 1: g1[i] / da2[i] are written in panels of JAMIE_PANEL columns (see jamie_gemm_problem.c_panel):
                                  * what the BatchNorm launches that consume them read when their `panel` is set */
+    /* optional (all modalities or none; L <= 64, d[i] a multiple of 8): jamie_latent_m_fwd computes the heads' product itself --
+     * mu | logvar_i = heads_a_bf16[i] [B, d[i]] (bf16: the encoder's output as its BatchNorm launch stored it) x
+     * heads_W_bf16[i] [2L, d[i]]^T (bf16 copy of fc_mu | fc_var, model.py:180,185), fp32 accumulation, + head_bias -- instead of
+     * summing the split-K slabs `ml` of a heads GEMM launch (ml / ml_nslab are ignored then; d[i] must be set) */
+    const void* heads_a_bf16[4]; const void* heads_W_bf16[4];
 } jamie_latent_m;
 /* What a riding sampler draws: idx[B] = jamie_sample_indices(B, N, offset, replace, {seed, step + step_add}, rng_stream)
  * (np.random.choice of jamie/jamie.py:556).  step_add = 1 in a launch that runs before the norm kernel has advanced the step. */

@@ -43,7 +43,7 @@ class CastProblem(C.Structure):
 class MseProblem(C.Structure):
     _fields_ = [('y', C.c_void_p), ('x', C.c_void_p), ('d', C.c_void_p), ('d_bf16', C.c_void_p), ('dT_bf16', C.c_void_p),
                 ('partial', C.c_void_p), ('R', C.c_int), ('C', C.c_int), ('nslab', C.c_int),
-                ('slab_stride', C.c_longlong), ('scale', C.c_float), ('pscale', C.c_float)]
+                ('slab_stride', C.c_longlong), ('scale', C.c_float), ('pscale', C.c_float), ('colpart', C.c_void_p)]
 
 
 class ColsumProblem(C.Structure):
@@ -105,7 +105,7 @@ class LatentM(C.Structure):
                 ('dml_bf16', C.c_void_p * 4), ('dmlT_bf16', C.c_void_p * 4),
                 ('dbias_head', C.c_void_p * 4), ('colpart', C.c_void_p), ('accumulate', C.c_int), ('ticket', C.c_void_p),
                 ('defer_final', C.c_int), ('head_W', C.c_void_p * 4), ('da2', C.c_void_p * 4), ('dec0_WT_bf16', C.c_void_p * 4),
-                ('g1_panel', C.c_int), ('da2_panel', C.c_int)]
+                ('g1_panel', C.c_int), ('da2_panel', C.c_int), ('heads_a_bf16', C.c_void_p * 4), ('heads_W_bf16', C.c_void_p * 4)]
 
 
 class SampleArgs(C.Structure):
@@ -123,6 +123,7 @@ class PdState(C.Structure):
 EXPORTS = {
     'jamie_last_error': (C.c_char_p, []),
     'jamie_version': (C.c_int, []),
+    'jamie_panel_width': (C.c_int, []),
     'jamie_max_partials': (C.c_int, []),
     'jamie_max_norm_partials': (C.c_int, []),
     'jamie_gemm_f32': (C.c_int, [C.POINTER(GemmProblem), C.c_int, C.c_int, C.c_void_p]),
@@ -452,14 +453,16 @@ def cast_problem(src, dst=None, dstT=None, nslab=1, slab_stride=0, rows=None, ds
     return p
 
 
-def mse_problem(y, x, d, d_bf16=None, dT_bf16=None, partial=None, scale=1.0, pscale=1.0):
-    """y [nslab, R, C] fp32 slabs (contiguous), x / d [R, C] fp32, optional bf16 [R, C] / [C, R] copies of d."""
+def mse_problem(y, x, d, d_bf16=None, dT_bf16=None, partial=None, scale=1.0, pscale=1.0, colpart=None):
+    """y [nslab, R, C] fp32 slabs (contiguous), x [R, C] fp32; outputs: d [R, C] fp32 (or None), optional bf16 [R, C] / [C, R]
+    copies of d, optional `colpart` [ceil(R / 64), C] (column sums of d per 64-row tile)."""
     p = MseProblem()
     nslab = y.shape[0] if y.dim() == 3 else 1
     R, Cc = x.shape
     p.y, p.x, p.d, p.d_bf16, p.dT_bf16, p.partial = ptr(y), ptr(x), ptr(d), ptr(d_bf16), ptr(dT_bf16), ptr(partial)
     p.R, p.C, p.nslab, p.slab_stride, p.scale, p.pscale = R, Cc, nslab, R * Cc, scale, pscale
-    p._keep = (y, x, d, d_bf16, dT_bf16, partial)
+    p.colpart = ptr(colpart)
+    p._keep = (y, x, d, d_bf16, dT_bf16, partial, colpart)
     return p
 
 

@@ -496,13 +496,14 @@ __global__ __launch_bounds__(128 * CQ) void bn_act_bwd4_kernel(BnBwdGroup g, flo
     const uint32_t thr = drop_threshold16(p_drop);
     // panel layout of the two fp32 inputs (bn_fwd_strip.h): this strip's rows are one contiguous block of each
     const bool pan = P.panel != 0;
-    const unsigned row_bytes = pan ? 64u : (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
-    const unsigned one_slab = pan ? (unsigned)((N + 15) >> 4) * (unsigned)B * 64u : (unsigned)B * (unsigned)N * 4u;
+    constexpr unsigned PW = JAMIE_PANEL, PB = 4u * JAMIE_PANEL;
+    const unsigned row_bytes = pan ? PB : (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const unsigned one_slab = pan ? (unsigned)((N + PW - 1) / PW) * (unsigned)B * PB : (unsigned)B * (unsigned)N * 4u;
     const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.da, 0, (int)((unsigned)(nslab - 1) * slab_bytes + one_slab), 0x00020000);
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.h, 0, (int)one_slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
-    const unsigned coff = pan ? (unsigned)(col >> 4) * ((unsigned)B * 64u) + (unsigned)(col & 15) * 4u : (unsigned)col * 4u;
+    const unsigned coff = pan ? ((unsigned)col / PW) * ((unsigned)B * PB) + ((unsigned)col % PW) * 4u : (unsigned)col * 4u;
     unsigned roff[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -641,7 +642,15 @@ extern "C" int jamie_bn_act_fwd_pf(const jamie_bnact_fwd_problem* pr, int count,
 // 375 strips = two rounds against 188 = one -- the 32-column kernel is taken: 20.9 -> 17.3 us per launch, while the d-wide layers
 // (188 strips: one round either way) keep 16 columns (12.6 / 11.1 us against 16.1 / 13.3; profiles/r03_by_grid_bn_fwd_cq8.txt).
 // Backward (two workgroups per CU): 16 columns always (32: +6 us per step).
-static int bn_pick_cq(long long strips16, bool needs16, bool fwd) {
+// Panel layout, round 5, REJECTED variant (-DJAMIE_PANEL=8 -DJAMIE_BN_PANEL_CQ2=1): with panels of 8 columns a strip of 8 columns
+// (CQ = 2, 256 threads) is one contiguous block per slab too, three such workgroups fit a CU (12 waves at 130 VGPRs), and config
+// 2's 2d-wide layers are then 750 strips = at most 3 per CU = 24 columns on the busiest CU against 32 now.  Measured: the step
+// 546.8 -> 574.3 us (profiles/r05_ab_panel8_cq2_rejected.log): the bf16 activations leave in 16-byte row segments and three
+// workgroups' load bursts share one CU's memory pipe; the balance is not what binds these launches.
+#ifndef JAMIE_BN_PANEL_CQ2
+#define JAMIE_BN_PANEL_CQ2 0
+#endif
+static int bn_pick_cq(long long strips16, bool needs16, bool fwd, bool panel = false, long long cols = 0) {
 #ifdef JAMIE_EXPERIMENTS      // (the experiments build's tests compare against 16-column strips: JAMIE_BN_CQ=4)
     const char* e = getenv(fwd ? "JAMIE_BN_CQ_FWD" : "JAMIE_BN_CQ_BWD");
     if (!e) e = getenv("JAMIE_BN_CQ");
@@ -650,7 +659,13 @@ static int bn_pick_cq(long long strips16, bool needs16, bool fwd) {
         return (!needs16 && (v == 2 || v == 8)) ? v : 4;
     }
 #endif
-    if (!fwd || needs16) return 4;
+    if (needs16) return 4;
+    if (panel && JAMIE_BN_PANEL_CQ2 && JAMIE_PANEL == 8 && cols > 0) {
+        const long long u8 = (cols + 7) / 8, u16 = (cols + 15) / 16;
+        const long long per8 = (u8 + 255) / 256, per16 = (u16 + 255) / 256;       // strips on the busiest CU
+        if (per8 <= 3 && per8 * 8 < per16 * 16) return 2;
+    }
+    if (!fwd) return 4;
     const long long r16 = (strips16 + 255) / 256, r32 = ((strips16 + 1) / 2 + 255) / 256;
     return (double)r32 * 1.6 < (double)r16 ? 8 : 4;
 }
@@ -686,8 +701,8 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
         d.panel = s.panel ? 1 : 0;
         if (s.panel) {
             any_panel = true;
-            const long long one = (long long)((s.N + 15) / 16) * 16 * s.B;          // floats of one slab in panels
-            JAMIE_ARG(s.nslab == 1 || s.slab_stride >= one, "panel layout: slab_stride >= ceil(N / 16) * 16 * B");
+            const long long one = (long long)((s.N + JAMIE_PANEL - 1) / JAMIE_PANEL) * JAMIE_PANEL * s.B;          // floats of one slab in panels
+            JAMIE_ARG(s.nslab == 1 || s.slab_stride >= one, "panel layout: slab_stride >= ceil(N / JAMIE_PANEL) * JAMIE_PANEL * B");
             JAMIE_ARG(((long long)(s.nslab - 1) * s.slab_stride + one) * 4 < 0xFFFFFFF0LL, "activation slabs must stay below 4 GiB");
         }
         d.blk_begin = blocks;
@@ -705,7 +720,9 @@ static int bn_act_fwd_impl(const jamie_bnact_fwd_problem* pr, int count, float p
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;        // (the float4 kernels carry the prefetch rider; the others ignore it)
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].outT_bf16 != nullptr;
-    int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16, true) : 4;
+    long long cols = 0;
+    for (int i = 0; i < count; ++i) cols += (pr[i].N + 7) / 8 * 8;
+    int cq = (wide && maxB <= 8 * BN4_RP) ? bn_pick_cq(blocks, needs16, true, any_panel, cols) : 4;
     if (cq == 8 && maxB > BN4_MAXR * BN4_RP) cq = 4;
     if (cq == 2) {                 // 8-column strips: the workgroup ranges of the problems again
         blocks = 0;
@@ -787,9 +804,9 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
         d.panel = s.panel ? 1 : 0;
         if (s.panel) {
             any_panel = true;
-            const long long one = (long long)((s.N + 15) / 16) * 16 * s.B;
+            const long long one = (long long)((s.N + JAMIE_PANEL - 1) / JAMIE_PANEL) * JAMIE_PANEL * s.B;
             JAMIE_ARG(s.skip_f32, "panel layout: dh leaves as bf16 only (skip_f32)");
-            JAMIE_ARG(s.nslab == 1 || s.slab_stride >= one, "panel layout: slab_stride >= ceil(N / 16) * 16 * B");
+            JAMIE_ARG(s.nslab == 1 || s.slab_stride >= one, "panel layout: slab_stride >= ceil(N / JAMIE_PANEL) * JAMIE_PANEL * B");
             JAMIE_ARG(((long long)(s.nslab - 1) * s.slab_stride + one) * 4 < 0xFFFFFFF0LL, "activation slabs must stay below 4 GiB");
         }
         blocks += 8 * (((s.N + BN_CW - 1) / BN_CW + 7) / 8);
@@ -820,7 +837,9 @@ static int bn_act_bwd_impl(const jamie_bnact_bwd_problem* pr, int count, float p
     const int pfb = pfr.n > 0 ? bn_pf_blocks() : 0;
     bool needs16 = false;
     for (int i = 0; i < count; ++i) needs16 = needs16 || pr[i].dhT_bf16 != nullptr;
-    int cq = wide4 ? bn_pick_cq(blocks, needs16, false) : 4;
+    long long cols = 0;
+    for (int i = 0; i < count; ++i) cols += (pr[i].N + 7) / 8 * 8;
+    int cq = wide4 ? bn_pick_cq(blocks, needs16, false, any_panel, cols) : 4;
     if (cq == 8 && maxB > BN4_MAXR * BN4_RP) cq = 4;
     if (cq == 2) {
         blocks = 0;

@@ -23,7 +23,7 @@ struct BnFwdDev {
     unsigned short* out_bf; unsigned short* outT_bf;
     long long slab_stride;
     int nslab, B, N, rng_stream, blk_begin;
-    int panel;           // h (every slab, and the sum written back) in panels of 16 columns: (row, col) at ((col / 16) * B + row) * 16 + col % 16
+    int panel;           // h (every slab, and the sum written back) in panels of P = JAMIE_PANEL columns: (row, col) at ((col / P) * B + row) * P + col % P
 };
 
 // Keep decision of element (row, col): 16 random bits against a 16-bit threshold.  One Philox call serves the 4
@@ -137,17 +137,18 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
     BN_STAMPV(5, __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) * 1000 + __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4));
     BN_STAMPV(6, P.N * 10 + P.nslab);
     const int B = P.B, N = P.N, nslab = P.nslab;
-    // panel layout (round 5; jamie_hip.h: JAMIE_PANEL): the 16 columns of a panel are contiguous for every row, the panels of a
-    // slab follow one another -- this strip's rows are ONE block of B x 64 bytes per slab (two for a 32-column strip) instead of
+    // panel layout (round 5; jamie_hip.h: JAMIE_PANEL): the columns of a panel are contiguous for every row, the panels of a
+    // slab follow one another -- this strip's rows are whole blocks of B x 4 JAMIE_PANEL bytes per slab instead of
     // B segments 4 N bytes apart: the slab loads, the statistics' only input, arrive 1.5-2 us earlier per launch
     // (profiles/r05_ab_bn_panel_timing.log)
     const bool pan = P.panel != 0;
-    const unsigned row_bytes = pan ? 64u : (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
-    const unsigned one_slab = pan ? (unsigned)((N + 15) >> 4) * (unsigned)B * 64u : (unsigned)B * (unsigned)N * 4u;
+    constexpr unsigned PW = JAMIE_PANEL, PB = 4u * JAMIE_PANEL;
+    const unsigned row_bytes = pan ? PB : (unsigned)N * 4u, slab_bytes = (unsigned)(P.slab_stride * 4);
+    const unsigned one_slab = pan ? (unsigned)((N + PW - 1) / PW) * (unsigned)B * PB : (unsigned)B * (unsigned)N * 4u;
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.h, 0, (int)((unsigned)(nslab - 1) * slab_bytes + one_slab), 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.mask, 0, P.mask ? B * N : 0, 0x00020000);
-    const unsigned coff = pan ? (unsigned)(col >> 4) * ((unsigned)B * 64u) + (unsigned)(col & 15) * 4u : (unsigned)col * 4u;
+    const unsigned coff = pan ? ((unsigned)col / PW) * ((unsigned)B * PB) + ((unsigned)col % PW) * 4u : (unsigned)col * 4u;
     unsigned roff[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -258,9 +259,12 @@ __device__ __forceinline__ void bn_fwd4_strip(const BnFwdDev& P, int col0, int t
         if (row < B && cok) {
             const long long o = (long long)row * N + col;
             if (nslab > 1) {      // (the summed pre-activation: next read by the backward pass, stored non-temporally)
-                float* hp = P.h + (pan ? (long long)(roff[j] >> 2) : o);
-                __builtin_nontemporal_store(v[j].x, hp); __builtin_nontemporal_store(v[j].y, hp + 1);
-                __builtin_nontemporal_store(v[j].z, hp + 2); __builtin_nontemporal_store(v[j].w, hp + 3);
+                // ONE 16-byte non-temporal store (a float4 vector: four scalar stores only merge while hipcc can prove the
+                // pointer's alignment -- behind the layout select it could not, and the store phase of the launch went from
+                // 1.3 to 3.0 us: profiles/r05_stamps_bn_fwd_panel.log)
+                typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+                bn_f32x4* hp = reinterpret_cast<bn_f32x4*>(P.h + (pan ? (long long)(roff[j] >> 2) : o));
+                __builtin_nontemporal_store((bn_f32x4){v[j].x, v[j].y, v[j].z, v[j].w}, hp);
             }
             const float hv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
             const float mv[4] = {mean.x, mean.y, mean.z, mean.w}, iv[4] = {invstd.x, invstd.y, invstd.z, invstd.w};

@@ -43,7 +43,7 @@ struct GemmBDev {
     int a_tr;            // A is [K, M] row-major (M contiguous), likewise (dW = dy^T a reads dy [B, out] and a [B, in])
     int store_nt;        // non-temporal output stores (weight gradients: next read by the optimiser, a whole backward pass later)
     int c_bf16;          // C is bf16 [M, ldc]: the fp32 accumulators are rounded once on the way out (weight gradients)
-    int c_panel;         // fp32 C in panels of 16 columns: (m, n) at ((n / 16) * M + m) * 16 + n % 16 (what the BatchNorm launches read)
+    int c_panel;         // fp32 C in panels of P = JAMIE_PANEL columns: (m, n) at ((n / P) * M + m) * P + n % P (what the BatchNorm launches read)
     unsigned a_bytes, b_bytes;
     float scale, pscale;
 };
@@ -546,6 +546,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_dma_kernel(GemmBGroup 
 // CONSECUTIVE n for one m, stored as one 16-byte access (4x fewer store instructions).
 // TRM = 0: no problem of the launch has a k-row-major operand (forward launches): the a_tr / b_tr paths are compiled out,
 // TRM = 1: per-problem flags (backward launches: dX reads W as stored, dW reads dy and a as stored)
+// (Round 5, measured neutral and taken out again: the eight tile counts as leading scalar kernel arguments delivered in SGPRs by
+//  hipcc's kernarg preload, -mllvm -amdgpu-kernarg-preload-count=8, so that the block decode starts without a scalar-memory
+//  round trip: 547.3 against 547.2 us per step, profiles/r05_ab_kernarg_preload_neutral.log -- the descriptor's own load behind
+//  the decode is the round trip that counts.)
 template <int BM, int BN, int WM, int WN, int TAG, int NB, int TRM, bool FUSE = false>
 __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const BnFuse* fz = nullptr) {
     constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
@@ -877,15 +881,17 @@ __device__ __forceinline__ void gemm_bf16_dma2_body(const GemmBGroup& g, const B
     // (~30 instructions and 6 branches each, 64-bit address arithmetic); here a piece is its bias add, (sum of squares,) pack and ONE
     // buffer store whose row offset is scalar -- the tile's CU slot is free again that much earlier (gemm_f32.hip, round 4).
     const unsigned c_elem = P.c_bf16 ? 2u : 4u;
-    // panel layout (c_panel; fp32 only, host-checked): a row of a 16-column panel is 64 bytes and the panels of a slab follow one
-    // another M x 64 bytes apart -- the row pitch and the column term of the offset change, nothing else does
+    // panel layout (c_panel; fp32 only, host-checked): a row of a panel is 4 JAMIE_PANEL bytes and the panels of a slab follow one
+    // another M rows apart -- the row pitch and the column term of the offset change, nothing else does
     const bool pan = !FUSE && P.c_panel != 0;
-    const unsigned long long c_ext = pan ? (unsigned long long)((P.N + 15) >> 4) * (unsigned long long)P.M * 64ull
+    constexpr unsigned PNW = JAMIE_PANEL, PNB = 4u * JAMIE_PANEL;          // panel width in columns / bytes per panel row
+    static_assert(JAMIE_PANEL % 4 == 0 && (JAMIE_PANEL & (JAMIE_PANEL - 1)) == 0, "a panel is a power of two of at least 4 columns");
+    const unsigned long long c_ext = pan ? (unsigned long long)((P.N + PNW - 1) / PNW) * (unsigned long long)P.M * PNB
                                          : ((unsigned long long)(P.M - 1) * (unsigned long long)P.ldc + (unsigned long long)P.N) * c_elem;
     if (!FUSE && P.epi == JAMIE_EPI_STORE && !P.accumulate && P.vec && (P.N & 3) == 0 && c_ext < 0xFFFFFFF0ull) {
         const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cout, 0, (int)(unsigned)c_ext, 0x00020000);
-        const unsigned ldcb = pan ? 64u : (unsigned)P.ldc * c_elem;
-        const unsigned coff = pan ? (unsigned)(nc >> 4) * ((unsigned)P.M * 64u) + (unsigned)(nc & 15) * 4u : (unsigned)nc * c_elem;
+        const unsigned ldcb = pan ? PNB : (unsigned)P.ldc * c_elem;
+        const unsigned coff = pan ? ((unsigned)nc / PNW) * ((unsigned)P.M * PNB) + ((unsigned)nc % PNW) * 4u : (unsigned)nc * c_elem;
         // (columns beyond N: an out-of-range offset from the start -- N % 4 == 0, a 16-byte piece is in or out whole; rows beyond M:
         //  a select per piece, in the edge tiles' instance only.  The edge tiles matter: in a one-round launch the slowest tile ends it.)
         const unsigned voff = nc < P.N ? (unsigned)(m0 + wm0 + rsub) * ldcb + coff : 0xFFFFFFF0u;
@@ -1186,10 +1192,10 @@ static int launch_dma(const jamie_gemm_problem* pr, int count, hipStream_t st, c
         d.b_tr = s.b_tr; d.a_tr = s.a_tr; d.store_nt = s.store_nt; d.c_bf16 = s.c_bf16; d.c_panel = s.c_panel;
         if (s.c_panel && !(V2 && s.epi == JAMIE_EPI_STORE && !s.accumulate && !s.c_bf16 && s.N % 4 == 0 && (uintptr_t)s.C % 16 == 0 &&
                            s.slab_stride % 4 == 0 && (!s.bias || (uintptr_t)s.bias % 16 == 0) &&
-                           (d.splitk == 1 || s.slab_stride >= (long long)((s.N + 15) / 16) * 16 * s.M) &&
-                           (long long)((s.N + 15) / 16) * s.M * 64 < 0xFFFFFFF0LL))
+                           (d.splitk == 1 || s.slab_stride >= (long long)((s.N + JAMIE_PANEL - 1) / JAMIE_PANEL) * JAMIE_PANEL * s.M) &&
+                           (long long)((s.N + JAMIE_PANEL - 1) / JAMIE_PANEL) * s.M * JAMIE_PANEL * 4 < 0xFFFFFFF0LL))
             return jamie_fail(-1, "%s: c_panel needs a large-tile configuration, a plain fp32 store, N %% 4 == 0, 16-byte aligned C / bias, "
-                                  "slab_stride >= ceil(N / 16) * 16 * M [%lld %lld]", "jamie_gemm_bf16", BM, BN);
+                                  "slab_stride >= ceil(N / JAMIE_PANEL) * JAMIE_PANEL * M [%lld %lld]", "jamie_gemm_bf16", BM, BN);
         if (s.c_bf16 && !(V2 && s.epi == JAMIE_EPI_STORE && !s.accumulate && d.splitk == 1 && s.bias == nullptr))
             return jamie_fail(-1, "%s: c_bf16 needs a large-tile configuration, a plain store, no bias, no accumulate, splitk == 1 [%lld %lld]",
                               "jamie_gemm_bf16", BM, BN);
@@ -1495,13 +1501,15 @@ __device__ __forceinline__ float4 JB_MSE_LD4(const float* p) {
     return make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
                        __builtin_nontemporal_load(p + 3));
 }
-struct MseDev { const float* y; const float* x; float* d; unsigned short* dst; unsigned short* dstT; float* partial;
+struct MseDev { const float* y; const float* x; float* d; unsigned short* dst; unsigned short* dstT; float* partial; float* colpart;
                 long long slab_stride; int R, C, nslab, blk_begin, tiles_c; float scale, pscale; };
 struct MseGroup { MseDev p[JAMIE_MAX_GROUP]; int count; };
 
 __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
     __shared__ float tile[64][65];
     __shared__ float red[4];
+    __shared__ float csum[4][64];
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     int pi = 0;
     for (int i = 1; i < JAMIE_MAX_GROUP; ++i)
         if (i < g.count && (int)blockIdx.x >= g.p[i].blk_begin) pi = i;
@@ -1550,7 +1558,7 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
                 v[0] = yv[pass].x - xv[pass].x; v[1] = yv[pass].y - xv[pass].y; v[2] = yv[pass].z - xv[pass].z; v[3] = yv[pass].w - xv[pass].w;
                 local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                 v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
-                *reinterpret_cast<float4*>(P.d + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (P.d) *reinterpret_cast<float4*>(P.d + o) = make_float4(v[0], v[1], v[2], v[3]);
                 if (P.dst) {
                     const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)v[0]), b1 = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
                     const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)v[2]), b3 = __builtin_bit_cast(unsigned short, (__bf16)v[3]);
@@ -1563,15 +1571,30 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
                     v[e] -= P.x[o + e];
                     local += v[e] * v[e];
                     v[e] *= P.scale;
-                    P.d[o + e] = v[e];
+                    if (P.d) P.d[o + e] = v[e];
                     if (P.dst) P.dst[o + e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
                 }
             }
         }
         tile[rr][4 * q] = v[0]; tile[rr][4 * q + 1] = v[1]; tile[rr][4 * q + 2] = v[2]; tile[rr][4 * q + 3] = v[3];
+        cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];          // (column sums of d: this thread's rows rr0 + 16 pass)
     }
     const float tot = block_sum(local, red);
     if (threadIdx.x == 0 && P.partial) P.partial[b] = tot * P.pscale;
+    if (P.colpart) {            // (uniform) column sums of this tile's 64 rows of d (rows beyond R hold 0), in a fixed order:
+        // a thread's four rows (rr0 + 16 pass), the four row phases of its wave by xor-shuffles, the four waves through LDS
+        // (a serial 64-row loop by 64 threads cost the launch 1.7 us: profiles/r05_ab_mse_colpart.log)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], 16); cs[e] += __shfl_xor(cs[e], 32); }
+        const int wvx = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[wvx][4 * q + e] = cs[e];
+        }
+        __syncthreads();
+        const int cc = threadIdx.x;
+        if (cc < 64 && c0 + cc < P.C) P.colpart[(long long)(r0 >> 6) * P.C + c0 + cc] = (csum[0][cc] + csum[1][cc]) + (csum[2][cc] + csum[3][cc]);
+    }
     if (!P.dstT) return;
     __syncthreads();
     const bool vect = (P.R % 4 == 0);
@@ -1603,14 +1626,15 @@ extern "C" int jamie_mse_cast(const jamie_mse_problem* pr, int count, void* stre
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
         const jamie_mse_problem& s = pr[i];
-        JAMIE_ARG(s.y && s.x && s.d && s.R > 0 && s.C > 0 && s.nslab >= 1, "null pointer / empty problem");
+        JAMIE_ARG(s.y && s.x && s.R > 0 && s.C > 0 && s.nslab >= 1, "null pointer / empty problem");
+        JAMIE_ARG(s.d || s.d_bf16 || s.dT_bf16, "no output requested");
         JAMIE_ARG(((uintptr_t)s.y % 16) == 0 && ((uintptr_t)s.x % 16) == 0 && ((uintptr_t)s.d % 16) == 0 &&
                       ((uintptr_t)s.d_bf16 % 8) == 0 && ((uintptr_t)s.dT_bf16 % 8) == 0,
                   "y, x, d must be 16-byte aligned (bf16 outputs 8-byte)");
         MseDev& d = g.p[i];
         d.y = s.y; d.x = s.x; d.d = s.d; d.dst = (unsigned short*)s.d_bf16; d.dstT = (unsigned short*)s.dT_bf16;
         d.partial = s.partial; d.slab_stride = s.slab_stride; d.R = s.R; d.C = s.C; d.nslab = s.nslab;
-        d.scale = s.scale; d.pscale = s.pscale;
+        d.scale = s.scale; d.pscale = s.pscale; d.colpart = s.colpart;
         d.blk_begin = blocks; d.tiles_c = (s.C + 63) / 64;
         blocks += ((s.R + 63) / 64) * d.tiles_c;
     }

@@ -532,7 +532,10 @@ struct LatMDev {
     const float* head_W[LM]; float* da2[LM];
     unsigned short* dec0_WT[LM];  // optional: bf16 [L, d] transposed copy of W_dec0 (written by the forward launch's row-block-0 chunks)
     int bchunk_begin[LM + 1];     // column chunks of that product (chunk 0: the owner workgroups), prefix sums
-    int g1_panel, da2_panel;      // g1 / da2 in panels of 16 columns ((b, c) at ((c / 16) * B + b) * 16 + c % 16): what BatchNorm reads
+    int g1_panel, da2_panel;      // g1 / da2 in panels of P = JAMIE_PANEL columns ((b, c) at ((c / P) * B + b) * P + c % P): what BatchNorm reads
+    // heads product inside the forward launch (round 5): mu | logvar = a2_i [B, d_i] (bf16) x head_W16_i [2L, d_i]^T (bf16), fp32
+    // accumulation -- what the heads GEMM launch + its split-K slabs were (`ml` unused then)
+    const unsigned short* heads_a[LM]; const unsigned short* heads_W[LM];
 };
 
 // ---- forward: ONE launch from the heads' split-K slabs to the decoder's first pre-activation ----
@@ -553,6 +556,11 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
     __shared__ float Ws[COLS][LMAX + 1];
     __shared__ float Cs[LF_ROWS][LMAX + 2];            // (+2: the MFMA operand read Cs[lane & 31][k + (lane >> 5)] is conflict-free)
     __shared__ float red[(LF_NT / 64 + 1) * (3 * LM + 1)];
+    // heads product (heads_a given): per-wave partial sums [waves / 2][col tiles][16][64] for the tree over the 16 waves' K
+    // ranges, then the row block's mu | logvar of every modality [MM][LF_ROWS][2 LMAX + 1]; LMAX <= 64 only (128: the GEMM launch)
+    constexpr int HT = LMAX <= 64 ? 2 * LMAX / 32 : 1;                      // 32-column tiles of mu | logvar
+    __shared__ float Hp[LMAX <= 64 ? 4 * HT * 16 * 64 : 1];               // four waves' partial sums at a time
+    __shared__ float Ms[LMAX <= 64 ? LF_ROWS * (2 * LMAX + 1) : 1];        // one modality's mu | logvar of the row block
     constexpr int M = MM;
     const int B = a.B, L = a.L, tid = threadIdx.x;
     const int n_rb = (B + LF_ROWS - 1) / LF_ROWS;
@@ -609,7 +617,110 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
             v_lv[j][i] = (i < M && ok) ? a.head_bias[i][L + l] : 0.f;
         }
     }
-    for (int s0 = 0; s0 < a.ml_nslab; s0 += TRIP) {       // TRIP slabs' loads in flight per round trip, added in slab order
+    const bool heads_here = LMAX <= 64 && a.heads_a[0] != nullptr;          // (uniform)
+    if constexpr (LMAX <= 64) {
+    if (heads_here) {
+        // ---- the heads' product for this row block (model.py:180,185: mu | logvar = a2 W_h^T), every modality: the operands are
+        // what the heads GEMM launch read (bf16 a2 as BatchNorm stored it, the bf16 weight copy), fp32 accumulation.  The 16 waves
+        // split K; a wave multiplies its K range on the matrix pipe (32x32x16: M = 32 columns of mu | logvar per tile, N = the 32
+        // cells) with the fragments loaded straight from global memory (W_h is 2L x d: every workgroup of the launch reads all of
+        // it through L2 -- 0.4 MB at config 2, the floor of this phase: ~6 us at the 55-66 GB/s a CU takes in), then the partial
+        // sums are added in a fixed tree through LDS.  Replaces the heads GEMM launch and its 8 + 8 split-K slabs.
+        typedef float hf32x16 __attribute__((ext_vector_type(16)));
+        typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+        typedef unsigned int hu32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NWV = LF_NT / 64;
+        const int wv = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+        const int tiles = (2 * L + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            if (i >= M) continue;
+            const int dd = a.d[i];
+            const int nks = (dd + 15) >> 4, per = (nks + NWV - 1) / NWV;
+            const int k_lo = wv * per, k_hi = min(nks, k_lo + per);
+            const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.heads_a[i], 0, B * dd * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.heads_W[i], 0, 2 * L * dd * 2, 0x00020000);
+            const unsigned arow = (unsigned)min(r0 + r, B - 1) * (unsigned)dd * 2u + 16u * hh;      // (cells beyond B repeat the last one: unused)
+            unsigned wrow[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) wrow[t] = (32 * t + r < 2 * L) ? (unsigned)(32 * t + r) * (unsigned)dd * 2u + 16u * hh : 0xFFFFFFF0u;
+            hf32x16 acc[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            // (KU k-steps per trip: their loads go out together; a k-step's second half may lie beyond d -- d is a multiple of 8 -- and
+            //  reads as zero: the per-lane offset is swapped for an out-of-range one, the row's neighbour must not leak in)
+            constexpr int KU = LMAX <= 32 ? 2 : 1;          // k-steps whose loads go out together (registers: 128 per lane at 1024 threads)
+#pragma unroll 1
+            for (int ks = k_lo; ks < k_hi; ks += KU) {
+                hu32x4 fa[KU], fw[KU][HT];
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    const int k0 = 16 * (ks + u);
+                    const bool in = ks + u < k_hi && k0 + 8 * hh < dd;
+                    fa[u] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, in ? (int)(arow + 2u * (unsigned)k0) : (int)0xFFFFFFF0u, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+                        fw[u][t] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (in && wrow[t] != 0xFFFFFFF0u) ? (int)(wrow[t] + 2u * (unsigned)k0) : (int)0xFFFFFFF0u, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+                        if (t < tiles)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fw[u][t]), __builtin_bit_cast(hbf16x8, fa[u]),
+                                                                            acc[t], 0, 0, 0);
+            }
+            // the 16 waves' sums added in a FIXED order through a 4-slot LDS buffer: waves [lo, lo + n) store, waves [to, to + n)
+            // add their partner's sum: (12..15 -> 8..11), (4..7 -> 0..3), (8..11 -> 0..3), (2, 3 -> 0, 1), (1 -> 0)
+            static_assert(NWV == 16, "the wave tree below is written for 16 waves");
+            // (the wave index as a SCALAR and the slot's base as one pointer: with `wv - lo` left to the compiler it folded the
+            //  negative constant into every access, 32 address registers per fold, all spilled)
+            const int wvs = __builtin_amdgcn_readfirstlane(wv);
+            auto fold = [&](int lo, int to, int n) {
+                if (wvs >= lo && wvs < lo + n) {
+                    float* hp = Hp + (wvs - lo) * (HT * 16 * 64) + lane;
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) hp[(t * 16 + e) * 64] = acc[t][e];
+                }
+                lds_barrier();
+                if (wvs >= to && wvs < to + n) {
+                    const float* hp = Hp + (wvs - to) * (HT * 16 * 64) + lane;
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[t][e] += hp[(t * 16 + e) * 64];
+                }
+                lds_barrier();
+            };
+            fold(12, 8, 4); fold(4, 0, 4); fold(8, 0, 4); fold(2, 0, 2); fold(1, 0, 1);
+            // wave 0 holds the sums: D[column 32 t + (e & 3) + 8 (e >> 2) + 4 hh][cell r] -> Ms[cell][column]
+            if (wvs == 0) {
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int c = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (c < 2 * L) Ms[r * (2 * LMAX + 1) + c] = acc[t][e];
+                    }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int el = tid + LF_NT * j;
+                const int row = el / L, l = el % L, b = r0 + row;
+                if (el >= LF_ROWS * L || b >= B) continue;
+                v_mu[j][i] += Ms[row * (2 * LMAX + 1) + l];
+                v_lv[j][i] += Ms[row * (2 * LMAX + 1) + L + l];
+            }
+            lds_barrier();               // (Ms is rewritten for the next modality)
+        }
+    }
+    }
+    for (int s0 = 0; s0 < (heads_here ? 0 : a.ml_nslab); s0 += TRIP) {       // TRIP slabs' loads in flight per round trip, added in slab order
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int el = tid + LF_NT * j;
@@ -747,9 +858,9 @@ __global__ __launch_bounds__(LF_NT) void latent_m_fwd_kernel(LatMDev a, const ui
         }
         LSTAMP(a, 4);
         if (ocol < a.d[mi]) {
-            // (panel layout: a row of a 16-column panel is 16 floats, the panels follow one another B rows apart)
-            float* out = a.g1[mi] + (a.g1_panel ? (long long)(ocol >> 4) * B * 16 + (ocol & 15) : (long long)ocol);
-            const long long pitch = a.g1_panel ? 16 : a.d[mi];
+            // (panel layout: a row of a panel is JAMIE_PANEL floats, the panels follow one another B rows apart)
+            float* out = a.g1[mi] + (a.g1_panel ? (long long)(ocol / JAMIE_PANEL) * B * JAMIE_PANEL + (ocol % JAMIE_PANEL) : (long long)ocol);
+            const long long pitch = a.g1_panel ? JAMIE_PANEL : a.d[mi];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int b = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -933,8 +1044,8 @@ __global__ __launch_bounds__(LF_NT) void latent_m_bwd_kernel(LatMDev a, SampleAr
         LSTAMP(a, 13);
         const int col = c0 + wv * 32 + r;
         if (col < a.d[mi]) {
-            float* out = a.da2[mi] + (a.da2_panel ? (long long)(col >> 4) * B * 16 + (col & 15) : (long long)col);
-            const long long pitch = a.da2_panel ? 16 : a.d[mi];
+            float* out = a.da2[mi] + (a.da2_panel ? (long long)(col / JAMIE_PANEL) * B * JAMIE_PANEL + (col % JAMIE_PANEL) : (long long)col);
+            const long long pitch = a.da2_panel ? JAMIE_PANEL : a.d[mi];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int b = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1059,6 +1170,14 @@ static int latm_to_dev(const jamie_latent_m* a, LatMDev& d) {
     d.losses = a->losses; d.rng_stream = a->rng_stream;
     d.defer_final = a->defer_final;
     d.g1_panel = a->g1_panel ? 1 : 0; d.da2_panel = a->da2_panel ? 1 : 0;
+    for (int i = 0; i < a->M; ++i) {
+        d.heads_a[i] = (const unsigned short*)a->heads_a_bf16[i]; d.heads_W[i] = (const unsigned short*)a->heads_W_bf16[i];
+        JAMIE_ARG((a->heads_a_bf16[i] != nullptr) == (a->heads_a_bf16[0] != nullptr) && (a->heads_W_bf16[i] != nullptr) == (a->heads_a_bf16[0] != nullptr),
+                  "heads product: a2 and W for every modality or for none");
+        JAMIE_ARG(!a->heads_a_bf16[i] || (a->L <= 64 && a->d[i] > 0 && a->d[i] % 8 == 0 && (uintptr_t)a->heads_a_bf16[i] % 16 == 0 &&
+                                          (uintptr_t)a->heads_W_bf16[i] % 16 == 0 && (long long)a->B * a->d[i] * 2 < 0x7FFFFFF0LL),
+                  "heads product: L <= 64, d a multiple of 8, 16-byte aligned bf16 operands");
+    }
     jamie_latent_m_fill_final(a, &d.fin);
     return 0;
 }
@@ -1069,10 +1188,10 @@ extern "C" int jamie_latent_m_fwd(const jamie_latent_m* a, const uint64_t* rng, 
     if (rc) return rc;
     bool need_rng = false;
     for (int i = 0; i < a->M; ++i) {
-        JAMIE_ARG(a->ml[i] && a->head_bias[i], "heads input");
+        JAMIE_ARG((a->ml[i] || a->heads_a_bf16[i]) && a->head_bias[i], "heads input");
         if (!a->eps_in[i]) need_rng = true;
     }
-    JAMIE_ARG(a->ml_nslab >= 1 && (a->ml_nslab == 1 || a->ml_slab_stride >= (long long)a->B * 2 * a->L), "ml slabs");
+    JAMIE_ARG(a->heads_a_bf16[0] || (a->ml_nslab >= 1 && (a->ml_nslab == 1 || a->ml_slab_stride >= (long long)a->B * 2 * a->L)), "ml slabs");
     JAMIE_ARG(!need_rng || rng, "rng state required when eps is not given");
     // chunk 0 must exist and belong to a workgroup that stores the latents: with no decoder product at all there is one
     const int n_rb = (a->B + LF_ROWS - 1) / LF_ROWS;

@@ -7,6 +7,7 @@ thread_local char g_jamie_err[512] = {0};
 
 extern "C" const char* jamie_last_error(void) { return g_jamie_err; }
 extern "C" int jamie_version(void) { return 100; }
+extern "C" int jamie_panel_width(void) { return JAMIE_PANEL; }
 extern "C" int jamie_max_partials(void) { return JAMIE_MAX_PARTIALS; }
 extern "C" int jamie_max_norm_partials(void) { return JAMIE_MAX_NORM_PARTIALS; }
 

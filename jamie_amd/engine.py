@@ -42,8 +42,14 @@ TUNING = {
                                   # OFF until an N > 1 A/B shows a gain: it adds a launch to the tail of the backward pass and turns
                                   # the merged rep + enc0 message into three all-reduces (~28 us of host enqueue each); bench.py
                                   # --tune split_last_dw=True is the A/B for the first multi-GPU box
+    'fused_heads': False,         # bf16 mode, fused latent kernels, L <= 64: the heads' product mu | logvar = a2 W_h^T inside the latent forward
+                                  # launch (every workgroup multiplies its 32 cells' rows by the whole 2L x d weight) instead of a GEMM launch
+                                  # + 8 split-K slabs.  Built, bit-checked (tests/test_hip_configs.py) and measured SLOWER in round 5: +10.4 us
+                                  # per step (profiles/r05_ab_fused_heads_rejected.log) -- a workgroup has to pull the whole weight (0.4 MB)
+                                  # and its cells' rows (0.2 MB) through ONE CU's 55-66 GB/s: ~10 us, more than the split-K launch it replaces
+    'mse_colpart': True,          # the decoder's output-bias gradient from jamie_mse_cast's per-tile column sums (no fp32 d x_hat in bf16 mode)
     'bn_panel': True,             # bf16 mode: the fp32 pre-activations / upstream gradients travel GEMM -> BatchNorm (-> BatchNorm backward)
-                                  # in panels of 16 columns (jamie_hip.h: JAMIE_PANEL): a BatchNorm strip is one contiguous block per slab
+                                  # in panels of 16 columns (jamie_hip.h: JAMIE_PANEL): a BatchNorm strip is whole contiguous blocks per slab
     'f32_pipe_solo': 'enc0,enc1',  # fp32, pipelined optimiser: the forward launches of these layers run beside clip + Adam on the optimiser
                                   # stream and take tile configuration 19 (= 17 at ONE workgroup per CU: half of each CU's wave slots
                                   # stay free for the streaming kernel); '' = off
@@ -95,7 +101,7 @@ def choose_splitk(M, N, K, bm=64, bn=64):
 BF16_CFG_ROWS_WIDE, BF16_CFG_ROWS, BF16_CFG_DW = 31, 32, 29
 BF16_TILE = {23: (256, 128), 24: (128, 128), 25: (128, 128), 29: (128, 128), 30: (128, 128), 31: (256, 128), 32: (128, 128)}
 N_CU = 256
-PANEL = 16                  # jamie_hip.h: JAMIE_PANEL
+PANEL = 16                  # jamie_hip.h: JAMIE_PANEL (TrainEngine reads the library's own value: jamie_panel_width)
 PANEL_KEYS = ('h1', 'h2', 'g1', 'g2', 'de2', 'de1', 'da2', 'da1')      # what a BatchNorm launch reads as fp32: GEMM slabs and their sums
 
 
@@ -356,6 +362,7 @@ class TrainEngine:
         # g1_panel / da2_panel), BatchNorm forward writes the summed pre-activation back in it and BatchNorm backward reads it; the
         # activations / gradients that leave a BatchNorm launch are bf16 row-major as before.  Which layers take it is decided per
         # step (_set_panels): a layer's buffers are in panels only when BOTH its forward and its backward producer can write them.
+        self.PANEL = int(nv.load().jamie_panel_width())
         self.panel = bool(self.bf16 and self.fuse_bf16 and TUNING['bn_panel'] and all(d % 4 == 0 for d in self.dims)
                           and all(self.gcfg.get(k, -1) in BF16_TILE for k in ('enc0', 'enc1', 'dec1', 'd_e2', 'd_e1', 'd_a1')))
         self._pan = {'bn0': False, 'bn1': False, 'bn2': False, 'bn3': False}
@@ -388,6 +395,9 @@ class TrainEngine:
             w['dxhat'] = torch.empty(B, d, **f32)
             if self.gcfg.get('dec2', -1) >= 0 or self.fcfg.get('dec2', -1) >= 0:   # split-K x_hat slabs, MSE in jamie_mse_cast
                 w['xh'] = torch.empty(sk['dec2'], B, d, **f32)
+                # ... which also leaves the column sums of d x_hat per 64-row tile: the decoder's output-bias gradient is then a sum
+                # of B / 64 rows (and in bf16 mode nothing reads an fp32 d x_hat any more: it is not written)
+                w['dxhat_cp'] = torch.zeros((B + 63) // 64, d, **f32)
             w['de2'] = self._slabs(sk['d_e2'], 2 * d)
             w['de1'] = self._slabs(sk['d_e1'], d)
             w['dcomb'] = torch.empty(sk['d_comb'] + 1, B, L, **f32)   # +1 slab: external d(combined) (autograd seam)
@@ -508,6 +518,7 @@ class TrainEngine:
         self._zs = None                  # enable_sharded_optimizer(): packed shard state of a data-parallel run
         self._dw_wait = None             # fp32 backward pass: the large layers' dW products waiting for _flush_dw
         self._dw_small = []              # ... and the skinny layers' that go with them
+        self._dxhat_cs = 'dxhat'         # which buffer the decoder's output-bias gradient is summed from (_forward)
         self.side_transposes, self._wT_pending, self._wT_stale = False, False, False
 
     # ---- pipelined optimiser: clip + Adam of step t on a second HIP stream, under the forward pass of step t+1 ----
@@ -737,7 +748,7 @@ class TrainEngine:
         what the buffer holds whenever its layer does NOT take the panel layout in a step (rows(): either layout as [S, B, N])."""
         if not self.panel:
             return torch.empty(S, self.B, N, device=self.dev, dtype=torch.float32)
-        npad = (N + PANEL - 1) // PANEL * PANEL
+        npad = (N + self.PANEL - 1) // self.PANEL * self.PANEL
         flat = torch.zeros(S * self.B * npad, device=self.dev, dtype=torch.float32)
         return torch.as_strided(flat, (S, self.B, N), (self.B * npad, N, 1))
 
@@ -758,6 +769,7 @@ class TrainEngine:
         if not self._paneled(key):
             return t
         S, B, N = t.shape
+        PANEL = self.PANEL
         npad = (N + PANEL - 1) // PANEL * PANEL
         flat = torch.as_strided(t, (S, npad // PANEL, B, PANEL), (B * npad, B * PANEL, PANEL, 1))
         return flat.permute(0, 2, 1, 3).reshape(S, B, npad)[:, :, :N]
@@ -1110,6 +1122,8 @@ class TrainEngine:
                 d.head_W[i], d.da2[i] = nv.ptr(self.m.p[f'm{i}.head.W']), nv.ptr(w['da2'])
                 d.da2_panel = int(self._paneled('da2'))
             if self.bf16:
+                if getattr(self, '_heads_in_latent', False):
+                    d.heads_a_bf16[i], d.heads_W_bf16[i] = nv.ptr(w['a2_bf']), nv.ptr(self.wbf[f'm{i}.head.W'])
                 d.dml_bf16[i] = nv.ptr(w['dml_bf'])
                 d.dmlT_bf16[i] = nv.ptr(w['dml_T']) if 'dml' in self.need_T else None
                 d.comb_bf16[i] = nv.ptr(w['comb_bf'])
@@ -1274,12 +1288,15 @@ class TrainEngine:
 
     def _forward(self, corr, Fblk, noise, fused_losses):
         B, L = self.B, self.L
+        self._dxhat_cs = 'dxhat'
         self._set_panels(fused_losses and self._fused_latent(corr, Fblk))
         # ---------------- forward ----------------
         self._fwd_block('x', 'enc0', 'h1', 'enc0', 'bn0', 'a1', 10, noise, 'enc_masks', 0)
         self._fwd_block('a1', 'enc1', 'h2', 'enc1', 'bn1', 'a2', 11, noise, 'enc_masks', 1)
-        self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)
         fused = fused_losses and self._fused_latent(corr, Fblk)
+        self._heads_in_latent = bool(fused and self.bf16 and self.L <= 64 and TUNING['fused_heads'])
+        if not self._heads_in_latent:
+            self._fwd_gemm('a2', 'head', 'ml', 'head', with_bias=False)
         lat = self._latent_desc(corr, Fblk, noise, fused)
         nv.latent_fwd(lat, self.state)
         if not fused:            # (the fused kernel has written g1 = comb W^T + b and the bf16 copies of comb itself)
@@ -1300,11 +1317,15 @@ class TrainEngine:
             for i, d in enumerate(self.dims):
                 w = self.ws[i]
                 rd = self.rdims[i]
-                probs.append(nv.mse_problem(w['xh'], w['x'], w['dxhat'], w.get('dxhat_bf'), w['dxhat_T'] if 'dxhat' in self.need_T else None,
+                cp = bool(TUNING['mse_colpart'])
+                probs.append(nv.mse_problem(w['xh'], w['x'], None if (self.bf16 and cp) else w['dxhat'], w.get('dxhat_bf'),
+                                            w['dxhat_T'] if 'dxhat' in self.need_T else None,
                                             partial=self.rec_partials[off:off + self.rec_tiles[i]],
-                                            scale=self.loss_weights[1] * 2.0 / (B * rd), pscale=1.0 / (B * rd)))
+                                            scale=self.loss_weights[1] * 2.0 / (B * rd), pscale=1.0 / (B * rd),
+                                            colpart=w['dxhat_cp'] if cp else None))
                 off += self.rec_tiles[i]
             nv.mse_cast(probs)
+            self._dxhat_cs = 'dxhat_cp' if TUNING['mse_colpart'] else 'dxhat'
             return lat
         probs, off = [], 0
         for i, d in enumerate(self.dims):                                 # x_hat GEMM + fused MSE
@@ -1397,7 +1418,8 @@ class TrainEngine:
         # workgroups (47 short ones beside 375 long ones) instead of being a launch of its own at the head of the backward
         # pass (with a gradient exchange too: the biases live in region `rep`, which is announced last)
         ride = bool(TUNING['cs_ride'])
-        cs_items = [(self.ws[i]['dxhat'], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))]
+        # (column sums of d x_hat: of the per-tile sums jamie_mse_cast left, where that launch made d x_hat; of d x_hat itself otherwise)
+        cs_items = [(self.ws[i][self._dxhat_cs], self.g[f'm{i}.dec2.b']) for i in range(len(self.dims))]
         if not ride:
             nv.colsum_group(cs_items, acc)
         self._bwd_gemms('dxhat', 'dec2', 'e2', 'de2', 'd_e2', ranges=dr.get('dec2'))

@@ -96,7 +96,12 @@ def _check_products_against_stored_operands(eng, model, noise, p):
         for a, lin, h in (('x', 'enc0', 'h1'), ('a1', 'enc1', 'h2'), ('e1', 'dec1', 'g2')):
             want = bfl(w[a + '_bf']) @ bfl(wb[f'm{i}.{lin}.W']).t() + P_[f'm{i}.{lin}.b']
             assert _rel(eng.rows(i, h)[0], want) < 5e-5, (i, lin, 'forward', _rel(eng.rows(i, h)[0], want))
-        assert _rel(w['ml'].sum(0), bfl(w['a2_bf']) @ bfl(wb[f'm{i}.head.W']).t()) < 5e-5, (i, 'head forward')
+        want_ml = bfl(w['a2_bf']) @ bfl(wb[f'm{i}.head.W']).t()
+        if getattr(eng, '_heads_in_latent', False):      # the product lives inside the latent forward launch: mu | logvar = product + bias
+            got_ml = torch.cat([w['mu'], w['lv']], 1) - P_[f'm{i}.head.b']
+            assert _rel(got_ml, want_ml) < 5e-5, (i, 'head forward (inside the latent launch)', _rel(got_ml, want_ml))
+        else:
+            assert _rel(w['ml'].sum(0), want_ml) < 5e-5, (i, 'head forward')
         if 'xh' in w:
             want = bfl(w['e2_bf']) @ bfl(wb[f'm{i}.dec2.W']).t() + P_[f'm{i}.dec2.b']
             assert _rel(w['xh'].sum(0), want) < 5e-5, (i, 'dec2 forward')

@@ -1107,6 +1107,16 @@ def test_mse_cast_matches_torch(nv, R, C, nslab):
     # tile order: m fastest (the 64x64 GEMM's fused epilogue)
     t0 = (diff[:64, :64].double() ** 2).sum().item() * pscale
     assert abs(part[0].item() - t0) < 1e-5 * t0
+    # without an fp32 output, with the per-tile column sums (round 5: the decoder's output-bias gradient is summed from them)
+    db2 = torch.zeros_like(db)
+    cp = torch.full(((R + 63) // 64, C), float('nan'), device='cuda')
+    nv.mse_cast([nv.mse_problem(y, x, None, db2, None, scale=scale, pscale=pscale, colpart=cp)])
+    torch.cuda.synchronize()
+    assert torch.equal(db2, db)
+    want = torch.stack([d[r0:r0 + 64].double().sum(0) for r0 in range(0, R, 64)])
+    assert torch.allclose(cp.double(), want, rtol=1e-5, atol=1e-9) and torch.allclose(cp.sum(0).double(), d.double().sum(0), rtol=1e-5, atol=1e-9)
+    with pytest.raises(nv.JamieHipError):
+        nv.mse_cast([nv.mse_problem(y, x, None, scale=scale)])
 
 
 @pytest.mark.parametrize('R,C', [(64, 64), (100, 72), (2000, 1000), (33, 201)])
@@ -1194,23 +1204,30 @@ def test_bn_prefetch_rider_changes_nothing(nv):
 
 
 # ---- panel layout of the BatchNorm launches' fp32 inputs (round 5; include/jamie_hip.h: JAMIE_PANEL) ----
-def _to_panels(t, npad=None):
-    """[S, B, N] row-major -> the same values in panels of 16 columns: flat [S, ceil(N / 16) * 16 * B]."""
+def _pw():
+    from jamie_amd import _native
+    return int(_native.load().jamie_panel_width())
+
+
+def _to_panels(t):
+    """[S, B, N] row-major -> the same values in panels of P = jamie_panel_width() columns: flat [S, ceil(N / P) * P * B]."""
     S, B, N = t.shape
-    npad = (N + 15) // 16 * 16
+    P = _pw()
+    npad = (N + P - 1) // P * P
     p = torch.zeros(S, B, npad, dtype=t.dtype, device=t.device)
     p[:, :, :N] = t
-    return p.reshape(S, B, npad // 16, 16).permute(0, 2, 1, 3).contiguous().reshape(S, -1)
+    return p.reshape(S, B, npad // P, P).permute(0, 2, 1, 3).contiguous().reshape(S, -1)
 
 
 def _from_panels(flat, B, N):
     S = flat.shape[0]
-    npad = (N + 15) // 16 * 16
-    return flat.reshape(S, npad // 16, B, 16).permute(0, 2, 1, 3).reshape(S, B, npad)[:, :, :N]
+    P = _pw()
+    npad = (N + P - 1) // P * P
+    return flat.reshape(S, npad // P, B, P).permute(0, 2, 1, 3).reshape(S, B, npad)[:, :, :N]
 
 
 @pytest.mark.parametrize('M,N,K,sk,cfg', [(512, 2000, 1000, 2, 31), (512, 1000, 2000, 3, 32), (512, 264, 512, 1, 29),
-                                           (300, 520, 256, 2, 23), (512, 504, 512, 1, 24)])
+                                           (300, 524, 256, 2, 23), (512, 508, 512, 1, 24)])
 def test_gemm_bf16_panel_store_equals_row_major_store(nv, M, N, K, sk, cfg):
     """c_panel: every slab of C in panels of 16 columns -- element (m, n) at ((n / 16) * M + m) * 16 + n % 16 -- holds bit for bit
     what the row-major store of the same launch holds (edge tiles in M and N, ragged last panel, bias on slab 0 only)."""
@@ -1219,13 +1236,14 @@ def test_gemm_bf16_panel_store_equals_row_major_store(nv, M, N, K, sk, cfg):
     A, W, bd = dev(a), dev(w), dev(bias)
     ref = torch.full((sk, M, N), float('nan'), device='cuda')
     nv.gemm_bf16([nv.gemm_problem(A, W, ref, M, N, K, K, K, N, bias=bd, splitk=sk, slab_stride=M * N)], cfg)
-    npad = (N + 15) // 16 * 16
+    P = _pw()
+    npad = (N + P - 1) // P * P
     out = torch.full((sk, M * npad), float('nan'), device='cuda')
     nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N, bias=bd, splitk=sk, slab_stride=M * npad, c_panel=True)], cfg)
     assert torch.equal(_from_panels(out, M, N), ref)
     # the padding columns of a ragged last panel are never written
     if npad != N:
-        pad = out.reshape(sk, npad // 16, M, 16)[:, -1, :, N % 16:]
+        pad = out.reshape(sk, npad // P, M, P)[:, -1, :, N % P:]
         assert torch.isnan(pad).all()
     with pytest.raises(nv.JamieHipError):          # small-tile configurations cannot write panels
         nv.gemm_bf16([nv.gemm_problem(A, W, out, M, N, K, K, K, N, bias=bd, splitk=sk, slab_stride=M * npad, c_panel=True)], 7)
@@ -1265,12 +1283,24 @@ def test_bn_act_panel_inputs_equal_row_major_inputs(nv, B, N, p, nslab):
         h0 = _from_panels(hd[:1], B, N)[0] if panel else hd[0]
         return out_bf, rm, rv, sm, si, h0.clone(), dh_bf, dg, db, dl
     a, b = run(False), run(True)
+    # (the panel launches may take another strip width -- 8 columns where that halves the busiest CU's columns -- so the column
+    #  statistics are summed in another order: equal to fp32 rounding, the bf16 outputs equal except where a value sits on a
+    #  rounding boundary)
     for x, y, name in zip(a, b, ('out', 'running_mean', 'running_var', 'save_mean', 'save_invstd', 'h sum', 'dh', 'dgamma', 'dbeta', 'dbias')):
-        assert torch.equal(x, y), name
+        if x.dtype == torch.bfloat16:
+            off = x != y
+            assert float(off.float().mean()) < 2e-3, (name, float(off.float().mean()))
+            assert float((x.float() - y.float()).abs().max()) <= 2 ** -7 * float(x.float().abs().max()), name
+        elif name == 'h sum':
+            assert torch.equal(x, y), name                      # (the slab sums are per element: no reduction order involved)
+        elif name == 'dbias':
+            assert float((x - y).abs().max()) < 1e-3, name      # (column sums of dh: mathematically zero)
+        else:
+            close(x, y.cpu().double(), rtol=2e-5, atol=2e-5 if name in ('dgamma', 'dbeta') else 1e-6)
     close(a[5], hs.sum(0), rtol=1e-6, atol=1e-6)
     # a panel-layout backward launch cannot write the fp32 dh in place (its input is in another layout)
     pb = nv.BnBwdProblem()
-    t = torch.zeros(1, B * ((N + 15) // 16 * 16), device='cuda')
+    t = torch.zeros(1, B * ((N + _pw() - 1) // _pw() * _pw()), device='cuda')
     pb.da, pb.nslab, pb.slab_stride, pb.h = nv.ptr(t), 1, t.shape[1], nv.ptr(t)
     pb.gamma, pb.beta, pb.save_mean, pb.save_invstd = nv.ptr(gamma), nv.ptr(beta), nv.ptr(gamma), nv.ptr(gamma)
     pb.dgamma, pb.dbeta, pb.B, pb.N, pb.panel = nv.ptr(torch.zeros(N, device='cuda')), nv.ptr(torch.zeros(N, device='cuda')), B, N, 1

@@ -28,6 +28,27 @@ tr = json.load(open(tr_path)) if os.path.exists(tr_path) else {}
 cfg = bench['config']['workload'].split(':')[0] + '_' + bench['dtype']
 tr[cfg] = {'kernel': KERNEL, 'hbm_bytes_per_launch': hbm, 'fetch_size_kib_raw': fetch, 'write_size_kib_raw': write,
            'launches_averaged': [n1, n2], 'correction': 'FETCH_SIZE x2 (gfx950), KiB -> bytes', 'source': name}
+# the kernel north_star names -- the encoder's first Linear, forward d -> 2d (reference model.py:151) -- gets an entry of its
+# own (bench.py: roofline.encoder_gemm.hbm_bytes): bf16: the 256 x 128-tile instance that only the d -> 2d launches use (enc0 and
+# dec1, identical shapes); fp32: the one kernel instance every forward / dX launch of the large layers shares (averaged over them)
+ENC = 'gemm_bf16_dma2_kernel<256, 128, 4, 4, 1, 3, 0>' if bench['dtype'] == 'bf16' else KERNEL
+
+
+def avg_counter_of(kernel, d, counter):
+    f = max(glob.glob(os.path.join(src, d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
+    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and kernel in r['Kernel_Name']]
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+ef, en1 = avg_counter_of(ENC, 'pmc_fetch', 'FETCH_SIZE')
+ew, en2 = avg_counter_of(ENC, 'pmc_write', 'WRITE_SIZE')
+ek = [r for r in rows if ENC in r['Name']]
+if ef is not None and ew is not None:
+    tr[cfg + '_encoder_gemm'] = {'kernel': ENC, 'hbm_bytes_per_launch': (2 * ef + ew) * 1024, 'fetch_size_kib_raw': ef, 'write_size_kib_raw': ew,
+                                 'launches_averaged': [en1, en2], 'correction': 'FETCH_SIZE x2 (gfx950), KiB -> bytes',
+                                 'rocprofv3_avg_launch_us': float(ek[0]['AverageNs']) / 1e3 if ek else None,
+                                 'note': 'bf16: the d -> 2d forward launches (enc0 and dec1: identical shapes); fp32: averaged over every forward / dX launch of the large layers',
+                                 'source': name}
 json.dump(tr, open(tr_path, 'w'), indent=1)
 bench['roofline']['traffic'] = hbm
 # the same command under rocprofv3 (--kernel-trace --stats): its own event timing next to the profiler's average, so the

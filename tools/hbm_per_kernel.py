@@ -37,4 +37,5 @@ for key, n, what in per_step:
     tot += avg * n
     print(f'{avg / 1e6:8.1f} MB/launch x {n} = {avg * n / 1e6:8.1f} MB/step   {what}  [{key}]')
 P = 40345130
-print(f'total {tot / 1e9:.3f} GB/step; algorithmic 44 P = {44 * P / 1e9:.3f} GB; ratio {tot / (44 * P):.3f}')
+print(f'total {tot / 1e9:.3f} GB/step; bf16 mode\'s own algorithmic bytes 34 P = {34 * P / 1e9:.3f} GB: ratio {tot / (34 * P):.3f}; '
+      f'the fp32 byte model 44 P = {44 * P / 1e9:.3f} GB: ratio {tot / (44 * P):.3f}')
