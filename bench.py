@@ -592,6 +592,8 @@ def main():
     ap.add_argument('--settle', type=int, default=0,
                     help='extra untimed plan replays in front of the W warm-up steps (default 0: --warmup is the only warm-up the '
                          'headline gets; the steady-state figure is the `steady_state` sub-record, timed behind the K steps)')
+    ap.add_argument('--step-trace', action='store_true', help='diagnostic: a HIP event behind every warm-up and timed step; their spacings '
+                    'ride in the line as `step_trace_us` (how the first steps after a cold start differ from the steady state)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` sub-records (C4 bf16, C5 dims fp32)')
     ap.add_argument('--tune', default=os.environ.get('JAMIE_TUNE', ''),
                     help='A/B measurements (tools/ab.sh): "key=value+key=value" for jamie_amd.engine.tune() -- tile / split-K plans and the '
@@ -721,10 +723,16 @@ def main():
     state['epoch'] = 0
     state['step'] = 2 + max(0, args.settle)
 
+    trace_ev = [] if args.step_trace else None
+
     def step():
         set_anneal()
         eng.run_plan(plan)
         state['step'] += 1
+        if trace_ev is not None and len(trace_ev) < 400:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(nv.current_stream())
+            trace_ev.append(e)
 
     def barrier():
         if world > 1:
@@ -738,8 +746,13 @@ def main():
         allreduce.enable_exposure(True, every=4)      # HIP events around finish()'s device-side waits (the exposed part of the exchange)
     events = os.environ.get('JAMIE_BENCH_NO_EVENTS') != '1'
     if events:
-        # drop the warm-up samples; sample every 8th step (every 2nd of a short run: the driver's K = 20 would leave 2-3 samples)
-        eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam', every=8 if args.steps > 64 else 2)
+        # drop the warm-up samples.  In the timed region only the two launches the roofline block needs are bracketed, on every 8th
+        # step (every 4th of a run under 16 steps): an event between two launches costs the step ~3 us (it ends the back-to-back
+        # overlap of the launches around it) -- with the four forward GEMM launches bracketed as well a sampled step read 590
+        # against 545 us (profiles/r05_step_trace_event_overhead.json).  The forward-GEMM average comes from the steady-state leg.
+        # (fp32: the roofline kernel IS the forward GEMM launch, and 12 events are 0.3 % of eight 1.3 ms steps: all three labels)
+        head_labels = ('enc0_gemm', 'adam') if args.dtype == 'bf16' else ('enc_gemm', 'enc0_gemm', 'adam')
+        eng.enable_kernel_timing(*head_labels, every=8 if args.steps >= 16 else 4)
     else:
         eng._timing = None
     t0 = time.perf_counter()
@@ -760,10 +773,10 @@ def main():
     # 14 ms after a cold start; the GPU's clock and caches settle over the first ~100 steps: 2-3 % on one box).  A sub-record,
     # never `value`.
     steady = None
-    timing_head = {k: eng.kernel_timing_ms(k, 'all') for k in ('enc_gemm', 'enc0_gemm', 'adam')} if events else None
+    timing_head = {k: eng.kernel_timing_ms(k, 'all') for k in head_labels} if events else None
     if args.dry_run_world <= 1:
         if events:
-            eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam', every=8)      # (this leg's own samples)
+            eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam', every=25)     # (this leg's own samples: 8 of 200 steps)
         barrier()
         ts = time.perf_counter()
         for _ in range(STEADY_STEPS):
@@ -778,6 +791,8 @@ def main():
                   'note': f'{STEADY_STEPS} more steps timed behind the K timed steps of the headline (same barriers, max over ranks)'}
         if events:
             steady['kernel_event_timing_ms'] = {k: eng.kernel_timing_ms(k, 'all') for k in ('enc_gemm', 'enc0_gemm', 'adam')}
+            if timing_head is not None and 'enc_gemm' not in timing_head:
+                timing_head['enc_gemm'] = steady['kernel_event_timing_ms']['enc_gemm']      # (bf16: bracketed in the steady-state leg only)
     if not events:          # kernel timings from extra steps AFTER the timed region -- on every rank (a step is a collective)
         eng.enable_kernel_timing('enc_gemm', 'enc0_gemm', 'adam')
         for _ in range(20):
@@ -835,6 +850,8 @@ def main():
             'adam': eng.kernel_timing_ms('adam', 'all')}
         # event pairs bracket one launch each; a host hiccup between the two records (GC, scheduler) shows up as a
         # multi-millisecond outlier in a handful of the samples, so the per-launch duration is the MEDIAN
+        if not timing_detail.get('enc_gemm'):          # (no steady-state leg, e.g. a dry run: the encoder launch stands in)
+            timing_detail['enc_gemm'] = timing_detail['enc0_gemm']
         gemm_ms, adam_ms = timing_detail['enc_gemm']['median'], timing_detail['adam']['median']
         kdims = eng.dims                                   # what the kernels multiply (padded feature counts, if any)
         gemm_flop = 4.0 * B * sum(d * d for d in kdims)
@@ -896,6 +913,9 @@ def main():
         }
         if steady is not None:
             out['steady_state'] = steady
+        if trace_ev:
+            torch.cuda.synchronize()
+            out['step_trace_us'] = [round(1e3 * a.elapsed_time(b), 1) for a, b in zip(trace_ev[:-1], trace_ev[1:])]
         if args.dry_run_world > 1:
             out['dry_run_world'] = args.dry_run_world
             out['dp_model'] = dp

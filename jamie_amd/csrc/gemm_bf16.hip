@@ -1505,6 +1505,9 @@ struct MseDev { const float* y; const float* x; float* d; unsigned short* dst; u
                 long long slab_stride; int R, C, nslab, blk_begin, tiles_c; float scale, pscale; };
 struct MseGroup { MseDev p[JAMIE_MAX_GROUP]; int count; };
 
+// CP: per-tile column sums of d (colpart); HAS_D: the fp32 output exists.  Template constants, not run-time tests: with `if (P.d)` /
+// `if (P.colpart)` inside the four passes the launch took 14.6 instead of 9.8 us in the step (profiles/r05_launch_timeline_*.txt)
+template <bool CP, bool HAS_D>
 __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
     __shared__ float tile[64][65];
     __shared__ float red[4];
@@ -1558,7 +1561,7 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
                 v[0] = yv[pass].x - xv[pass].x; v[1] = yv[pass].y - xv[pass].y; v[2] = yv[pass].z - xv[pass].z; v[3] = yv[pass].w - xv[pass].w;
                 local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                 v[0] *= P.scale; v[1] *= P.scale; v[2] *= P.scale; v[3] *= P.scale;
-                if (P.d) *reinterpret_cast<float4*>(P.d + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (HAS_D) *reinterpret_cast<float4*>(P.d + o) = make_float4(v[0], v[1], v[2], v[3]);
                 if (P.dst) {
                     const unsigned short b0 = __builtin_bit_cast(unsigned short, (__bf16)v[0]), b1 = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
                     const unsigned short b2 = __builtin_bit_cast(unsigned short, (__bf16)v[2]), b3 = __builtin_bit_cast(unsigned short, (__bf16)v[3]);
@@ -1571,17 +1574,17 @@ __global__ __launch_bounds__(256) void mse_cast_kernel(MseGroup g) {
                     v[e] -= P.x[o + e];
                     local += v[e] * v[e];
                     v[e] *= P.scale;
-                    if (P.d) P.d[o + e] = v[e];
+                    if constexpr (HAS_D) P.d[o + e] = v[e];
                     if (P.dst) P.dst[o + e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
                 }
             }
         }
         tile[rr][4 * q] = v[0]; tile[rr][4 * q + 1] = v[1]; tile[rr][4 * q + 2] = v[2]; tile[rr][4 * q + 3] = v[3];
-        cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];          // (column sums of d: this thread's rows rr0 + 16 pass)
+        if constexpr (CP) { cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3]; }    // (column sums of d: this thread's rows rr0 + 16 pass)
     }
     const float tot = block_sum(local, red);
     if (threadIdx.x == 0 && P.partial) P.partial[b] = tot * P.pscale;
-    if (P.colpart) {            // (uniform) column sums of this tile's 64 rows of d (rows beyond R hold 0), in a fixed order:
+    if constexpr (CP) {         // column sums of this tile's 64 rows of d (rows beyond R hold 0), in a fixed order:
         // a thread's four rows (rr0 + 16 pass), the four row phases of its wave by xor-shuffles, the four waves through LDS
         // (a serial 64-row loop by 64 threads cost the launch 1.7 us: profiles/r05_ab_mse_colpart.log)
 #pragma unroll
@@ -1638,6 +1641,13 @@ extern "C" int jamie_mse_cast(const jamie_mse_problem* pr, int count, void* stre
         d.blk_begin = blocks; d.tiles_c = (s.C + 63) / 64;
         blocks += ((s.R + 63) / 64) * d.tiles_c;
     }
-    hipLaunchKernelGGL(mse_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    // (every problem of a launch alike: with / without the fp32 output, with / without the column sums)
+    bool cp = pr[0].colpart != nullptr, has_d = pr[0].d != nullptr;
+    for (int i = 1; i < count; ++i)
+        JAMIE_ARG((pr[i].colpart != nullptr) == cp && (pr[i].d != nullptr) == has_d, "every problem with / without d and colpart alike");
+    if (cp && has_d) hipLaunchKernelGGL((mse_cast_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (cp) hipLaunchKernelGGL((mse_cast_kernel<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (has_d) hipLaunchKernelGGL((mse_cast_kernel<false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((mse_cast_kernel<false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     return jamie_launch_status("jamie_mse_cast");
 }

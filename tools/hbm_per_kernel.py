@@ -25,7 +25,7 @@ per_step = [('clip_adam', 1, 'clip + Adam (+ bf16 weight copy, + next batch gath
             ('gemm_bf16_dma2_kernel<256, 128, 4, 4, 1, 3, 0>', 2, 'forward d -> 2d'),
             ('gemm_bf16_dma2_kernel<128, 128, 2, 4, 1, 3, 0>', 2, 'forward 2d -> d'),
             ('bn_act_bwd4', 4, 'BatchNorm backward'), ('bn_act_fwd4_kernel<4, 8>', 2, 'BatchNorm forward, 2d-wide layers (32-column strips)'),
-            ('bn_act_fwd4_kernel<4, 4>', 2, 'BatchNorm forward, d-wide layers'), ('mse_cast', 1, 'MSE + d x_hat'),
+            ('bn_act_fwd4_kernel<4, 4>', 2, 'BatchNorm forward, d-wide layers'), ('mse_cast_kernel', 1, 'MSE + d x_hat'),
             ('latent_m_bwd', 1, 'latent backward'), ('latent_m_fwd', 1, 'latent forward'),
             ('gemm_bf16_dma_kernel<64, 64, 2, 2, 0, 3, 0>', 1, 'heads forward')]
 tot = 0.0

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+for V in True False; do
+OUT=$PWD/gpurun_out/r05prof_mse_$V
+mkdir -p $OUT
+( cd /tmp && export TMPDIR=/tmp && JAMIE_TUNE=mse_colpart=$V rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-f32-record --no-other-configs > $OUT/stats.json 2> /dev/null )
+python tools/trace_gaps.py $OUT | grep -E "steps of|mse_cast|bn_act_bwd4" | head -4
+find $OUT -name '*_kernel_trace.csv' -delete
+done
