@@ -1,5 +1,6 @@
-set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r05
-bash tools/ab.sh -r 2 "-" "JAMIE_TUNE=bwd_k_per_slab=1000" "JAMIE_TUNE=bwd_k_per_slab=1400" "JAMIE_TUNE=bf16_rows=31:4,2;32:3,2" "JAMIE_TUNE=bf16_rows=31:3,2;32:4,2" "JAMIE_TUNE=sk_skinny=4" > gpurun_out/r05/ab_slab_plans_panel.log 2>&1
-cat gpurun_out/r05/ab_slab_plans_panel.log
+timeout -k 10 600 python -m pytest tests/test_hip_configs.py tests/test_hip_step.py tests/test_hip_kernels.py -q -m gpu -x > gpurun_out/r05/t_latpin.log 2>&1
+rc=$?; echo "pytest rc $rc"; tail -3 gpurun_out/r05/t_latpin.log
+[ $rc -eq 0 ] && bash tools/ab.sh -r 4 "-" "JAMIE_LIB=$PWD/jamie_amd/libjamie_hip_nopin.so" > gpurun_out/r05/ab_latent_descriptor_burst.log 2>&1
+cat gpurun_out/r05/ab_latent_descriptor_burst.log
