@@ -42,7 +42,22 @@ CONFIGS = {
 DEFAULT_DTYPE = {'c5': 'f32'}
 ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the exposure model (dp_model): stated, not measured
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, 2, 1, true>'      # engine.F32_CFG_ROWS = 17 on the large layers
+F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, 2, 1, true, 0>'      # engine.F32_CFG_ROWS = 17 on the large layers
+F32_X3_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 2, 2, true, true, 2, 1, false, 1>'  # engine.F32_CFG_X3 = 20 (the default: TUNING['f32_x3'])
+X3_PRODUCTS = 6                  # bf16 MFMAs per fp32 product in configuration 20 (three-piece cuts: hh, hm, mh, hl, lh, mm)
+
+
+def f32_roofline_terms(eng):
+    """(peak in fp32-equivalent TFLOP/s, kernel name, note) of the large fp32 launches of `eng`: configuration 20 runs every fp32
+    product as six bf16 MFMAs, so its ceiling is the dense bf16 peak / 6 (the fp32 pipe's own 157.3 TFLOP/s is not what binds it);
+    configuration 17 runs on the fp32 matrix pipe."""
+    from jamie_amd import engine as je
+    if eng.fcfg.get('enc0', -1) == je.F32_CFG_X3:
+        return (PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS, F32_X3_ROOFLINE_KERNEL,
+                f'fp32 products on the bf16 matrix pipe: every element cut into three bf16 pieces, {X3_PRODUCTS} v_mfma_f32_32x32x16_bf16 per '
+                f'fp32 product; achieved / peak are fp32-equivalent TFLOP/s, peak = {PEAK_BF16_MFMA_TFLOPS:.0f} / {X3_PRODUCTS} '
+                f'(the fp32 pipe\'s own peak is {PEAK_F32_MFMA_TFLOPS})')
+    return PEAK_F32_MFMA_TFLOPS, F32_ROOFLINE_KERNEL, 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32)'
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (never the 2:1-sparsity figure)
 INGEST_TBPS = 17.0               # L2 -> LDS ingest of the whole chip: 256 CUs x 66 GB/s (MI355X_MICROARCH.md 'Indexed rows: gather into LDS';
@@ -292,7 +307,7 @@ def encoder_gemm_record(eng, ms, config, dtype):
     B, dims = eng.B, eng.dims
     es = 2 if dtype == 'bf16' else 4
     flop = 4.0 * B * sum(d * d for d in dims)
-    peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+    peak, f32_note = (PEAK_BF16_MFMA_TFLOPS, None) if dtype == 'bf16' else f32_roofline_terms(eng)[::2]
     alg = sum(B * d * es + 2 * d * d * es + B * 2 * d * 4 for d in dims)
     ingest, tiles, slices = 0.0, [], []
     for i, d in enumerate(dims):
@@ -318,7 +333,7 @@ def encoder_gemm_record(eng, ms, config, dtype):
            'hbm_bytes': hbm, 'hbm_bytes_source': note, 'frac_hbm': (hbm / t / 1e9 / PEAK_HBM_GBS) if hbm else None,
            'tile': tiles, 'k_slices': slices, 'ingest_model_bytes': ingest, 'ingest_peak_TBps': INGEST_TBPS,
            'frac_ingest': ingest / t / 1e12 / INGEST_TBPS,
-           'binding': 'L2 -> LDS ingest of the CUs' if dtype == 'bf16' else 'MFMA (fp32 matrix pipe)'}
+           'binding': 'L2 -> LDS ingest of the CUs' if dtype == 'bf16' else 'MFMA: ' + f32_note}
     return out
 
 
@@ -348,13 +363,14 @@ def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20, co
     achieved = gemm_flop / (tm['median'] * 1e-3) / 1e12
     cells_s = B * steps / dt
     total = eng.read_losses()[1]
+    peak, kname, pnote = f32_roofline_terms(eng)
     return {'value': cells_s, 'unit': 'cells/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
             'dtype': 'f32', 'final_loss': total,
-            'roofline': {'bound': 'mfma', 'kernel': F32_ROOFLINE_KERNEL + ' (Linear d<->2d forward '
+            'roofline': {'bound': 'mfma', 'kernel': kname + ' (Linear d<->2d forward '
                                                      'GEMM, both modalities in one launch; 4 launches/step)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': tm['median'], 'flop_per_launch': gemm_flop,
-                         'whole_step_frac': cells_s * flops_per_cell(model_dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'peak_note': pnote,
+                         'frac': achieved / peak, 'avg_launch_ms': tm['median'], 'flop_per_launch': gemm_flop,
+                         'whole_step_frac': cells_s * flops_per_cell(model_dims, L) / (peak * 1e12),
                          'encoder_gemm': encoder_gemm_record(eng, tm0['median'], config, 'f32')}}
 
 
@@ -396,7 +412,7 @@ def other_config_record(name, dtype, dev, B=512, steps=20, warmup=5):
            'parameters': model.num_parameters(), 'flop_per_cell': flops_per_cell(dims, L), 'final_loss': total,
            'encoder_gemm': encoder_gemm_record(eng, tm0['median'], name, dtype) if tm0 else None}
     if dtype == 'f32':
-        rec['whole_step_frac_mfma'] = rec['value'] * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        rec['whole_step_frac_mfma'] = rec['value'] * flops_per_cell(dims, L) / (f32_roofline_terms(eng)[0] * 1e12)
     rec['leg_seconds'] = round(time.perf_counter() - t_leg, 1)
     del plan, eng, model, data
     torch.cuda.empty_cache()
@@ -860,12 +876,13 @@ def main():
         enc0 = encoder_gemm_record(eng, timing_detail['enc0_gemm']['median'], args.config, args.dtype) if timing_detail['enc0_gemm'] else None
         if args.dtype == 'f32':
             achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': F32_ROOFLINE_KERNEL + ' (Linear d<->2d forward '
+            peak, kname, pnote = f32_roofline_terms(eng)
+            roof = {'bound': 'mfma', 'kernel': kname + ' (Linear d<->2d forward '
                                               'GEMM, both modalities in one launch; 4 launches/step)',
-                    'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop,
+                    'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'peak_note': pnote,
+                    'frac': achieved / peak, 'avg_launch_ms': gemm_ms, 'flop_per_launch': gemm_flop,
                     'traffic': traffic, 'traffic_source': traffic_source,
-                    'whole_step_frac': cells_s / world * flops_per_cell(dims, L) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                    'whole_step_frac': cells_s / world * flops_per_cell(dims, L) / (peak * 1e12),
                     'encoder_gemm': enc0}
         else:
             n_par = model.layout.total

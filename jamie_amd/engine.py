@@ -35,6 +35,9 @@ TUNING = {
     'stagger': True,              # flat optimiser buffers start 4 KB apart
     'adam_rotate': False,         # clip + Adam walks from the second layer's region (+5 us: off)
     'f32_dx_plan': True, 'f32_fused_norm': True,
+    'f32_x3': True,               # fp32 mode: the large products on the bf16 matrix pipe, every fp32 element cut into three bf16 pieces
+                                  # (gemm_f32.hip configuration 20: fp32-level error, 1313 -> 1059 us per step at config 2); False: the
+                                  # fp32 matrix pipe (configuration 17)
     'fused_da2': True, 'fused_latent': True, 'direct_comm': True, 'cs_ride': True, 'late_dec0_dw': True, 'range_ride': True,
     'defer_final': True, 'fused_sampler': True, 'gather_ride': True,
     'dw_store_nt': True,          # weight gradients stored non-temporally (next read by the optimiser, a backward pass later)
@@ -144,11 +147,20 @@ F32_CFG_DW = 17             # fp32 dW (TN, K = batch) of the large layers when t
                             # config 5's dimensions run 6.86 against 6.97 ms per step, config 2 the same: r04_f32_dp_dw_tile.log)
 F32_CFG_DW_FUSED = 17       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
 F32_CFG_SOLO = 19           # 17 with 56 KB of unused dynamic LDS: one workgroup per CU (forward launches beside the optimiser stream)
+F32_CFG_X3 = 20             # 128x128x32 on four waves of 64x64, the products as six bf16 MFMAs on three-piece cuts (TUNING['f32_x3']): one
+                            # workgroup per CU (144 KB of LDS), ~1.0 us per k-step against 2.05
+
+
+def f32_cfg(kind='rows'):
+    """Tile configuration of the large fp32 launches: 'rows' (forward / dX), 'dw', 'dw_fused'."""
+    if TUNING['f32_x3']:
+        return F32_CFG_X3
+    return {'rows': F32_CFG_ROWS, 'dw': F32_CFG_DW, 'dw_fused': F32_CFG_DW_FUSED}[kind]
 
 
 def _f32_fused_cfg():
     """Tile configuration of the fp32 dW launches that also write their tiles' sums of squares (TUNING['f32_dw_cfg'] overrides)."""
-    return int(TUNING['f32_dw_cfg']) if TUNING['f32_dw_cfg'] not in (None, '') else F32_CFG_DW_FUSED
+    return int(TUNING['f32_dw_cfg']) if TUNING['f32_dw_cfg'] not in (None, '') else f32_cfg('dw_fused')
 
 
 def launch_makespan(works, n_cu=N_CU, per_cu=2, solo=0.87):
@@ -208,11 +220,11 @@ def launch_makespan(works, n_cu=N_CU, per_cu=2, solo=0.87):
 
 def plan_f32_rows(B, shapes):
     """(tile configuration, K slices per problem) of an fp32 forward / dX launch; see _plan_f32_rows."""
-    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), TUNING['f32_rows'], TUNING['f32_rows_cfg'])
+    return _plan_f32_rows(B, tuple(tuple(x) for x in shapes), TUNING['f32_rows'], TUNING['f32_rows_cfg'], bool(TUNING['f32_x3']))
 
 
 @functools.lru_cache(maxsize=256)
-def _plan_f32_rows(B, shapes, _knob, _tile=None):
+def _plan_f32_rows(B, shapes, _knob, _tile=None, _x3=False):
     """fp32 forward / dX launch with shapes = [(N_i, K_i)]: the 128x128x32 tile (two workgroups per CU) with K slices of one
     common length, chosen by a model of the launch: workgroup work = k-steps + 3 (prologue, store tail), launch time =
     launch_makespan of the grid (every problem's slices in problem order) + what the extra slabs cost their consumer
@@ -223,14 +235,18 @@ def _plan_f32_rows(B, shapes, _knob, _tile=None):
     8.61 -> 7.60 ms per step, forward launches 94 -> 120 TFLOP/s.  (-1, None): keep the default."""
     if B < 256 or any(N < 512 or K < 512 for (N, K) in shapes):
         return -1, None
+    default_cfg = F32_CFG_X3 if _x3 else F32_CFG_ROWS
     if _knob:
         parts = _knob.split(';')
         part = parts[0] if (all(N >= K for (N, K) in shapes) or len(parts) == 1) else parts[1]
         cfg, _, part = part.rpartition(':')                 # ("cfg:s0,s1": another tile configuration)
         sks = [int(v) for v in part.split(',')]
-        return (int(cfg) if cfg else F32_CFG_ROWS), [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
+        return (int(cfg) if cfg else default_cfg), [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
     tiles = [math.ceil(B / 128) * math.ceil(N / 128) for (N, K) in shapes]
     kstep_us, overhead, slab_tbps = 2.05, 3.0, 3.0
+    per_cu, solo = 2, 0.87
+    if _x3:      # (configuration 20: one workgroup per CU, ~1.0 us per k-step, two tiles cut before the first MFMA)
+        kstep_us, overhead, per_cu, solo = 1.0, 5.0, 1, 1.0
     best, seen = None, set()
     for kc in range(256, max(K for (_, K) in shapes) + 1, 8):
         sk = tuple(min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes)
@@ -239,10 +255,10 @@ def _plan_f32_rows(B, shapes, _knob, _tile=None):
         seen.add(sk)
         works = [K / s / 32.0 + overhead for t, s, (_, K) in zip(tiles, sk, shapes) for _ in range(t * s)]
         slabs = sum((s - 1) * B * N * 8.0 for s, (N, _) in zip(sk, shapes)) / (slab_tbps * 1e6)        # us
-        cost = launch_makespan(works) * kstep_us + slabs
+        cost = launch_makespan(works, per_cu=per_cu, solo=solo) * kstep_us + slabs
         if best is None or cost < best[0] - 1e-9:
             best = (cost, list(sk))
-    return (int(_tile) if _tile not in (None, '') else F32_CFG_ROWS, best[1]) if best else (-1, None)
+    return (int(_tile) if _tile not in (None, '') else default_cfg, best[1]) if best else (-1, None)
 
 
 def kl_anneal(epoch, min_epochs, epoch_DNN):
@@ -923,7 +939,7 @@ class TrainEngine:
                                          c_panel=self._paneled(out_key, self.gcfg.get(sk_key, -1))))
         cfg = self.gcfg.get(sk_key, -1)
         fcfg = self.fcfg.get(sk_key, -1)
-        if (not self.bf16 and self.pipeline and fcfg == F32_CFG_ROWS and lin in str(TUNING['f32_pipe_solo']).split(',')):
+        if (not self.bf16 and self.pipeline and fcfg == F32_CFG_ROWS and lin in str(TUNING['f32_pipe_solo']).split(',')):      # (not 20: one per CU as it is)
             fcfg = F32_CFG_SOLO           # (same tile, same K slices, same sums: one workgroup per CU while clip + Adam streams beside it)
         self._wait_params(lin)
         # 'enc_gemm': every large forward launch; 'enc0_gemm': the encoder's first Linear alone (model.py:151, d -> 2d, both
@@ -978,8 +994,11 @@ class TrainEngine:
         skinny layers whose dW rides in the same launch; `ranges` (bf16 large-tile launch only): the range-norm work rides too."""
         probs = self._dw_problems(dy_key, a_key, lin, only)
         for ex in (extra or []):
+            # (fp32: a skinny layer does not ride in a bf16x3 launch -- its product would then depend on which launch carried it;
+            #  it keeps the fp32 pipe and a launch of its own, as in the grouped order of _flush_dw)
             if len(probs) + self.M <= (nv.MAX_GEMM_GROUP if self.bf16 else nv.MAX_GEMM_GROUP_F32) \
-                    and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(ex[2])):
+                    and (not self.bf16 or self._dw_cfg(lin) == self._dw_cfg(ex[2])) \
+                    and (self.bf16 or self._f32_dw_cfg(lin) != F32_CFG_X3 or self._f32_dw_cfg(ex[2]) == F32_CFG_X3):
                 probs += self._dw_problems(*ex)
             else:
                 self._dw_gemm(*ex)
@@ -1014,7 +1033,7 @@ class TrainEngine:
         if big and self._f32_dw_fused:
             return _f32_fused_cfg()           # (the partial sums are laid out for this tile)
         small = TUNING['f32_dw_small_cfg']
-        return (int(env) if env not in (None, '') else F32_CFG_DW) if big else (int(small) if small not in (None, '') else -1)
+        return (int(env) if env not in (None, '') else f32_cfg('dw')) if big else (int(small) if small not in (None, '') else -1)
 
     def _dw_cfg(self, lin):
         """Tile configuration of the dW launch of layer `lin` (-1: the library default for small / skinny problems)."""

@@ -62,8 +62,11 @@ def test_bench_roofline_kernel_names_exist_in_the_library(lib):
     out = subprocess.run(['nm', '-C', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert f'void {bench.F32_ROOFLINE_KERNEL}(GemmGroup)' in out, bench.F32_ROOFLINE_KERNEL
     assert 'clip_adam_kernel<' in out
-    # <BM, BN, BK, WM, WN, A_KC, B_KC, FAST, TAG, MID>: configuration 17 = 128x128x32 on 4 x 4 waves with the barrier in mid k-step
-    assert engine.F32_CFG_ROWS == 17 and bench.F32_ROOFLINE_KERNEL.endswith('<128, 128, 32, 4, 4, true, true, 2, 1, true>')
+    # <BM, BN, BK, WM, WN, A_KC, B_KC, FAST, TAG, MID, X3>: configuration 17 = 128x128x32 on 4 x 4 waves with the barrier in mid k-step
+    assert engine.F32_CFG_ROWS == 17 and bench.F32_ROOFLINE_KERNEL.endswith('<128, 128, 32, 4, 4, true, true, 2, 1, true, 0>')
+    # <..., MID, X3>: configuration 20 = 128x128x32 on 2 x 2 waves, the products as bf16 MFMAs on three-piece cuts
+    assert f'void {bench.F32_X3_ROOFLINE_KERNEL}(GemmGroup)' in out, bench.F32_X3_ROOFLINE_KERNEL
+    assert engine.F32_CFG_X3 == 20 and engine.TUNING['f32_x3'] is True
 
 
 def test_package_reads_no_environment_switches():
@@ -479,12 +482,26 @@ def test_f32_split_k_plans_come_from_the_launch_model():
     """engine.plan_f32_rows picks the K slices of an fp32 forward / dX launch by simulating the grid on 256 CUs with two
     workgroups each (engine.launch_makespan): the plans measured best on the GPU (profiles/r03_c5_f32_plan_sweep*.log,
     r03_c2_f32_plan_check.log) must come out of it."""
-    from jamie_amd.engine import F32_CFG_ROWS, launch_makespan, plan_f32_rows
+    from jamie_amd.engine import F32_CFG_ROWS, F32_CFG_X3, launch_makespan, plan_f32_rows, tune
+    B = 512
+    # the default: configuration 20 (one workgroup per CU, ~1 us per k-step) -- its own model parameters, plans measured on the GPU
+    # (profiles/r05_ab_f32_bf16x3_plans.log)
+    assert plan_f32_rows(B, [(4000, 2000), (2000, 1000)]) == (F32_CFG_X3, [3, 2])
+    assert plan_f32_rows(B, [(2000, 4000), (1000, 2000)]) == (F32_CFG_X3, [3, 2])
+    assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)]) == (F32_CFG_X3, [2, 1])
+    assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)]) == (F32_CFG_X3, [4, 2])
+    tune(f32_x3=False)
+    try:
+        _plans_of_the_fp32_pipe(B, F32_CFG_ROWS, launch_makespan, plan_f32_rows)
+    finally:
+        tune(f32_x3=True)
+
+
+def _plans_of_the_fp32_pipe(B, F32_CFG_ROWS, launch_makespan, plan_f32_rows):
     assert launch_makespan([10.0] * 4, n_cu=2) == pytest.approx(20.0)             # two CUs, two workgroups each
     assert launch_makespan([10.0] * 3, n_cu=2) == pytest.approx(20.0)             # the lone one finishes earlier (10 / 0.87)
     assert launch_makespan([10.0] * 5, n_cu=2) == pytest.approx(20.0 + 10.0 / 0.87)
     assert launch_makespan([8.0, 2.0], n_cu=1) == pytest.approx(4.0 + 6.0 / 0.87)  # shared until the short one leaves
-    B = 512
     assert plan_f32_rows(B, [(4000, 2000), (2000, 1000)]) == (F32_CFG_ROWS, [3, 2])          # config 2, d -> 2d
     cfg, sk = plan_f32_rows(B, [(2000, 4000), (1000, 2000)])                                 # config 2, 2d -> d: (3, 2) = (6, 3) measured
     assert cfg == F32_CFG_ROWS and sk in ([3, 2], [6, 3], [6, 4])
