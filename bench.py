@@ -374,6 +374,27 @@ def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20, co
                          'encoder_gemm': encoder_gemm_record(eng, tm0['median'], config, 'f32')}}
 
 
+def run_side_leg(kind, args, timeout_s=240):
+    """One sub-record (`f32`, `c4_bf16`, `c5dims_f32`) in a CHILD process (bench.py --side-leg): a sub-record must never lose the
+    headline, and a process that meets a GPU fault does not come back to print anything.  The child is started, never exec'ed into."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--side-leg', kind, '--config', args.config, '--batch', str(args.batch)]
+    if args.tune:
+        cmd += ['--tune', args.tune]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'error': f'child process: no result within {timeout_s} s'}
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith('{"side_leg"'):
+            rec = json.loads(ln)['record']
+            rec['child_process_seconds'] = round(time.perf_counter() - t0, 1)
+            return rec
+    return {'value': None, 'error': f'child process exited with {p.returncode}: ' + (p.stderr.strip().splitlines() or ['no output'])[-1][:300]}
+
+
 def other_config_record(name, dtype, dev, B=512, steps=20, warmup=5):
     """One more single-GPU configuration of BASELINE.json timed by the same process (driver-timed figures for
     C4 and for C5's dimensions): the workload at its own size (synthetic cells as in the headline, the noise term drawn on the
@@ -611,6 +632,9 @@ def main():
     ap.add_argument('--step-trace', action='store_true', help='diagnostic: a HIP event behind every warm-up and timed step; their spacings '
                     'ride in the line as `step_trace_us` (how the first steps after a cold start differ from the steady state)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` sub-records (C4 bf16, C5 dims fp32)')
+    ap.add_argument('--side-leg', default='', choices=['', 'f32', 'c4_bf16', 'c5dims_f32'],
+                    help='(internal) run ONE sub-record and print it: the headline process starts its sub-records as child processes, so '
+                         'that nothing that goes wrong in one of them can lose the headline line')
     ap.add_argument('--tune', default=os.environ.get('JAMIE_TUNE', ''),
                     help='A/B measurements (tools/ab.sh): "key=value+key=value" for jamie_amd.engine.tune() -- tile / split-K plans and the '
                          'older variant of every adopted change (engine.TUNING); also read from JAMIE_TUNE')
@@ -663,6 +687,15 @@ def main():
     if args.cells > 0:
         n_cells = args.cells
     B = args.batch
+    if args.side_leg:
+        if args.side_leg == 'f32':
+            data_leg = synth_shard(n_cells, 0, n_cells, dims, 0, 1, dev)
+            rec = f32_record(dims, L, B, data_leg, n_cells, min(dims) < B and len(dims) == 2, dev, config=args.config)
+        else:
+            cname, cdt = {'c4_bf16': ('c4', 'bf16'), 'c5dims_f32': ('c5dims', 'f32')}[args.side_leg]
+            rec = other_config_record(cname, cdt, dev, B)
+        print(json.dumps({'side_leg': args.side_leg, 'record': rec}), flush=True)
+        return
     if args.dtype == 'bf16' and any(v % 8 for v in [L, B]):
         args.dtype = 'f32'          # bf16 operands need a latent size and a batch that are multiples of 8
     # feature counts that are not multiples of 8 (config 1: 100, config 4: 500): the bf16 engine pads them (model.py)
@@ -1026,7 +1059,7 @@ def main():
         if args.dtype == 'bf16' and not args.no_f32_record and len(dims) == 2 and not any(d % 8 for d in dims):
             del eng, model
             torch.cuda.empty_cache()
-            out['f32'] = f32_record(dims, L, B, data_real, hi - lo, rep, dev, config=args.config)
+            out['f32'] = run_side_leg('f32', args)
         if args.config == 'c2' and args.dtype == 'bf16' and not args.no_other_configs and B == 512 and args.dry_run_world <= 1:
             # driver-timed sub-records of the other single-GPU configurations, inside a stated budget: each leg is skipped (and says
             # so) when the process has already spent OTHER_BUDGET_S since it started
@@ -1041,10 +1074,7 @@ def main():
                 if spent > OTHER_BUDGET_S:
                     out['other_configs'][key] = {'value': None, 'skipped': f'{spent:.0f} s spent before this leg: over the {OTHER_BUDGET_S:.0f} s budget'}
                     continue
-                try:
-                    out['other_configs'][key] = other_config_record(cname, cdt, dev, B)
-                except Exception as err:         # noqa: BLE001  (a sub-record must never lose the headline)
-                    out['other_configs'][key] = {'value': None, 'error': f'{type(err).__name__}: {err}'[:300]}
+                out['other_configs'][key] = run_side_leg(key, args)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dims, L, B, args.cpu_budget)
             out['gpu_over_cpu'] = cells_s / out['cpu_baseline']['value']
