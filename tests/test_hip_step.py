@@ -829,6 +829,42 @@ def test_full_size_config2_step_vs_oracle(jam):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+def test_fp32_step_on_the_bf16_pipe_stays_with_the_fp32_pipe(jam):
+    """fp32 mode, config 2's layer sizes: the step whose large products run as six bf16 MFMAs on three-piece cuts
+    (engine.TUNING['f32_x3'], the default: gemm_f32.hip configuration 20) against the same step on the fp32 matrix pipe
+    (configuration 17) -- every gradient region, the clip norm and the parameters after three steps agree to fp32 rounding
+    (relative L2 distance 1e-5: two fp32 summation orders differ by as much), and the plans it takes are the ones the host model names."""
+    from jamie_amd import engine
+    from jamie_amd.engine import TrainEngine
+    from jamie_amd.model import edModelVar
+    B, dims, L = 512, (2000, 1000), 32
+    g = torch.Generator().manual_seed(11)
+    X = [torch.randn(B, d, generator=g).cuda() for d in dims]
+    out = {}
+    try:
+        for x3 in (True, False):
+            engine.tune(f32_x3=x3)
+            torch.manual_seed(666)
+            model = edModelVar(dims, L)
+            eng = TrainEngine(model, B, seed=3)
+            assert eng.fcfg['enc0'] == (engine.F32_CFG_X3 if x3 else engine.F32_CFG_ROWS)
+            eng.set_batch(X)
+            for _ in range(3):
+                eng.step()
+            torch.cuda.synchronize()
+            out[x3] = (eng.grad.double().clone(), eng.norm_partials.double().sum().sqrt().item(), model.flat.double().clone(),
+                       eng.read_losses()[1])
+            del eng, model
+    finally:
+        engine.tune(f32_x3=True)
+    (ga, na, pa, la), (gb, nb, pb, lb) = out[True], out[False]
+    assert torch.isfinite(ga).all() and torch.isfinite(pa).all()
+    assert ((ga - gb).norm() / gb.norm()).item() < 1e-5, 'gradient'
+    assert abs(na - nb) < 1e-5 * nb, 'clip norm'
+    assert ((pa - pb).norm() / pb.norm()).item() < 1e-6, 'parameters'
+    assert abs(la - lb) < 1e-5 * abs(lb), 'loss'
+
+
 def test_fp32_weight_gradients_grouped_at_the_end_equal_one_launch_per_layer(jam):
     """fp32, one GPU: the large layers' dW products wait for the end of the backward pass and go out as ONE launch
     (engine.TUNING['f32_dw_group'] = 4: 2560 tiles = 5.0 rounds of the chip's 512 slots instead of 4 x 1.25).  Same tiles,
