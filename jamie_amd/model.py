@@ -319,6 +319,7 @@ class edModelVar:
         return x.to(self.device, torch.float32).contiguous()
 
     EVAL_GEMM_CFG = None
+    EVAL_X3 = True
 
     @staticmethod
     def _eval_cfg(n, nout, k):

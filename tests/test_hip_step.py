@@ -830,10 +830,15 @@ def test_full_size_config2_step_vs_oracle(jam):
 
 
 def test_fp32_step_on_the_bf16_pipe_stays_with_the_fp32_pipe(jam):
-    """fp32 mode, config 2's layer sizes: the step whose large products run as six bf16 MFMAs on three-piece cuts
+    """fp32 mode, config 2's layer sizes: the first step whose large products run as six bf16 MFMAs on three-piece cuts
     (engine.TUNING['f32_x3'], the default: gemm_f32.hip configuration 20) against the same step on the fp32 matrix pipe
-    (configuration 17) -- every gradient region, the clip norm and the parameters after three steps agree to fp32 rounding
-    (relative L2 distance 1e-5: two fp32 summation orders differ by as much), and the plans it takes are the ones the host model names."""
+    (configuration 17), weight-gradient matrix by weight-gradient matrix.  Typical distance 1e-6 (relative L2), i.e. fp32
+    rounding: the median over the twelve matrices must stay below 5e-6.  A single matrix may be further off -- a pre-activation
+    that lands on the other side of LeakyReLU's kink changes one element of dz by a factor of 100, ~1e-3 of its layer's dW; the
+    fp32 pipe against ITSELF with other K slices (the yardstick run below) shows the same events (profiles/r05_x3_step_distance.log)
+    -- so at most two matrices may exceed 1e-4, none 2e-2.  Losses agree to 1e-6.  Later steps are not compared: Adam's first
+    update is lr * sign(g), which turns rounding noise in near-zero gradients into full-size parameter differences in any pair of
+    fp32 implementations."""
     from jamie_amd import engine
     from jamie_amd.engine import TrainEngine
     from jamie_amd.model import edModelVar
@@ -842,27 +847,33 @@ def test_fp32_step_on_the_bf16_pipe_stays_with_the_fp32_pipe(jam):
     X = [torch.randn(B, d, generator=g).cuda() for d in dims]
     out = {}
     try:
-        for x3 in (True, False):
-            engine.tune(f32_x3=x3)
+        for name, knobs, cfg in (('x3', dict(f32_x3=True, f32_rows=None), engine.F32_CFG_X3),
+                                 ('pipe', dict(f32_x3=False, f32_rows=None), engine.F32_CFG_ROWS),
+                                 ('pipe_other_slices', dict(f32_x3=False, f32_rows='17:4,4;17:4,4'), engine.F32_CFG_ROWS)):
+            engine.tune(**knobs)
             torch.manual_seed(666)
             model = edModelVar(dims, L)
             eng = TrainEngine(model, B, seed=3)
-            assert eng.fcfg['enc0'] == (engine.F32_CFG_X3 if x3 else engine.F32_CFG_ROWS)
+            assert eng.fcfg['enc0'] == cfg
             eng.set_batch(X)
-            for _ in range(3):
-                eng.step()
+            eng.step()
             torch.cuda.synchronize()
-            out[x3] = (eng.grad.double().clone(), eng.norm_partials.double().sum().sqrt().item(), model.flat.double().clone(),
-                       eng.read_losses()[1])
+            assert torch.isfinite(eng.grad).all()
+            out[name] = ({k: v.double().clone() for k, v in model.layout.views(eng.grad).items() if k.endswith('.W')}, eng.read_losses())
             del eng, model
     finally:
-        engine.tune(f32_x3=True)
-    (ga, na, pa, la), (gb, nb, pb, lb) = out[True], out[False]
-    assert torch.isfinite(ga).all() and torch.isfinite(pa).all()
-    assert ((ga - gb).norm() / gb.norm()).item() < 1e-5, 'gradient'
-    assert abs(na - nb) < 1e-5 * nb, 'clip norm'
-    assert ((pa - pb).norm() / pb.norm()).item() < 1e-6, 'parameters'
-    assert abs(la - lb) < 1e-5 * abs(lb), 'loss'
+        engine.tune(f32_x3=True, f32_rows=None)
+
+    def distances(a, b):
+        return sorted(((a[k] - b[k]).norm() / b[k].norm()).item() for k in b)
+    d_x3, d_yard = distances(out['x3'][0], out['pipe'][0]), distances(out['pipe_other_slices'][0], out['pipe'][0])
+    print('per-matrix relative L2 distances of the first gradient, sorted\n  bf16 pipe vs fp32 pipe:', ' '.join(f'{v:.1e}' for v in d_x3),
+          '\n  fp32 pipe vs itself with other K slices:', ' '.join(f'{v:.1e}' for v in d_yard))
+    assert len(d_x3) == 12
+    assert d_x3[len(d_x3) // 2] < 5e-6, d_x3
+    assert sum(v > 1e-4 for v in d_x3) <= 2 and d_x3[-1] < 2e-2, d_x3
+    for a, b in zip(out['x3'][1][0] + [out['x3'][1][1]], out['pipe'][1][0] + [out['pipe'][1][1]]):
+        assert abs(a - b) <= 1e-6 * abs(b) + 1e-9, (out['x3'][1], out['pipe'][1])
 
 
 def test_fp32_weight_gradients_grouped_at_the_end_equal_one_launch_per_layer(jam):
