@@ -27,6 +27,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// bf16x3 k-loop, row-contiguous operands: which 4 k x 4 m block a lane stages (see the loop's note on 8-byte LDS stores).
+// JAMIE_X3_HALF16 (A/B): the two 8-byte halves of a chunk 16 lanes apart -- a third of the dW launch's LDS cycles were conflicts
+#ifdef JAMIE_X3_HALF16
+#define JF_X3_KQ(lane) (((lane) >> 4) & 1)
+#define JF_X3_C4(lane) (((lane) & 15) + 16 * ((lane) >> 5))
+#else
+#define JF_X3_KQ(lane) (((lane) >> 3) & 1)
+#define JF_X3_C4(lane) (((lane) & 7) + 8 * ((lane) >> 4))
+#endif
+
 // diagnostic build only (tools/stamp_gemm_bf16.sh): in-kernel s_memrealtime stamps, see gemm_bf16.hip
 #ifdef JAMIE_GEMMB_STAMP
 __device__ unsigned long long jamie_dbg_stamps_f32[8192 * 8];
@@ -214,9 +224,10 @@ void gemm_f32_kernel(GemmGroup g) {
             a_k[j] = c4 * 4;            // k offset within tile
             a_lds[j] = row * A_LD + c4 * 4;
         } else {
-            // (X3: a thread takes a 4 k x 4 m block -- k rows 4 kq + j -- so that its LDS writes are 4 consecutive k of one row)
-            const int krow = X3 ? 4 * (2 * wid + ((lane >> 4) & 1)) + j : f / (BM / 4);
-            const int c4 = X3 ? (lane & 15) + 16 * (lane >> 5) : f % (BM / 4);
+            // (X3: a thread takes a 4 k x 4 m block -- k rows 4 kq + j -- so that its LDS writes are 4 consecutive k of one row;
+            //  kq alternates every 8 lanes, see the k-loop's note on the 8-byte stores)
+            const int krow = X3 ? 4 * (2 * wid + JF_X3_KQ(lane)) + j : f / (BM / 4);
+            const int c4 = X3 ? JF_X3_C4(lane) : f % (BM / 4);
             const int gm = m0 + c4 * 4;
             a_ptr[j] = P.A + gm;
             a_lim[j] = max(0, min(4, P.M - gm));   // valid elements along m
@@ -236,8 +247,8 @@ void gemm_f32_kernel(GemmGroup g) {
             b_k[j] = c4 * 4;
             b_lds[j] = row * B_LD + c4 * 4;
         } else {
-            const int krow = X3 ? 4 * (2 * wid + ((lane >> 4) & 1)) + j : f / (BN / 4);
-            const int c4 = X3 ? (lane & 15) + 16 * (lane >> 5) : f % (BN / 4);
+            const int krow = X3 ? 4 * (2 * wid + JF_X3_KQ(lane)) + j : f / (BN / 4);
+            const int c4 = X3 ? JF_X3_C4(lane) : f % (BN / 4);
             const int gn = n0 + c4 * 4;
             b_ptr[j] = P.B + gn;
             b_lim[j] = max(0, min(4, P.N - gn));
@@ -336,15 +347,18 @@ void gemm_f32_kernel(GemmGroup g) {
         // A plane is [128 rows][32 k] bf16 in 64-byte rows.  16-byte chunk c (8 k) of row R lives at chunk c ^ ((R >> 2) & 3) of the
         // 64-byte block R ^ ((R >> 4) & 3): (a) the fragment read -- lane (r, h) takes chunk 2 s + h of row R0 + r, 16 consecutive
         // rows per LDS cycle -- meets 16 different 16-byte slots of a 256-byte line; (b) a K-contiguous operand's writes (8 lanes per
-        // row, 8 rows per instruction) fill two whole lines; (c) a row-contiguous operand's writes -- a thread holds 4 k x 4 m, lanes
-        // 0-15 rows 4 c + e of 16 different c, lanes 16-31 the other 8-byte half of the same chunks -- meet 16 different slots too
-        // (the block term varies with c >> 2, the chunk term with c & 3).  No padding, no transposed reads.
+        // row, 8 rows per instruction) fill two whole lines; (c) a row-contiguous operand's writes -- a thread holds 4 k x 4 m; an
+        // 8-byte store is serviced 16 contiguous lanes at a time over 32 banks (MI355X_MICROARCH.md, LDS table): lanes 0-7 take rows
+        // 4 c + e of 8 consecutive c, lanes 8-15 the other 8-byte half (the next 4 k) of the same chunks -- 16 different 8-byte
+        // words of a 128-byte window (the block term varies with c >> 2, the chunk term with c & 3).  (With the halves 16 lanes apart
+        // the counters showed a third of the dW launch's LDS cycles as bank conflicts: r05_pmc_step_f32_bf16x3.txt.)  No padding,
+        // no transposed reads.
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         constexpr int PL_A = BM * 64, PL_B = BN * 64, ST_SZ = 3 * (PL_A + PL_B);        // bytes: one plane of A / of B, one stage
         unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
         auto img = [](int R, int c, int half) { return ((R ^ ((R >> 4) & 3)) << 6) + ((c ^ ((R >> 2) & 3)) << 4) + (half << 3); };
-        const int rc4 = (lane & 15) + 16 * (lane >> 5), rkq = 2 * wid + ((lane >> 4) & 1);     // (the row-contiguous assignment above)
+        const int rc4 = JF_X3_C4(lane), rkq = 2 * wid + JF_X3_KQ(lane);      // (the row-contiguous assignment above)
         int a_w[4], b_w[4];
         static_assert(LA == 4 && LB == 4, "bf16x3: four float4 per thread and operand");
 #pragma unroll
