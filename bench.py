@@ -43,7 +43,7 @@ DEFAULT_DTYPE = {'c5': 'f32'}
 ASSUMED_BUS_GBS = 300.0          # all-reduce BUS bandwidth assumed by the exposure model (dp_model): stated, not measured
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F32_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 4, 4, true, true, 2, 1, true, 0>'      # engine.F32_CFG_ROWS = 17 on the large layers
-F32_X3_ROOFLINE_KERNEL = 'gemm_f32_kernel<128, 128, 32, 2, 2, true, true, 2, 1, false, 1>'  # engine.F32_CFG_X3 = 20 (the default: TUNING['f32_x3'])
+F32_X3_ROOFLINE_KERNEL = 'gemm_f32_kernel<256, 128, 32, 2, 2, true, true, 2, 1, false, 1>'  # engine.F32_CFG_X3 = 21 (the default: TUNING['f32_x3'])
 X3_PRODUCTS = 6                  # bf16 MFMAs per fp32 product in configuration 20 (three-piece cuts: hh, hm, mh, hl, lh, mm)
 
 
@@ -52,7 +52,7 @@ def f32_roofline_terms(eng):
     product as six bf16 MFMAs, so its ceiling is the dense bf16 peak / 6 (the fp32 pipe's own 157.3 TFLOP/s is not what binds it);
     configuration 17 runs on the fp32 matrix pipe."""
     from jamie_amd import engine as je
-    if eng.fcfg.get('enc0', -1) == je.F32_CFG_X3:
+    if eng.fcfg.get('enc0', -1) in (je.F32_CFG_X3, 20):
         return (PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS, F32_X3_ROOFLINE_KERNEL,
                 f'fp32 products on the bf16 matrix pipe: every element cut into three bf16 pieces, {X3_PRODUCTS} v_mfma_f32_32x32x16_bf16 per '
                 f'fp32 product; achieved / peak are fp32-equivalent TFLOP/s, peak = {PEAK_BF16_MFMA_TFLOPS:.0f} / {X3_PRODUCTS} '

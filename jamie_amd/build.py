@@ -12,6 +12,15 @@ CSRC = os.path.join(_HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(_HERE, 'libjamie_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+# Per-source flags.  gemm_f32.hip: the kernels index their by-value argument struct with a run-time problem number; clang copies a
+# by-value aggregate into a private alloca and InstCombine forwards the loads back to the kernarg segment only while the alloca has
+# at most 300 users -- the 256 x 128 bf16x3 instantiation has more, kept the 2.5 KB copy in SCRATCH, every descriptor field in a
+# vector register and a readfirstlane loop in front of every buffer load (twice the run time).
+FILE_FLAGS = {'gemm_f32.hip': ['-mllvm', '-instcombine-max-copied-from-constant-users=100000']}
+
+
+def file_flags(src):
+    return FILE_FLAGS.get(os.path.basename(src), [])
 
 
 def library_path():
@@ -46,7 +55,7 @@ def build_variant(tag, flags, verbose=False, only=None):
 
     def cc(so):
         if (only is None or os.path.basename(so[0]) in only) and not (fresh and _mtime(so[1]) >= max(_mtime(so[0]), hnew)):
-            subprocess.run([hipcc] + FLAGS + list(flags) + ['-c', so[0], '-o', so[1]], check=True)
+            subprocess.run([hipcc] + FLAGS + file_flags(so[0]) + list(flags) + ['-c', so[0], '-o', so[1]], check=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(cc, zip(srcs, objs)))
     with open(stamp, 'w') as f:
@@ -88,7 +97,7 @@ def build_library(force=False, verbose=False, jobs=None):
         return LIB
 
     def cc(so):
-        cmd = [hipcc] + FLAGS + extra + ['-c', so[0], '-o', so[1]]
+        cmd = [hipcc] + FLAGS + file_flags(so[0]) + extra + ['-c', so[0], '-o', so[1]]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)

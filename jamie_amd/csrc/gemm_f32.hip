@@ -27,6 +27,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = BEGIN .. END-1
+template <int I, int END, typename F>
+__device__ __forceinline__ void jf_static_for(F&& f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        jf_static_for<I + 1, END>(f);
+    }
+}
+
 // bf16x3 k-loop, row-contiguous operands: which 4 k x 4 m block a lane stages (see the loop's note on 8-byte LDS stores).
 // JAMIE_X3_HALF16 (A/B): the two 8-byte halves of a chunk 16 lanes apart -- a third of the dW launch's LDS cycles were conflicts
 #ifdef JAMIE_X3_HALF16
@@ -131,7 +140,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM
 void gemm_f32_kernel(GemmGroup g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    static_assert(!X3 || (BM == 128 && BN == 128 && BK == 32 && NT == 256 && FAST != 0 && !MID), "bf16x3: 128 x 128 x 32 on four waves of 64 x 64");
+    static_assert(!X3 || ((BM == 128 || BM == 256) && BN == 128 && BK == 32 && NT == 256 && WM == 2 && FAST != 0 && !MID),
+                  "bf16x3: 128 x 128 x 32 or 256 x 128 x 32 on four waves");
     // (row-contiguous images need no padding: a 32-lane group of ds_read_b32 reads 32 consecutive dwords of ONE k row, an 8-lane
     //  group of ds_write_b128 writes 128 contiguous bytes; rows a multiple of 256 bytes apart let all four k rows of a fragment
     //  come from one base register by ds_read2st64_b32 -- with the 4-dword pad every pair needed an address add of its own)
@@ -142,8 +152,8 @@ void gemm_f32_kernel(GemmGroup g) {
     constexpr int LA = BM * BK / 4 / NT, LB = BN * BK / 4 / NT;
     static_assert(LA >= 1 && LB >= 1 && BK % 8 == 0, "tile/thread mismatch");
     static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "tile/thread mismatch");
-    // (X3: three stages of three bf16 planes per operand, 64-byte rows of 32 k: 144 KB)
-    __shared__ __attribute__((aligned(16))) float smem[X3 ? 3 * 3 * (BM + BN) * BK / 2 : 2 * (A_SZ + B_SZ)];
+    // (X3: three (BM = 128) or two (BM = 256) stages of three bf16 planes per operand, 64-byte rows of 32 k: 144 KB)
+    __shared__ __attribute__((aligned(16))) float smem[X3 ? (BM == 128 ? 3 : 2) * 3 * (BM + BN) * BK / 2 : 2 * (A_SZ + B_SZ)];
     __shared__ float red[WM * WN];
 
     // ---- block -> (problem, tile), XCD-aware.  Hardware deals consecutive block ids round-robin over the 8
@@ -226,8 +236,8 @@ void gemm_f32_kernel(GemmGroup g) {
         } else {
             // (X3: a thread takes a 4 k x 4 m block -- k rows 4 kq + j -- so that its LDS writes are 4 consecutive k of one row;
             //  kq alternates every 8 lanes, see the k-loop's note on the 8-byte stores)
-            const int krow = X3 ? 4 * (2 * wid + JF_X3_KQ(lane)) + j : f / (BM / 4);
-            const int c4 = X3 ? JF_X3_C4(lane) : f % (BM / 4);
+            const int krow = X3 ? 4 * (2 * wid + JF_X3_KQ(lane)) + (j & 3) : f / (BM / 4);
+            const int c4 = X3 ? JF_X3_C4(lane) + 32 * (j >> 2) : f % (BM / 4);       // (BM = 256: a second block, 128 rows on)
             const int gm = m0 + c4 * 4;
             a_ptr[j] = P.A + gm;
             a_lim[j] = max(0, min(4, P.M - gm));   // valid elements along m
@@ -343,8 +353,10 @@ void gemm_f32_kernel(GemmGroup g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if constexpr (X3 != 0) {
-        // ---- bf16x3 k-loop (four waves of 64 x 64, one workgroup per CU) ----
-        // A plane is [128 rows][32 k] bf16 in 64-byte rows.  16-byte chunk c (8 k) of row R lives at chunk c ^ ((R >> 2) & 3) of the
+        // ---- bf16x3 k-loop (four waves, one per SIMD; one workgroup per CU) ----
+        // BM = 128: wave tiles of 64 x 64, three LDS stages; BM = 256: wave tiles of 128 x 64 (the cut per MFMA falls by a quarter,
+        // a fragment read serves more MFMAs, a tile's prologue and stores are spread over twice the work), two LDS stages.
+        // A plane is [rows][32 k] bf16 in 64-byte rows.  16-byte chunk c (8 k) of row R lives at chunk c ^ ((R >> 2) & 3) of the
         // 64-byte block R ^ ((R >> 4) & 3): (a) the fragment read -- lane (r, h) takes chunk 2 s + h of row R0 + r, 16 consecutive
         // rows per LDS cycle -- meets 16 different 16-byte slots of a 256-byte line; (b) a K-contiguous operand's writes (8 lanes per
         // row, 8 rows per instruction) fill two whole lines; (c) a row-contiguous operand's writes -- a thread holds 4 k x 4 m; an
@@ -355,16 +367,28 @@ void gemm_f32_kernel(GemmGroup g) {
         // no transposed reads.
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        constexpr int NST = BM == 128 ? 3 : 2;                     // LDS stages
+        constexpr int LAG = NST - 1;                               // step kt cuts tile kt + LAG
         constexpr int PL_A = BM * 64, PL_B = BN * 64, ST_SZ = 3 * (PL_A + PL_B);        // bytes: one plane of A / of B, one stage
+        constexpr int NLD = LA + LB;                               // float4 loads (= units of the cut) per thread and tile
+        constexpr int MB = 6 * TM * TN;                            // MFMAs per k-block of 16
+        constexpr int NF = 3 * (TM + TN);                          // fragments per k-block
+        constexpr int NPH = 6 * NLD;                               // phases of a tile's cut: one per MFMA gap, from gap 0
+        constexpr int BAR = NST == 3 ? MB + 3 : NPH + 1;           // the step's barrier sits behind MFMA number BAR
+        static_assert(LB == 4 && (LA == 4 || LA == 8) && TN == 2 && NPH <= 2 * MB && BAR + NF + 4 <= 2 * MB && NF <= MB - NLD,
+                      "bf16x3: gap budget of a k-step");
         unsigned char* const lds = reinterpret_cast<unsigned char*>(smem);
-        auto img = [](int R, int c, int half) { return ((R ^ ((R >> 4) & 3)) << 6) + ((c ^ ((R >> 2) & 3)) << 4) + (half << 3); };
+        auto img = [](int R, int c, int half) __attribute__((always_inline)) { return ((R ^ ((R >> 4) & 3)) << 6) + ((c ^ ((R >> 2) & 3)) << 4) + (half << 3); };
         const int rc4 = JF_X3_C4(lane), rkq = 2 * wid + JF_X3_KQ(lane);      // (the row-contiguous assignment above)
-        int a_w[4], b_w[4];
-        static_assert(LA == 4 && LB == 4, "bf16x3: four float4 per thread and operand");
+        int a_w[LA], b_w[LB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LA; ++u) {
             const int f = tid + u * NT;
-            a_w[u] = A_KC ? img(f >> 3, (f & 7) >> 1, f & 1) : img(4 * rc4 + u, rkq >> 1, rkq & 1);
+            a_w[u] = A_KC ? img(f >> 3, (f & 7) >> 1, f & 1) : img(4 * (rc4 + 32 * (u >> 2)) + (u & 3), rkq >> 1, rkq & 1);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int f = tid + u * NT;
             b_w[u] = B_KC ? img(f >> 3, (f & 7) >> 1, f & 1) : img(4 * rc4 + u, rkq >> 1, rkq & 1);
         }
         // one unit = 4 consecutive k of one tile row: cut into the three planes, three 8-byte LDS writes -- in SIX phases of at most 6
@@ -374,7 +398,7 @@ void gemm_f32_kernel(GemmGroup g) {
         float cx[4];
         u32x2 chi, cmid, clo;
         // (the subtractions as v_pk_add_f32 on pairs: 4 instructions fewer per unit, no faster -- 78.4 against 76.0 us on the d -> 2d shapes)
-        auto cut_phase = [&](auto phc, unsigned char* base, int plane_sz, float x0, float x1, float x2, float x3) {
+        auto cut_phase = [&](auto phc, unsigned char* base, int plane_sz, float x0, float x1, float x2, float x3) __attribute__((always_inline)) {
             constexpr int PH = decltype(phc)::value;
             constexpr unsigned HI = 0xFFFF0000u, SEL = 0x07060302u;
             if constexpr (PH == 0) {
@@ -398,179 +422,180 @@ void gemm_f32_kernel(GemmGroup g) {
                 *reinterpret_cast<u32x2*>(base + 2 * plane_sz) = clo;
             }
         };
-        auto cut_store = [&](unsigned char* base, int plane_sz, auto phc, float x0, float x1, float x2, float x3) {
+        auto cut_store = [&](unsigned char* base, int plane_sz, auto phc, float x0, float x1, float x2, float x3) __attribute__((always_inline)) {
             constexpr int PH = decltype(phc)::value;          // 0 .. 5: that phase; 6: all of them
-            if constexpr (PH == 6) {
-                cut_phase(std::integral_constant<int, 0>{}, base, plane_sz, x0, x1, x2, x3);
-                cut_phase(std::integral_constant<int, 1>{}, base, plane_sz, x0, x1, x2, x3);
-                cut_phase(std::integral_constant<int, 2>{}, base, plane_sz, x0, x1, x2, x3);
-                cut_phase(std::integral_constant<int, 3>{}, base, plane_sz, x0, x1, x2, x3);
-                cut_phase(std::integral_constant<int, 4>{}, base, plane_sz, x0, x1, x2, x3);
-                cut_phase(std::integral_constant<int, 5>{}, base, plane_sz, x0, x1, x2, x3);
-            } else cut_phase(phc, base, plane_sz, x0, x1, x2, x3);
+            if constexpr (PH == 6)
+                jf_static_for<0, 6>([&](auto pc) __attribute__((always_inline)) { cut_phase(pc, base, plane_sz, x0, x1, x2, x3); });
+            else cut_phase(phc, base, plane_sz, x0, x1, x2, x3);
         };
-        auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
-        // unit u of the staged tile (0-3: A, 4-7: B) into stage `st`; k0 = the tile's first k (in-row tails of the FAST == 1 instance)
-        // (two sets of staging registers: tile t rides in set t & 1 from the top of step t-2 to the middle of step t-1 -- a whole
-        //  k-step of ~0.9 us between a load's issue and its first use; with one set it was half a step and the loop ran at the
-        //  memory latency, 1.9 us per k-step)
-        float4 xa[2][4], xb[2][4];
-        auto load_one = [&](auto sc, auto jc, int k0) {          // load j of the eight of a tile (0-3: A, 4-7: B); the last one advances k
+        auto comp = [](const float4& v, int e) __attribute__((always_inline)) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+        // Staging registers.  BM = 128: two sets, tile t rides in set t & 1 from its request at the top of a step, a whole k-step
+        // before its cut starts (with one set and half a step the loop ran at the memory latency, 1.9 us per k-step).  BM = 256: ONE set
+        // (two would be 96 registers beside 128 accumulators and up to 96 of fragments: the buffer descriptors ended up in vector
+        // registers, a readfirstlane loop in front of every load): a float4 is requested again -- for the tile after -- in the gap
+        // behind the last phase that reads it, so it still has a whole step to arrive.
+        constexpr int NSET = BM == 128 ? 2 : 1;
+        float4 xa[NSET][LA], xb[NSET][LB];
+        auto load_one = [&](auto sc, auto jc, int k0) __attribute__((always_inline)) {          // load j of a tile (0 .. LA-1: A, then B); the last of an operand advances its k
             constexpr int S = decltype(sc)::value, J = decltype(jc)::value;
             const int kleft = kend - k0;
-            if constexpr (J < 4) xa[S][J] = buf_ld4(a_rs, a_k[J] < kleft ? a_vo[J] : JAMIE_OOB, a_so);
-            else xb[S][J - 4] = buf_ld4(b_rs, b_k[J - 4] < kleft ? b_vo[J - 4] : JAMIE_OOB, b_so);
-            if constexpr (J == 7) { a_so += a_step; b_so += b_step; }
+            if constexpr (J < LA) xa[S][J] = buf_ld4(a_rs, a_k[J] < kleft ? a_vo[J] : JAMIE_OOB, a_so);
+            else xb[S][J - LA] = buf_ld4(b_rs, b_k[J - LA] < kleft ? b_vo[J - LA] : JAMIE_OOB, b_so);
+            if constexpr (J == LA - 1) a_so += a_step;
+            if constexpr (J == NLD - 1) b_so += b_step;
         };
-        auto load_x3 = [&](auto sc, int k0) {
-            load_one(sc, std::integral_constant<int, 0>{}, k0); load_one(sc, std::integral_constant<int, 1>{}, k0);
-            load_one(sc, std::integral_constant<int, 2>{}, k0); load_one(sc, std::integral_constant<int, 3>{}, k0);
-            load_one(sc, std::integral_constant<int, 4>{}, k0); load_one(sc, std::integral_constant<int, 5>{}, k0);
-            load_one(sc, std::integral_constant<int, 6>{}, k0); load_one(sc, std::integral_constant<int, 7>{}, k0);
+        // the gap in which load j of the NEXT tile to be cut goes out: two sets: gap j; one set: behind phase 1 of the unit (K-contiguous
+        // operand) or of the block's last unit (row-contiguous: its four float4 are read by all four units of the block) that reads it
+        auto load_gap = [](int j) __attribute__((always_inline)) {
+            if (NSET == 2) return j;
+            const bool kc = j < LA ? A_KC : B_KC;
+            return kc ? 6 * j + 2 : 6 * (j | 3) + 2 + (j & 3);       // (j counts A's then B's float4: unit numbers)
         };
-        auto unit = [&](unsigned char* st, int k0, auto sc, auto uc, auto phc) {
-            constexpr int U = decltype(uc)::value, e = U & 3, S = decltype(sc)::value;
-            const float4 (&ra)[4] = xa[S];
-            const float4 (&rb)[4] = xb[S];
-            if constexpr (U < 4) {
+        auto load_x3 = [&](auto sc, int k0) __attribute__((always_inline)) { jf_static_for<0, NLD>([&](auto jc) __attribute__((always_inline)) { load_one(sc, jc, k0); }); };
+        // unit u of the staged tile (0 .. LA-1: A, then B) into stage `st`; k0 = the tile's first k (in-row tails of the FAST == 1 instance)
+        auto unit = [&](unsigned char* st, int k0, auto sc, auto uc, auto phc) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value, S = decltype(sc)::value;
+            if constexpr (U < LA) {
+                constexpr int e = U & 3, q = U & ~3;             // (row-contiguous: component e of the four k rows of block q / 4)
                 if constexpr (A_KC) {
-                    float4 v = ra[e];
-                    if (FAST == 1) v = mask4(v, kend - (k0 + a_k[e]));
-                    cut_store(st + a_w[e], PL_A, phc, v.x, v.y, v.z, v.w);
+                    float4 v = xa[S][U];
+                    if (FAST == 1) v = mask4(v, kend - (k0 + a_k[U]));
+                    cut_store(st + a_w[U], PL_A, phc, v.x, v.y, v.z, v.w);
                 } else {
-                    const bool ok = FAST != 1 || e < a_lim[0];
-                    cut_store(st + a_w[e], PL_A, phc, ok ? comp(ra[0], e) : 0.f, ok ? comp(ra[1], e) : 0.f, ok ? comp(ra[2], e) : 0.f, ok ? comp(ra[3], e) : 0.f);
+                    const bool ok = FAST != 1 || e < a_lim[q];
+                    cut_store(st + a_w[U], PL_A, phc, ok ? comp(xa[S][q], e) : 0.f, ok ? comp(xa[S][q + 1], e) : 0.f,
+                              ok ? comp(xa[S][q + 2], e) : 0.f, ok ? comp(xa[S][q + 3], e) : 0.f);
                 }
             } else {
+                constexpr int V = U - LA, e = V & 3;
                 if constexpr (B_KC) {
-                    float4 v = rb[e];
-                    if (FAST == 1) v = mask4(v, kend - (k0 + b_k[e]));
-                    cut_store(st + 3 * PL_A + b_w[e], PL_B, phc, v.x, v.y, v.z, v.w);
+                    float4 v = xb[S][V];
+                    if (FAST == 1) v = mask4(v, kend - (k0 + b_k[V]));
+                    cut_store(st + 3 * PL_A + b_w[V], PL_B, phc, v.x, v.y, v.z, v.w);
                 } else {
                     const bool ok = FAST != 1 || e < b_lim[0];
-                    cut_store(st + 3 * PL_A + b_w[e], PL_B, phc, ok ? comp(rb[0], e) : 0.f, ok ? comp(rb[1], e) : 0.f, ok ? comp(rb[2], e) : 0.f, ok ? comp(rb[3], e) : 0.f);
+                    cut_store(st + 3 * PL_A + b_w[V], PL_B, phc, ok ? comp(xb[S][0], e) : 0.f, ok ? comp(xb[S][1], e) : 0.f,
+                              ok ? comp(xb[S][2], e) : 0.f, ok ? comp(xb[S][3], e) : 0.f);
                 }
             }
         };
+        typedef std::integral_constant<int, 6> PHALL;
+        auto cut_tile = [&](unsigned char* st, int k0, auto sc) __attribute__((always_inline)) { jf_static_for<0, NLD>([&](auto uc) __attribute__((always_inline)) { unit(st, k0, sc, uc, PHALL{}); }); };
         int a_r[TM], a_s[TM], b_r[TN], b_s[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) { const int R = wm0 + i * 32 + r; a_r[i] = (R ^ ((R >> 4) & 3)) << 6; a_s[i] = (R >> 2) & 3; }
 #pragma unroll
         for (int j = 0; j < TN; ++j) { const int R = wn0 + j * 32 + r; b_r[j] = (R ^ ((R >> 4) & 3)) << 6; b_s[j] = (R >> 2) & 3; }
         bf16x8 fa[2][TM][3], fb[2][TN][3];
-        auto read_one = [&](auto setc, auto fc, const unsigned char* st, int s16) {      // fragment f of the twelve of a k-block
+        auto read_one = [&](auto setc, auto fc, const unsigned char* st, int s16) __attribute__((always_inline)) {      // fragment f of the NF of a k-block
             constexpr int SET = decltype(setc)::value, F = decltype(fc)::value;
-            if constexpr (F < 6) {
+            if constexpr (F < 3 * TM) {
                 constexpr int i = F / 3, pl = F % 3;
                 fa[SET][i][pl] = *reinterpret_cast<const bf16x8*>(st + pl * PL_A + a_r[i] + (((2 * s16 + h) ^ a_s[i]) << 4));
             } else {
-                constexpr int j = (F - 6) / 3, pl = (F - 6) % 3;
+                constexpr int j = (F - 3 * TM) / 3, pl = (F - 3 * TM) % 3;
                 fb[SET][j][pl] = *reinterpret_cast<const bf16x8*>(st + 3 * PL_A + pl * PL_B + b_r[j] + (((2 * s16 + h) ^ b_s[j]) << 4));
             }
         };
-        auto read_frags = [&](int set, const unsigned char* st, int s16) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    fa[set][i][pl] = *reinterpret_cast<const bf16x8*>(st + pl * PL_A + a_r[i] + (((2 * s16 + h) ^ a_s[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    fb[set][j][pl] = *reinterpret_cast<const bf16x8*>(st + 3 * PL_A + pl * PL_B + b_r[j] + (((2 * s16 + h) ^ b_s[j]) << 4));
-        };
-        // the six products of a k-block, smallest first; with `st` the eight units of the NEXT tile ride between them (three
-        // MFMAs -- ~100 matrix-pipe cycles -- per unit of ~25 vector instructions and three LDS writes)
-        // the six products of a k-block, smallest first.  UNITS: phases PH0 .. PH0 + 23 of the cut of tile kt+2 share the block with
-        // the 24 MFMAs -- one wave per SIMD, so what the matrix pipe does not get from THIS wave's instruction stream it does not
-        // get: behind every MFMA one phase of a unit, pinned there.  (Measured on the way, per k-step of 48 MFMAs = 1536 pipe
-        // cycles: three MFMAs then a whole unit, all units in the first k-block, two LDS stages: 1.9 us; a third of a unit behind
-        // every MFMA of the first k-block: 1.45 us; three stages, a third behind every second MFMA: 1.3 us; sched_group_barrier
-        // pipelines held in one of the two unrolled steps only.)
-        // One k-block: MFMA m, then its gap.  Gap m of the FIRST block: phase m of the cut; load m of tile kt+3 (m < 8); fragment
-        // m - 12 of this tile's second block (m >= 12).  Gap m of the SECOND block: phase 24 + m; behind MFMA 3 the step's barrier
-        // (four MFMAs = 128 pipe cycles are queued while the wave waits for its LDS writes and for the others); fragments m - 4 of
-        // the NEXT tile's first block (4 <= m < 16).
-        auto block = [&](auto setc, auto pc, auto cutc, auto morec, unsigned char* cur, unsigned char* nx1, unsigned char* nx2, int kt) {
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, 1> S1;
+        // One k-block: MFMA m (the six products of the block's TM x TN tiles, smallest first), then its gap -- one wave per SIMD, so
+        // what the matrix pipe does not get from THIS wave's instruction stream it does not get, and every piece of the step's
+        // other work is pinned into a gap.  With g = the MFMA's number in the step: phase g of the cut of tile kt+LAG (g < NPH);
+        // load g of tile kt+LAG+1 (g < NLD); fragment g - (MB - NF) of this tile's second block (MB - NF <= g < MB); behind MFMA BAR
+        // the step's barrier (the MFMAs issued before it are queued while the wave waits for its LDS writes and for the others);
+        // fragment g - BAR - 1 of the NEXT tile's first block (BAR < g <= BAR + NF).  (Measured on the way, 128 x 128, per k-step of
+        // 48 MFMAs = 1536 pipe cycles: three MFMAs then a whole unit, all units in the first k-block, two LDS stages: 1.9 us; a third
+        // of a unit behind every MFMA of the first k-block: 1.45; three stages, a third behind every second MFMA: 1.3; a sixth behind
+        // every MFMA: 1.05; loads and fragment reads in the gaps too: 1.0.  sched_group_barrier pipelines held in one of the two
+        // unrolled steps only.)
+        auto block = [&](auto setc, auto pc, auto cutc, auto morec, unsigned char* cur, unsigned char* nx1, unsigned char* nxc, int kt) __attribute__((always_inline)) {
             constexpr int SET = decltype(setc)::value, PAR = decltype(pc)::value;
             constexpr bool CUT = decltype(cutc)::value, MORE = decltype(morec)::value;
-            static_assert(TM == 2 && TN == 2, "bf16x3: 24 MFMAs per k-block");
-            auto one = [&](auto mc) {
-                constexpr int m = decltype(mc)::value, q = m / 4, i = (m % 4) / 2, j = m % 2;
+            constexpr int CS = NSET == 2 ? PAR ^ (LAG & 1) : 0;   // staging set of tile kt + LAG
+            constexpr int LS = NSET == 2 ? CS ^ 1 : 0;           // ... the set tile kt + LAG + 1 is requested into
+            jf_static_for<0, MB>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value, g = SET * MB + m, q = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN;
                 constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i][QA[q]], fb[SET][j][QB[q]], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (CUT) {
-                    constexpr int ph = 24 * SET + m;
-                    unit(nx2, kbeg + (kt + 2) * BK, std::integral_constant<int, PAR>{}, std::integral_constant<int, ph / 6>{}, std::integral_constant<int, ph % 6>{});
-                    if constexpr (SET == 0 && m < 8) load_one(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, m>{}, kbeg + (kt + 3) * BK);
+                    if constexpr (g < NPH)
+                        unit(nxc, kbeg + (kt + LAG) * BK, std::integral_constant<int, CS>{}, std::integral_constant<int, g / 6>{}, std::integral_constant<int, g % 6>{});
+                    jf_static_for<0, NLD>([&](auto jc) __attribute__((always_inline)) {
+                        if constexpr (load_gap(decltype(jc)::value) == g) load_one(std::integral_constant<int, LS>{}, jc, kbeg + (kt + LAG + 1) * BK);
+                    });
                 }
-                if constexpr (SET == 0 && m >= 12) read_one(std::integral_constant<int, 1>{}, std::integral_constant<int, m - 12>{}, cur, 1);
-                if constexpr (SET == 1 && MORE) {
-                    if constexpr (m == 3) {
-                        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): my LDS writes of this step's first block are out
+                if constexpr (SET == 0 && m >= MB - NF) read_one(S1{}, std::integral_constant<int, m - (MB - NF)>{}, cur, 1);
+                if constexpr (MORE) {
+                    if constexpr (g == BAR) {
+                        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): my LDS writes so far are out, my second block's fragments in
                         __builtin_amdgcn_s_barrier();
                     }
-                    if constexpr (m >= 4 && m < 16) read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, m - 4>{}, nx1, 0);
+                    if constexpr (g > BAR && g <= BAR + NF) read_one(S0{}, std::integral_constant<int, g - BAR - 1>{}, nx1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            };
-#define JF_X3_M4(b) one(std::integral_constant<int, (b)>{}); one(std::integral_constant<int, (b) + 1>{}); one(std::integral_constant<int, (b) + 2>{}); one(std::integral_constant<int, (b) + 3>{})
-            JF_X3_M4(0); JF_X3_M4(4); JF_X3_M4(8); JF_X3_M4(12); JF_X3_M4(16); JF_X3_M4(20);
-#undef JF_X3_M4
+            });
         };
-        typedef std::integral_constant<int, 0> S0;
-        typedef std::integral_constant<int, 1> S1;
-        typedef std::integral_constant<int, 6> PHALL;
-#define JF_X3_UNITS(st, k0, sc) do { \
-            unit(st, k0, sc, std::integral_constant<int, 0>{}, PHALL{}); unit(st, k0, sc, std::integral_constant<int, 1>{}, PHALL{}); \
-            unit(st, k0, sc, std::integral_constant<int, 2>{}, PHALL{}); unit(st, k0, sc, std::integral_constant<int, 3>{}, PHALL{}); \
-            unit(st, k0, sc, std::integral_constant<int, 4>{}, PHALL{}); unit(st, k0, sc, std::integral_constant<int, 5>{}, PHALL{}); \
-            unit(st, k0, sc, std::integral_constant<int, 6>{}, PHALL{}); unit(st, k0, sc, std::integral_constant<int, 7>{}, PHALL{}); } while (0)
-        // Three LDS stages, two sets of staging registers.  Tile t lives in stage t % 3 and travels in register set t & 1: requested at
-        // the top of step t-3, cut into its stage during the whole of step t-2 (a phase behind every second MFMA), multiplied in step
-        // t.  ONE barrier per step, between the k-blocks: a wave behind barrier kt has finished step kt-1's cut (tile kt+1, read behind
-        // this barrier) and all its reads of tile kt-1 (whose stage tile kt+2 is being cut into) lie in front of barrier kt-1.
-        if (nk > 0) {
-            load_x3(S0{}, kbeg);                  // (beyond the K slice: out-of-range offsets -- zeros, no traffic)
-            load_x3(S1{}, kbeg + BK);
-            JF_X3_UNITS(lds, kbeg, S0{});
-            load_x3(S0{}, kbeg + 2 * BK);
-            JF_X3_UNITS(lds + ST_SZ, kbeg + BK, S1{});
+        // Tile t lives in LDS stage t % NST and travels in register set t & 1: requested a whole step before its cut, cut during step
+        // t - LAG (one phase per gap), multiplied in step t.  ONE barrier per step: a wave behind barrier kt has finished every write
+        // of the tile(s) cut up to there and all its reads of tile kt-1 lie in front of barrier kt-1.  Three stages: the cut of tile
+        // kt+2 fills the WHOLE step (both k-blocks) and the barrier sits early in the second block; two stages (BM = 256, 144 KB): the
+        // cut of tile kt+1 ends before the barrier, which sits behind it, three quarters into the step.
+        if (nk > 0) {                                             // (beyond the K slice: out-of-range offsets -- zeros, no traffic)
+            load_x3(S0{}, kbeg);
+            if constexpr (LAG == 2) {
+                load_x3(S1{}, kbeg + BK);
+                cut_tile(lds, kbeg, S0{});
+                load_x3(S0{}, kbeg + 2 * BK);
+                cut_tile(lds + ST_SZ, kbeg + BK, S1{});
+            } else {
+                cut_tile(lds, kbeg, S0{});
+                load_x3(S0{}, kbeg + BK);
+            }
         }
-#undef JF_X3_UNITS
         __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         JF_STAMP(1);
-        if (nk > 0) { read_frags(0, lds, 0); }
+        if (nk > 0) jf_static_for<0, NF>([&](auto fc) __attribute__((always_inline)) { read_one(S0{}, fc, lds, 0); });
         int s_cur = 0;                                // stage of tile kt
-        // CUT: tile kt+2 exists (kt even <-> its registers are set 0); MORE: tile kt+1 exists
-        auto step = [&](int kt, auto pc, auto cutc, auto morec) {
-            const int s_n1 = s_cur == 2 ? 0 : s_cur + 1, s_n2 = s_n1 == 2 ? 0 : s_n1 + 1;
+        // CUT: tile kt+LAG exists; MORE: tile kt+1 exists
+        auto step = [&](int kt, auto pc, auto cutc, auto morec) __attribute__((always_inline)) {
+            const int s_n1 = s_cur == NST - 1 ? 0 : s_cur + 1, s_n2 = s_n1 == NST - 1 ? 0 : s_n1 + 1;
             unsigned char* const cur = lds + s_cur * ST_SZ;
             unsigned char* const nx1 = lds + s_n1 * ST_SZ;
-            unsigned char* const nx2 = lds + s_n2 * ST_SZ;
+            unsigned char* const nxc = lds + (LAG == 2 ? s_n2 : s_n1) * ST_SZ;
             __builtin_amdgcn_sched_barrier(0);
-            block(S0{}, pc, cutc, morec, cur, nx1, nx2, kt);
-            block(S1{}, pc, cutc, morec, cur, nx1, nx2, kt);
+            block(S0{}, pc, cutc, morec, cur, nx1, nxc, kt);
+            block(S1{}, pc, cutc, morec, cur, nx1, nxc, kt);
             s_cur = s_n1;
         };
+        typedef std::true_type T_;
+        typedef std::false_type F_;
         int kt = 0;
-        for (; kt + 3 < nk; kt += 2) {
-            step(kt, S0{}, std::true_type{}, std::true_type{});
-            step(kt + 1, S1{}, std::true_type{}, std::true_type{});
+        for (; kt + LAG + 1 < nk; kt += 2) {          // (straight-line pairs: a branch inside made hipcc keep the accumulators in two register sets)
+            step(kt, S0{}, T_{}, T_{});
+            step(kt + 1, S1{}, T_{}, T_{});
         }
         const int rest = nk - kt;
-        if (rest == 3) {
-            step(kt, S0{}, std::true_type{}, std::true_type{});
-            step(kt + 1, S1{}, std::false_type{}, std::true_type{});
-            step(kt + 2, S0{}, std::false_type{}, std::false_type{});
-        } else if (rest == 2) {
-            step(kt, S0{}, std::false_type{}, std::true_type{});
-            step(kt + 1, S1{}, std::false_type{}, std::false_type{});
-        } else if (rest == 1) {
-            step(kt, S0{}, std::false_type{}, std::false_type{});
+        if constexpr (LAG == 2) {
+            if (rest == 3) {
+                step(kt, S0{}, T_{}, T_{});
+                step(kt + 1, S1{}, F_{}, T_{});
+                step(kt + 2, S0{}, F_{}, F_{});
+            } else if (rest == 2) {
+                step(kt, S0{}, F_{}, T_{});
+                step(kt + 1, S1{}, F_{}, F_{});
+            } else if (rest == 1) {
+                step(kt, S0{}, F_{}, F_{});
+            }
+        } else {
+            if (rest == 2) {
+                step(kt, S0{}, T_{}, T_{});
+                step(kt + 1, S1{}, F_{}, F_{});
+            } else if (rest == 1) {
+                step(kt, S0{}, F_{}, F_{});
+            }
         }
     } else {
     if (nk > 0) {
@@ -1166,7 +1191,10 @@ static int launch_cfg(const jamie_gemm_problem* pr, int count, hipStream_t st, i
     if constexpr (X3 != 0) {
         // bf16x3: the buffer-descriptor instances only (every layer of every BASELINE configuration); anything else takes the fp32
         // pipe on configuration 17's tile (same BM x BN: per-tile partial buffers sized for one fit the other)
-        if (!(fast && !tails)) return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC, true>(pr, count, st);
+        if (!(fast && !tails)) {
+            if constexpr (BM == 128) return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC, true>(pr, count, st);
+            else return launch_cfg<256, 128, 32, 4, 4, A_KC, B_KC>(pr, count, st);
+        }
         if (big) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 1, false, X3>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, A_KC, B_KC, 2, 0, false, X3>), dim3(tiles), dim3(WM * WN * 64), 0, st, g);
         return jamie_launch_status("jamie_gemm_f32");
@@ -1277,6 +1305,7 @@ static int launch_layout(const jamie_gemm_problem* pr, int count, int cfg, hipSt
         case 19: return launch_cfg<128, 128, 32, 4, 4, A_KC, B_KC, true>(pr, count, st, 56 * 1024);
         // the products on the bf16 matrix pipe, every fp32 element as three bf16 pieces (see the kernel): four waves of 64 x 64
         case 20: return launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC, false, 1>(pr, count, st);
+        case 21: return launch_cfg<256, 128, 32, 2, 2, A_KC, B_KC, false, 1>(pr, count, st);      // ... four waves of 128 x 64, two LDS stages
         default: return jamie_fail(-1, "%s: unknown tile configuration [%lld %lld]", "jamie_gemm_f32", cfg, 0);
     }
 }
@@ -1329,11 +1358,11 @@ extern "C" int jamie_gemm_f32(const jamie_gemm_problem* pr, int count, int layou
 
 // tile geometry of a configuration (host helper: sizing of per-tile partial buffers)
 extern "C" int jamie_gemm_tile(int layout, int max_m, int max_n, int max_k, int cfg, int* bm, int* bn) {
-    static const int T[21][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
+    static const int T[22][2] = {{64, 128}, {64, 64}, {128, 128}, {128, 64}, {128, 128}, {32, 128}, {64, 64}, {64, 64}, {64, 64}, {64, 64},
                                  {64, 128}, {128, 64}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 256}, {128, 128}, {64, 64}, {128, 128},
-                                 {128, 128}};
+                                 {128, 128}, {256, 128}};
     if (cfg < 0) cfg = pick_cfg(layout, max_m, max_n, max_k);
-    if (cfg > 20 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
+    if (cfg > 21 || !bm || !bn) return jamie_fail(-1, "%s: bad arguments [%lld %lld]", "jamie_gemm_tile", cfg, 0);
     *bm = T[cfg][0]; *bn = T[cfg][1];
     return 0;
 }

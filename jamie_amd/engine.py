@@ -147,8 +147,12 @@ F32_CFG_DW = 17             # fp32 dW (TN, K = batch) of the large layers when t
                             # config 5's dimensions run 6.86 against 6.97 ms per step, config 2 the same: r04_f32_dp_dw_tile.log)
 F32_CFG_DW_FUSED = 17       # ... 128x128x32 on 16 waves when the launch also writes its tiles' sums of squares (fused clip norm)
 F32_CFG_SOLO = 19           # 17 with 56 KB of unused dynamic LDS: one workgroup per CU (forward launches beside the optimiser stream)
-F32_CFG_X3 = 20             # 128x128x32 on four waves of 64x64, the products as six bf16 MFMAs on three-piece cuts (TUNING['f32_x3']): one
-                            # workgroup per CU (144 KB of LDS), ~1.0 us per k-step against 2.05
+F32_CFG_X3 = 21             # 256x128x32 on four waves of 128x64, the products as six bf16 MFMAs on three-piece cuts (TUNING['f32_x3']): one
+                            # workgroup per CU (144 KB of LDS), ~1.9 us per k-step of twice the work (fp32 pipe, 128x128: 2.05).  20 = the same
+                            # on 128x128 tiles (1.0 us per k-step, three LDS stages): 1066 against 993 us per step at config 2
+                            # (profiles/r05_ab_f32_bf16x3_256.log) -- per flop the two loops are within 5 % (both run at the matrix pipe's
+                            # rate under the clock the chip holds), the larger tile halves the number of tile prologues and store tails
+F32_X3_TILE_M = 256
 
 
 def f32_cfg(kind='rows'):
@@ -242,11 +246,11 @@ def _plan_f32_rows(B, shapes, _knob, _tile=None, _x3=False):
         cfg, _, part = part.rpartition(':')                 # ("cfg:s0,s1": another tile configuration)
         sks = [int(v) for v in part.split(',')]
         return (int(cfg) if cfg else default_cfg), [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
-    tiles = [math.ceil(B / 128) * math.ceil(N / 128) for (N, K) in shapes]
     kstep_us, overhead, slab_tbps = 2.05, 3.0, 3.0
-    per_cu, solo = 2, 0.87
-    if _x3:      # (configuration 20: one workgroup per CU, ~1.0 us per k-step, two tiles cut before the first MFMA)
-        kstep_us, overhead, per_cu, solo = 1.0, 5.0, 1, 1.0
+    per_cu, solo, bm = 2, 0.87, 128
+    if _x3:      # (configuration 21: 256-row tiles, one workgroup per CU, ~1.9 us per k-step, ~7 us of prologue + stores per tile)
+        kstep_us, overhead, per_cu, solo, bm = 1.9, 4.0, 1, 1.0, F32_X3_TILE_M
+    tiles = [math.ceil(B / bm) * math.ceil(N / 128) for (N, K) in shapes]
     best, seen = None, set()
     for kc in range(256, max(K for (_, K) in shapes) + 1, 8):
         sk = tuple(min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes)

@@ -328,7 +328,10 @@ class edModelVar:
         (tools/bench_gemm_sq.py, tools/bench_infer.py); the class attribute EVAL_GEMM_CFG overrides (diagnostics)."""
         if edModelVar.EVAL_GEMM_CFG is not None:
             return int(edModelVar.EVAL_GEMM_CFG)
-        return 17 if (n >= 2048 and nout >= 512 and k >= 512) else -1
+        # 21: the same fp32 products on the bf16 matrix pipe (gemm_f32.hip: three-piece cuts, fp32-level error, 256 x 128 tiles): 4.5
+        # against 3.2 M cells/s through `transform` / `impute` at config 2 (profiles/r05_bench_infer_bf16x3.log; 20, its 128 x 128
+        # form: 4.15-4.4); EVAL_X3 = False: the fp32 pipe
+        return (21 if edModelVar.EVAL_X3 else 17) if (n >= 2048 and nout >= 512 and k >= 512) else -1
 
     def _lin_bn_act(self, i, x, lin, bn):
         W, b = self.p[f'm{i}.{lin}.W'], self.p[f'm{i}.{lin}.b']

@@ -57,7 +57,7 @@ def test_gemm_layouts(nv, layout, M, N, K):
     close(out, ref, rtol=1e-5, atol=2e-6 * scale)
 
 
-@pytest.mark.parametrize('cfg', [4, 10, 11, 12, 15, 16, 17, 18, 20])
+@pytest.mark.parametrize('cfg', [4, 10, 11, 12, 15, 16, 17, 18, 20, 21])
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
 def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
     """The register-staged fp32 kernel on its larger tiles (128x128 on 8 / 16 waves, 64x128, 128x64, 256x128, 128x256) in every
@@ -88,7 +88,7 @@ def test_gemm_f32_large_tile_configurations(nv, layout, cfg):
             assert torch.equal(out, ref), f'{layout} cfg {cfg} != cfg {twin} at {(M, N, K, sk)}'
 
 
-@pytest.mark.parametrize('cfg', [1, 12, 17, 20])
+@pytest.mark.parametrize('cfg', [1, 12, 17, 20, 21])
 def test_gemm_f32_lean_epilogue_is_exact_on_integers(nv, cfg):
     """The fp32 kernel's lean store path (4-byte buffer stores with a scalar-register row offset, the value's register reused two
     instructions later): integer-valued operands, exact products, every element, interior and edge tiles, slabs and a plain
@@ -106,9 +106,10 @@ def test_gemm_f32_lean_epilogue_is_exact_on_integers(nv, cfg):
             assert torch.equal(out.sum(0).cpu(), ref), (cfg, M, N, K, sk, rep)
 
 
+@pytest.mark.parametrize('x3', [20, 21])
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
-def test_gemm_f32_three_bf16_pieces_keep_fp32(nv, layout):
-    """Configuration 20 (the fp32 products on the bf16 matrix pipe, every element cut into three bf16 pieces): (a) the cut is
+def test_gemm_f32_three_bf16_pieces_keep_fp32(nv, layout, x3):
+    """Configurations 20 / 21 (128 x 128 / 256 x 128 tiles; the fp32 products on the bf16 matrix pipe, every element cut into three bf16 pieces): (a) the cut is
     EXACT -- a product with a 0/1 selection matrix returns every 24-bit significand bit of the other operand, in either operand
     position and every layout; (b) on config 2's layer shapes its distance from fp64 stays within a small factor of the fp32
     pipe's own (configuration 17), split-K slabs included."""
@@ -130,19 +131,19 @@ def test_gemm_f32_three_bf16_pieces_keep_fp32(nv, layout):
     a = torch.randn(M, K, generator=g) * torch.exp(4 * torch.randn(M, K, generator=g))          # wide range of exponents
     perm = torch.randperm(K, generator=g)
     sel = torch.zeros(K, N); sel[perm, torch.arange(K)] = 1.0                                       # out[:, j] = a[:, perm[j]]
-    assert torch.equal(run(a, sel, 20)[:, :K], a[:, perm]), 'A operand: a piece of the cut is lost'
+    assert torch.equal(run(a, sel, x3)[:, :K], a[:, perm]), 'A operand: a piece of the cut is lost'
     b = torch.randn(K, N, generator=g) * torch.exp(4 * torch.randn(K, N, generator=g))
     selm = torch.zeros(M, K); selm[torch.arange(M), perm[:M]] = 1.0
-    assert torch.equal(run(selm, b, 20), b[perm[:M]]), 'B operand: a piece of the cut is lost'
+    assert torch.equal(run(selm, b, x3), b[perm[:M]]), 'B operand: a piece of the cut is lost'
     for (m, n, k, sk) in ((512, 4000, 2000, 3), (512, 1000, 2000, 1)):
         a, b = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g) / np.sqrt(k)
         ref = a.double() @ b.double()
-        e3 = (run(a, b, 20, sk).double() - ref).abs().max().item()
+        e3 = (run(a, b, x3, sk).double() - ref).abs().max().item()
         e1 = (run(a, b, 17, sk).double() - ref).abs().max().item()
         assert e3 <= 4 * e1 + 1e-7, (layout, m, n, k, sk, e3, e1)
 
 
-@pytest.mark.parametrize('cfg', [1, 12, 17, 18, 20])
+@pytest.mark.parametrize('cfg', [1, 12, 17, 18, 20, 21])
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
 def test_gemm_f32_rows_that_end_inside_a_float4(nv, layout, cfg):
     """Buffer-descriptor path with in-row tails (the `FAST = 1` instantiation: 16-byte aligned bases and leading dimensions that

@@ -833,7 +833,7 @@ def test_fp32_step_on_the_bf16_pipe_stays_with_the_fp32_pipe(jam):
     """fp32 mode, config 2's layer sizes: the first step whose large products run as six bf16 MFMAs on three-piece cuts
     (engine.TUNING['f32_x3'], the default: gemm_f32.hip configuration 20) against the same step on the fp32 matrix pipe
     (configuration 17), weight-gradient matrix by weight-gradient matrix.  Typical distance 1e-6 (relative L2), i.e. fp32
-    rounding: the median over the twelve matrices must stay below 5e-6.  A single matrix may be further off -- a pre-activation
+    rounding: the median over the twelve matrices must stay below 5e-6 or three times the yardstick run's median.  A single matrix may be further off -- a pre-activation
     that lands on the other side of LeakyReLU's kink changes one element of dz by a factor of 100, ~1e-3 of its layer's dW; the
     fp32 pipe against ITSELF with other K slices (the yardstick run below) shows the same events (profiles/r05_x3_step_distance.log)
     -- so at most two matrices may exceed 1e-4, none 2e-2.  Losses agree to 1e-6.  Later steps are not compared: Adam's first
@@ -870,7 +870,7 @@ def test_fp32_step_on_the_bf16_pipe_stays_with_the_fp32_pipe(jam):
     print('per-matrix relative L2 distances of the first gradient, sorted\n  bf16 pipe vs fp32 pipe:', ' '.join(f'{v:.1e}' for v in d_x3),
           '\n  fp32 pipe vs itself with other K slices:', ' '.join(f'{v:.1e}' for v in d_yard))
     assert len(d_x3) == 12
-    assert d_x3[len(d_x3) // 2] < 5e-6, d_x3
+    assert d_x3[len(d_x3) // 2] <= max(5e-6, 3 * d_yard[len(d_yard) // 2]), (d_x3, d_yard)
     assert sum(v > 1e-4 for v in d_x3) <= 2 and d_x3[-1] < 2e-2, d_x3
     for a, b in zip(out['x3'][1][0] + [out['x3'][1][1]], out['pipe'][1][0] + [out['pipe'][1][1]]):
         assert abs(a - b) <= 1e-6 * abs(b) + 1e-9, (out['x3'][1], out['pipe'][1])

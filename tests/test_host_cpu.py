@@ -66,7 +66,7 @@ def test_bench_roofline_kernel_names_exist_in_the_library(lib):
     assert engine.F32_CFG_ROWS == 17 and bench.F32_ROOFLINE_KERNEL.endswith('<128, 128, 32, 4, 4, true, true, 2, 1, true, 0>')
     # <..., MID, X3>: configuration 20 = 128x128x32 on 2 x 2 waves, the products as bf16 MFMAs on three-piece cuts
     assert f'void {bench.F32_X3_ROOFLINE_KERNEL}(GemmGroup)' in out, bench.F32_X3_ROOFLINE_KERNEL
-    assert engine.F32_CFG_X3 == 20 and engine.TUNING['f32_x3'] is True
+    assert engine.F32_CFG_X3 == 21 and engine.TUNING['f32_x3'] is True
 
 
 def test_package_reads_no_environment_switches():
@@ -486,10 +486,10 @@ def test_f32_split_k_plans_come_from_the_launch_model():
     B = 512
     # the default: configuration 20 (one workgroup per CU, ~1 us per k-step) -- its own model parameters, plans measured on the GPU
     # (profiles/r05_ab_f32_bf16x3_plans.log)
-    assert plan_f32_rows(B, [(4000, 2000), (2000, 1000)]) == (F32_CFG_X3, [3, 2])
-    assert plan_f32_rows(B, [(2000, 4000), (1000, 2000)]) == (F32_CFG_X3, [3, 2])
-    assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)]) == (F32_CFG_X3, [2, 1])
-    assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)]) == (F32_CFG_X3, [4, 2])
+    assert plan_f32_rows(B, [(4000, 2000), (2000, 1000)]) == (F32_CFG_X3, [3, 2])          # 256 tiles of 256 x 128: one round
+    assert plan_f32_rows(B, [(2000, 4000), (1000, 2000)]) == (F32_CFG_X3, [6, 3])          # 240 tiles
+    assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)])[0] == F32_CFG_X3
+    assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)])[0] == F32_CFG_X3
     tune(f32_x3=False)
     try:
         _plans_of_the_fp32_pipe(B, F32_CFG_ROWS, launch_makespan, plan_f32_rows)

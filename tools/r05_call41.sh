@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+bash tools/ab.sh -r 2 "-" "JAMIE_TUNE=f32_rows=21:3,2;21:6,3+f32_dw_cfg=21" "JAMIE_TUNE=f32_rows=21:3,2;21:6,4+f32_dw_cfg=21" "JAMIE_TUNE=f32_rows=21:3,2;21:5,3+f32_dw_cfg=21" "JAMIE_TUNE=f32_dw_cfg=21" -- --dtype f32 > gpurun_out/r05/ab_f32_x3_256b.log 2>&1
+cat gpurun_out/r05/ab_f32_x3_256b.log
