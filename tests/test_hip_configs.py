@@ -699,13 +699,24 @@ def _seeded_eval_model(jam, dims, L, seed=11):
     return model, P, Bf
 
 
-def test_eval_fast_path_many_rows_vs_oracle(jam):
-    """embed / impute at (2000, 1000) where the 128x128x32 tile + fused eval-BatchNorm epilogue run (n >= 2048 rows):
+@pytest.mark.parametrize('x3', [True, False])
+def test_eval_fast_path_many_rows_vs_oracle(jam, x3):
+    """embed / impute at (2000, 1000) where the large tile + fused eval-BatchNorm epilogue run (n >= 2048 rows) -- on the bf16
+    matrix pipe (configuration 21: three-piece cuts of every fp32 element, the default) and on the fp32 pipe (configuration 17):
     n = 5000 (not a tile multiple), chunked so that a chunk boundary and a short (< 2048 rows: default tile) last chunk
     are both crossed; rtol 1e-4 / atol 1e-5 against the oracle from identical weights (north_star's inference claim)."""
     dims, L = (2000, 1000), 32
     model, P, Bf = _seeded_eval_model(jam, dims, L)
-    assert model._eval_cfg(4096, 2000, 2000) == 17
+    type(model).EVAL_X3 = x3
+    try:
+        _eval_fast_path(model, P, Bf, dims, 21 if x3 else 17)
+    finally:
+        type(model).EVAL_X3 = True
+
+
+def _eval_fast_path(model, P, Bf, dims, cfg):
+    assert model._eval_cfg(4096, 2000, 2000) == cfg
+    assert model._eval_cfg(1000, 2000, 2000) == -1
     n = 5000
     X = _synth(n, dims, seed=8)
     with torch.no_grad():
