@@ -16,6 +16,9 @@
 //   * grouped launch: up to JAMIE_MAX_GEMM_GROUP_F32 problems (the modalities) share one grid; block ids are
 //     remapped so that the M-tiles that re-read one weight panel run back to back on one XCD (its L2).
 //   * split-K writes fp32 slabs (deterministic; the consumer kernel sums them).
+//   * configurations 20 / 21 (template argument X3): the same fp32 problems on the bf16 matrix pipe -- every element cut into
+//     three bf16 pieces on its way to LDS, six v_mfma_f32_32x32x16_bf16 per product, fp32-level error; the engine's default for
+//     the large layers since round 5 (see the kernel's X3 branch).
 #include "common.h"
 #include <type_traits>
 
