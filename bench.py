@@ -337,9 +337,11 @@ def encoder_gemm_record(eng, ms, config, dtype):
     return out
 
 
-def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=60, warmup=20, config='c2'):
-    """The parity configuration (exact-fp32 MFMA) on the same workload: cells/s, ms/step and the roofline of ITS dominant
-    kernel, the forward d <-> 2d Linear GEMM launch (north_star: >= 60 % of the binding roofline on the encoder matmul)."""
+def f32_record(model_dims, L, B, data, n_rows, rep, dev, steps=100, warmup=40, config='c2'):
+    """The parity configuration (fp32 tensors; the large products on the bf16 matrix pipe as six MFMAs on three-piece cuts, or on the
+    fp32 pipe with --tune f32_x3=False) on the same workload: cells/s, ms/step and the roofline of ITS dominant kernel, the forward
+    d <-> 2d Linear GEMM launch (north_star: >= 60 % of the binding roofline on the encoder matmul).  Runs in a child process that
+    starts cold: 40 untimed steps (the clock settles over the first ~15), 100 timed ones -- 0.15 s."""
     from jamie_amd.engine import TrainEngine
     from jamie_amd.model import edModelVar
     torch.manual_seed(666)
