@@ -153,6 +153,7 @@ F32_CFG_X3 = 21             # 256x128x32 on four waves of 128x64, the products a
                             # (profiles/r05_ab_f32_bf16x3_256.log) -- per flop the two loops are within 5 % (both run at the matrix pipe's
                             # rate under the clock the chip holds), the larger tile halves the number of tile prologues and store tails
 F32_X3_TILE_M = 256
+F32_CFG_X3_128 = 20         # the 128 x 128 form (three LDS stages): the planner takes it where it needs fewer K slices
 
 
 def f32_cfg(kind='rows'):
@@ -246,23 +247,32 @@ def _plan_f32_rows(B, shapes, _knob, _tile=None, _x3=False):
         cfg, _, part = part.rpartition(':')                 # ("cfg:s0,s1": another tile configuration)
         sks = [int(v) for v in part.split(',')]
         return (int(cfg) if cfg else default_cfg), [sks[min(i, len(sks) - 1)] for i in range(len(shapes))]
-    kstep_us, overhead, slab_tbps = 2.05, 3.0, 3.0
-    per_cu, solo, bm = 2, 0.87, 128
-    if _x3:      # (configuration 21: 256-row tiles, one workgroup per CU, ~1.9 us per k-step, ~7 us of prologue + stores per tile)
-        kstep_us, overhead, per_cu, solo, bm = 1.9, 4.0, 1, 1.0, F32_X3_TILE_M
-    tiles = [math.ceil(B / bm) * math.ceil(N / 128) for (N, K) in shapes]
-    best, seen = None, set()
-    for kc in range(256, max(K for (_, K) in shapes) + 1, 8):
-        sk = tuple(min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes)
-        if sk in seen:
-            continue
-        seen.add(sk)
-        works = [K / s / 32.0 + overhead for t, s, (_, K) in zip(tiles, sk, shapes) for _ in range(t * s)]
-        slabs = sum((s - 1) * B * N * 8.0 for s, (N, _) in zip(sk, shapes)) / (slab_tbps * 1e6)        # us
-        cost = launch_makespan(works, per_cu=per_cu, solo=solo) * kstep_us + slabs
-        if best is None or cost < best[0] - 1e-9:
-            best = (cost, list(sk))
-    return (int(_tile) if _tile not in (None, '') else default_cfg, best[1]) if best else (-1, None)
+    slab_tbps = 3.0
+    # (tile configuration, rows per tile, us per k-step, per-tile overhead in k-steps, workgroups per CU, a lone workgroup's rate)
+    if _x3:      # bf16x3: 256 x 128 tiles (half the tile prologues / store tails) or 128 x 128 (fewer K slices fill the chip: fewer
+        #          slabs for the consumer) -- whichever the model prices lower for this launch; one workgroup per CU either way
+        #          (k-step times under the clock the chip holds in launches of this length: 1.0 us was measured on short ones;
+        #          with it the model put config 5's launches on the small tile, measured 5.5 % slower there)
+        kinds = [(F32_CFG_X3, F32_X3_TILE_M, 1.9, 4.0, 1, 1.0), (F32_CFG_X3_128, 128, 1.15, 6.0, 1, 1.0)]
+    else:
+        kinds = [(F32_CFG_ROWS, 128, 2.05, 3.0, 2, 0.87)]
+    if _tile not in (None, ''):
+        kinds = [k for k in kinds if k[0] == int(_tile)] or [(int(_tile),) + kinds[0][1:]]
+    best = None
+    for cfg, bm, kstep_us, overhead, per_cu, solo in kinds:
+        tiles = [math.ceil(B / bm) * math.ceil(N / 128) for (N, K) in shapes]
+        seen = set()
+        for kc in range(256, max(K for (_, K) in shapes) + 1, 8):
+            sk = tuple(min(8, max(1, math.ceil(K / kc))) for (_, K) in shapes)
+            if sk in seen:
+                continue
+            seen.add(sk)
+            works = [K / s / 32.0 + overhead for t, s, (_, K) in zip(tiles, sk, shapes) for _ in range(t * s)]
+            slabs = sum((s - 1) * B * N * 8.0 for s, (N, _) in zip(sk, shapes)) / (slab_tbps * 1e6)        # us
+            cost = launch_makespan(works, per_cu=per_cu, solo=solo) * kstep_us + slabs
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, cfg, list(sk))
+    return (best[1], best[2]) if best else (-1, None)
 
 
 def kl_anneal(epoch, min_epochs, epoch_DNN):
@@ -1214,6 +1224,10 @@ class TrainEngine:
         """x_i = data_i[idx_i]  (jamie.py:583).  `idx` = list of int32 device tensors.  `with_wT=False`: the batch is being
         loaded while the optimiser may still be writing the weights (prefetch): leave the weight transposes to _backward."""
         if self.bf16:      # gather + bf16 copy (+ transposed copy) of the batch, and the skinny weights' transposes: one launch
+            # (pipelined optimiser: the optimiser stream makes those transposes behind each group's update; made here, beside it,
+            #  they read weights that clip + Adam may be half-way through and race its own copies: the next backward pass then
+            #  ran on stale skinny weights every few steps -- found by test_pipelined_optimizer_is_bit_identical run on its own)
+            with_wT = with_wT and not self.pipeline
             probs = self._batch_problems(data, idx)
             nv.cast_transpose(probs + (self._wT_problems() if with_wT else []))
             if with_wT:

@@ -487,9 +487,9 @@ def test_f32_split_k_plans_come_from_the_launch_model():
     # the default: configuration 20 (one workgroup per CU, ~1 us per k-step) -- its own model parameters, plans measured on the GPU
     # (profiles/r05_ab_f32_bf16x3_plans.log)
     assert plan_f32_rows(B, [(4000, 2000), (2000, 1000)]) == (F32_CFG_X3, [3, 2])          # 256 tiles of 256 x 128: one round
-    assert plan_f32_rows(B, [(2000, 4000), (1000, 2000)]) == (F32_CFG_X3, [6, 3])          # 240 tiles
-    assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)])[0] == F32_CFG_X3
-    assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)])[0] == F32_CFG_X3
+    assert plan_f32_rows(B, [(2000, 4000), (1000, 2000)]) == (20, [3, 2])                  # 256 tiles of 128 x 128: half the slabs of (6, 3)
+    assert plan_f32_rows(B, [(10000, 5000), (4000, 2000)]) == (F32_CFG_X3, [4, 2])         # config 5's dimensions: measured best
+    assert plan_f32_rows(B, [(5000, 10000), (2000, 4000)]) == (F32_CFG_X3, [5, 2])
     tune(f32_x3=False)
     try:
         _plans_of_the_fp32_pipe(B, F32_CFG_ROWS, launch_makespan, plan_f32_rows)
