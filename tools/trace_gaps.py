@@ -1,7 +1,8 @@
 """Launch timeline of the step from the rocprofv3 kernel trace of tools/profile_bench.sh's stats pass (gpurun_out/<tag>/stats):
 per launch of one steady-state step (median over the last steps): kernel duration, and the GAP between the end of the previous
 dispatch and the start of this one -- what a dependent kernel boundary costs after each producer (MI355X_MICROARCH.md price list,
-row `boundary`: 1.45-1.9 us + dirty bytes / 6 TB/s).  Usage: python tools/trace_gaps.py gpurun_out/<tag>"""
+row `boundary`: 1.45-1.9 us + dirty bytes / 6 TB/s; rocprofv3 7.x stamps a dispatch's start at the previous one's end when the
+launches are back to back, so the boundary is inside `dur` and the gaps read 0).  Usage: python tools/trace_gaps.py gpurun_out/<tag>"""
 import csv, glob, os, sys
 import numpy as np
 src = sys.argv[1]
@@ -23,4 +24,4 @@ print(f'{len(steps)} steps of {n} launches; medians in us; step = {np.median(dur
       f'(kernels {np.median(dur.sum(1)):.1f} + gaps {np.median(gap.sum(1)):.1f})')
 for j in range(n):
     r = rows[steps[-1][0] + j]
-    print(f'{j + 1:3d} gap {np.median(gap[:, j]):6.2f}  dur {np.median(dur[:, j]):7.2f}  grid {r.get("Grid_Size", "?"):>8s}  {r["Kernel_Name"][:100]}')
+    print(f'{j + 1:3d} gap {np.median(gap[:, j]):6.2f}  dur {np.median(dur[:, j]):7.2f}  grid {str(r.get("Grid_Size", r.get("Grid_Size_X", "?"))):>8s}  {r["Kernel_Name"][:100]}')
