@@ -15,7 +15,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$OUT/g*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'gemm_f32_kernel<128' not in r['Kernel_Name']: continue
+        if 'gemm_f32_kernel<128' not in r['Kernel_Name'] and 'gemm_f32_kernel<256' not in r['Kernel_Name']: continue
         acc[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in sorted(acc.items()):
     m = {c: sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:])) for c, v in d.items()}
