@@ -56,8 +56,12 @@ class PrimeDual:
             setattr(st, k, nv.ptr(getattr(self, k)))
         st.m, st.n, st.rho, st.epsilon = m, n, self.rho, self.epsilon
         self._state = st
-        # large squares: the 128x128x32 tile on 16 waves (tools/bench_prime_dual.py); small problems: the 64x64 default
-        self.gemm_cfg = (17 if min(m, n) >= 1024 else -1) if gemm_cfg is None else int(gemm_cfg)
+        # large squares: the fp32 products on the bf16 matrix pipe (gemm_f32.hip configurations 21 / 20: every element cut into three
+        # bf16 pieces, six MFMAs per product, fp32-level error): 241 against 139 TFLOP/s at N = 8192, 172 against 107 at 2048
+        # (tools/bench_prime_dual.py, profiles/r05_bench_prime_dual_bf16x3.log; gemm_cfg=17: the fp32 pipe's 128x128x32 tile);
+        # small problems: the 64x64 default
+        mn = min(m, n)
+        self.gemm_cfg = (21 if mn >= 3072 else 20 if mn >= 1024 else -1) if gemm_cfg is None else int(gemm_cfg)
         P = nv.gemm_problem
         self._t1 = [P(self.F, self.FKy, self.T1, n, n, m, n, n, n)]             # T1 [n,n] = F^T FKy        (TN)
         self._g1 = [P(self.FKy, self.T1, self.G1, m, n, n, n, n, n)]            # G1 [m,n] = FKy T1         (NN)

@@ -70,6 +70,31 @@ def test_prime_dual_vs_oracle(jam, m, n, delay, eps):
     assert np.isfinite(err) and abs(a - hist[-1]) < 2e-4 * abs(hist[-1])
 
 
+def test_prime_dual_large_products_on_the_bf16_pipe(jam):
+    """N >= 1024: the four products of an iteration run on the bf16 matrix pipe (three-piece cuts of every fp32 element,
+    gemm_f32.hip configuration 20; 21 from 3072).  40 iterations at 1280 x 1152 against the same iterations on the fp32 pipe
+    (gemm_cfg=17, the path the small-size tests pin to the oracle and the reference's goldens): the scaling factor iteration by
+    iteration and the final F."""
+    from jamie_amd.correspondence import PrimeDual
+    m, n = 1280, 1152
+    g = torch.Generator(device='cuda').manual_seed(3)
+    X, Y = torch.randn(m, 24, generator=g, device='cuda'), torch.randn(n, 16, generator=g, device='cuda')
+    Kx, Ky = torch.cdist(X, X), torch.cdist(Y, Y)
+    runs = {}
+    for cfg in (None, 17):
+        pd = PrimeDual(Kx, Ky, 24, 16, rho=10, epsilon=1e-3, delay=5, device='cuda', gemm_cfg=cfg)
+        assert pd.gemm_cfg == (20 if cfg is None else 17)
+        alphas = []
+        for _ in range(40):
+            pd.step()
+            alphas.append(float(pd.alpha.item()))
+        runs[cfg] = (np.array(alphas), pd.F.double().cpu().numpy())
+    np.testing.assert_allclose(runs[None][0], runs[17][0], rtol=2e-5)
+    assert np.isfinite(runs[None][1]).all()
+    assert _rel(runs[None][1], runs[17][1]) < 1e-4
+    assert PrimeDual(torch.zeros(4096, 4096, device='cuda'), torch.zeros(4096, 4096, device='cuda'), 8, 8, device='cuda').gemm_cfg == 21
+
+
 def test_prime_dual_is_deterministic(jam):
     from jamie_amd.correspondence import prime_dual
     g = np.load(os.path.join(GOLD, 'pd1_delay0.npz'))
