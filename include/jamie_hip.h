@@ -106,7 +106,7 @@ int jamie_gemm_f32(const jamie_gemm_problem* problems /*host*/, int count, int l
 /* Same with an explicit tile configuration (tuning / benchmarks); cfg < 0 = choose by shape.  Configurations 0-19 run on the fp32
  * matrix pipe (v_mfma_f32_32x32x2_f32).  Configurations 20 (128 x 128 tiles) and 21 (256 x 128) run the SAME fp32 problem on the bf16 matrix pipe: every fp32 element is cut
  * into three bf16 pieces (x = hi + mid + lo, exact) and a product is six v_mfma_f32_32x32x16_bf16 into an fp32 accumulator -- fp32
- * inputs, fp32 outputs, error at the level of an fp32 product's own rounding (dropped terms < 2^-23 |a||b|); non-finite inputs
+ * inputs, fp32 outputs, error at the level of an fp32 product's own rounding (dropped terms <= 2^-21, typically 2^-24 of |a||b|); non-finite inputs
  * give NaN.  Every layout and epilogue; problems whose operands are not 16-byte aligned with leading dimensions and extents that
  * are multiples of 4 take the fp32 pipe's configuration of the same tile (17 / 15) instead.  The engine's default for the large layers
  * in fp32 mode (reference: the `addmm` / `mm` dispatches of model.py:151-207 and their autograd). */

@@ -136,7 +136,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
 // its tile goes from the staging registers to LDS -- into three bf16 pieces by truncation, x = hi + mid + lo EXACTLY (8 + 8 + 8
 // significand bits; x - hi and (x - hi) - mid are exact in fp32), the LDS holds three bf16 planes per operand, and a k-block of 16
 // is six v_mfma_f32_32x32x16_bf16 into the one fp32 accumulator: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi (every bf16 x bf16
-// product is exact in fp32; the three dropped terms are below 2^-23 of |a||b|, the rounding level of an fp32 product itself).
+// product is exact in fp32; the three dropped terms are at most 2^-21 and typically 2^-24 of |a||b|: the rounding level of an fp32 product itself).
 // Non-finite inputs come out as NaN (inf - inf in the cut), where the fp32 pipe would give inf.  See the k-loop for the LDS image.
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int FAST, int TAG, bool MID = false, int X3 = 0>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN >= 16 && BM * BN <= 128 * 128 ? 8 : 1)))      // (16 waves of 32x32: two workgroups per CU)

@@ -561,3 +561,35 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2'], capture_output=True,
                        text=True, env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+def test_three_piece_cut_of_an_fp32_value_is_exact():
+    """The arithmetic fact gemm_f32.hip's configurations 20 / 21 rest on (restated in numpy): cutting an fp32 value by
+    truncation -- hi = x with its low 16 bits cleared, mid = (x - hi) likewise, lo = (x - hi) - mid -- gives three bf16
+    values (low 16 bits zero) whose sum is x EXACTLY; both subtractions are exact in fp32.  Every bf16 x bf16 product is exact
+    in fp32 (8 x 8 significand bits), and the three products the kernels drop (mid lo, lo mid, lo lo) are at most 2^-21 and typically 2^-24 of |a||b| (an fp32 product's own rounding is 2^-24)."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200000) * np.exp(8 * rng.standard_normal(200000))).astype(np.float32)
+    x = np.concatenate([x, np.float32([0.0, -0.0, 1.0, -1.0, 3.0e38, 1.2e-30, 1 + 2 ** -23, 255.99998])])
+
+    def trunc(v):
+        return (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    hi = trunc(x)
+    r1 = (x - hi).astype(np.float32)
+    assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - hi.astype(np.float64))        # exact subtraction
+    mid = trunc(r1)
+    r2 = (r1 - mid).astype(np.float32)
+    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - mid.astype(np.float64))
+    lo = trunc(r2)
+    assert np.array_equal(lo, r2)                                                                          # nothing left behind
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    for piece in (hi, mid, lo):
+        assert not (piece.view(np.uint32) & np.uint32(0xFFFF)).any()                                       # representable in bf16
+    nz = x != 0
+    assert (np.abs(mid[nz]) <= np.abs(x[nz]) * 2.0 ** -7).all() and (np.abs(lo[nz]) <= np.abs(x[nz]) * 2.0 ** -15).all()
+    # the dropped terms of a product, relative to |a||b|
+    a, b = x[:100000], x[100000:200000]
+    am, al, bm, bl = mid[:100000].astype(np.float64), lo[:100000].astype(np.float64), mid[100000:200000].astype(np.float64), lo[100000:200000].astype(np.float64)
+    dropped = np.abs(am * bl + al * bm + al * bl)
+    scale = np.abs(a.astype(np.float64) * b.astype(np.float64))
+    ok = scale > 0
+    assert (dropped[ok] <= scale[ok] * 2.0 ** -21).all() and np.median(dropped[ok] / scale[ok]) < 2.0 ** -24
